@@ -1,0 +1,467 @@
+"""Generates the golden fixtures in this directory FROM THE REFERENCE ITSELF.
+
+Run only in the build container, where the reference is mounted read-only at
+/root/reference:
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_goldens.py
+
+The reference is imported (never copied); five third-party modules that are absent
+from the image (cv2, scenepic, progress, numba, trimesh) are replaced by inert
+stand-ins in ``sys.modules`` -- none of them is on the arithmetic captured below
+(RGB colour space only, no Dilate mode, hand-built camera poses instead of
+``orbit``).  Outputs are plain ``.npz`` data: inputs and the reference's outputs.
+Versions used are recorded in ``meta.npz``.
+"""
+
+import os
+import sys
+import types
+
+import numpy as np
+
+REFERENCE = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _install_stubs():
+    class _Absorb:
+        def __init__(self, *a, **k):
+            pass
+
+        def __getattr__(self, name):
+            return _Absorb()
+
+        def __call__(self, *a, **k):
+            return _Absorb()
+
+    cv2 = types.ModuleType("cv2")
+    cv2.COLOR_YCrCB2RGB = 0
+    cv2.COLOR_RGB2YCrCb = 1
+    cv2.MORPH_ELLIPSE = 2
+    cv2.INTER_AREA = 3
+
+    def _disk(_, size):
+        r = size[0] // 2
+        yy, xx = np.mgrid[-r:r + 1, -r:r + 1]
+        return (xx * xx + yy * yy <= r * r).astype(np.uint8)
+
+    def _dilate(mask, element):
+        from scipy.ndimage import binary_dilation
+        return binary_dilation(mask > 0, structure=element > 0).astype(np.uint8)
+
+    cv2.getStructuringElement = _disk
+    cv2.dilate = _dilate
+    sys.modules["cv2"] = cv2
+
+    sp = types.ModuleType("scenepic")
+    for name in ["Scene", "Camera", "Transforms", "Colors", "Shading", "Mesh", "Canvas3D"]:
+        setattr(sp, name, _Absorb())
+    sys.modules["scenepic"] = sp
+
+    progress = types.ModuleType("progress")
+    bar = types.ModuleType("progress.bar")
+
+    class Bar:
+        def __init__(self, *a, **k):
+            pass
+
+        def next(self, *a, **k):
+            pass
+
+        def finish(self):
+            pass
+
+        def writeln(self, line):
+            pass
+
+    bar.Bar = Bar
+    bar.ChargingBar = Bar
+    progress.bar = bar
+    sys.modules["progress"] = progress
+    sys.modules["progress.bar"] = bar
+
+    numba = types.ModuleType("numba")
+    numba.njit = lambda *a, **k: (a[0] if a and callable(a[0]) else (lambda f: f))
+    sys.modules["numba"] = numba
+    sys.modules["trimesh"] = types.ModuleType("trimesh")
+
+
+def formula_fill(shape, salt):
+    """Portable deterministic weights: integer hash -> exact float32 in [-b, b),
+    b = 1/sqrt(fan_in).  Tests regenerate full-size model weights with this."""
+    n = int(np.prod(shape))
+    fan_in = shape[-1] if len(shape) > 1 else shape[0]
+    h = (np.arange(n, dtype=np.uint64) * np.uint64(2654435761) + np.uint64(salt * 40503 + 12345))
+    h = (h % np.uint64(2 ** 32)) >> np.uint64(8)
+    vals = (h.astype(np.float64) / 2 ** 24 * 2 - 1) / np.sqrt(fan_in)
+    return vals.astype(np.float32).reshape(shape)
+
+
+def look_at_camera(eye, width, height, fov_deg=40.0):
+    """Hand-built camera-to-world (x right, y down, z forward) looking at the origin."""
+    eye = np.asarray(eye, np.float32)
+    fwd = -eye / np.linalg.norm(eye)
+    up = np.array([0, 1, 0], np.float32)
+    if abs(np.dot(fwd, up)) > 0.95:
+        up = np.array([1, 0, 0], np.float32)
+    right = np.cross(fwd, up)
+    right /= np.linalg.norm(right)
+    down = np.cross(fwd, right)
+    ext = np.eye(4, dtype=np.float32)
+    ext[:3, 0], ext[:3, 1], ext[:3, 2], ext[:3, 3] = right, down, fwd, eye
+    focal = 0.5 * width / np.tan(0.5 * np.deg2rad(fov_deg))
+    intr = np.array([[focal, 0, width / 2], [0, focal, height / 2], [0, 0, 1]], np.float32)
+    return intr, ext
+
+
+def scene_npz(path, num_cameras=6, size=16, seed=3):
+    """Tiny analytic RGBA dataset in the reference's NPZ schema (README.md:133-139)."""
+    rng = np.random.RandomState(seed)
+    intr, ext, images = [], [], []
+    for c in range(num_cameras):
+        ang = 2 * np.pi * c / num_cameras
+        eye = [3.2 * np.cos(ang), 1.0 + 0.3 * np.sin(3 * ang), 3.2 * np.sin(ang)]
+        k_mat, e_mat = look_at_camera(eye, size, size)
+        intr.append(k_mat)
+        ext.append(e_mat)
+        yy, xx = np.mgrid[0:size, 0:size]
+        rr = np.hypot(xx - size / 2, yy - size / 2)
+        img = np.zeros((size, size, 4), np.uint8)
+        hit = rr < size * 0.33
+        img[..., 0] = np.where(hit, 40 + 20 * c, 0)
+        img[..., 1] = np.where(hit, (xx * 255 // size), 0)
+        img[..., 2] = np.where(hit, (yy * 255 // size), 0)
+        img[..., 3] = np.where(hit, 255, 0)
+        img[..., :3] += (rng.randint(0, 3, (size, size, 3)) * hit[..., None]).astype(np.uint8)
+        images.append(img)
+    np.savez(path, images=np.stack(images), intrinsics=np.stack(intr),
+             extrinsics=np.stack(ext), bounds=(np.eye(4) * 2).astype(np.float32),
+             split_counts=np.array([num_cameras - 2, 1, 1], np.int32))
+
+
+def main():
+    _install_stubs()
+    sys.path.insert(0, REFERENCE)
+    sys.dont_write_bytecode = True
+    import torch
+    import torch.nn.functional as F
+    import fourier_feature_nets as ffn
+    from fourier_feature_nets.ray_sampler import _determine_cdf
+    from fourier_feature_nets import utils as ref_utils
+    import contextlib
+    import io
+
+    np.savez(os.path.join(OUT, "meta.npz"), torch=torch.__version__, numpy=np.__version__,
+             reference="matajoh/fourier_feature_nets v1.0.0")
+
+    # ---------------- 1. raygen + near/far (a1, a2) -------------------------
+    W, H = 20, 16
+    cams, intr, ext = [], [], []
+    eyes = [[0.3, 0.2, -4.0], [2.5, 1.5, 2.5], [-3.0, 0.4, 1.0]]
+    for i, eye in enumerate(eyes):
+        k_mat, e_mat = look_at_camera(eye, W, H)
+        intr.append(k_mat)
+        ext.append(e_mat)
+        cams.append(ffn.CameraInfo.create("c%d" % i, ffn.Resolution(W, H), k_mat, e_mat))
+    out = {}
+    for tag, bounds in [("eye2", (np.eye(4) * 2).astype(np.float32)),
+                        ("scale2", np.diag([2, 2, 2, 1]).astype(np.float32))]:
+        with contextlib.redirect_stdout(io.StringIO()):
+            smp = ffn.RaySampler(bounds, cams, 8)
+        out["starts_" + tag] = smp.starts.numpy()
+        out["directions_" + tag] = smp.directions.numpy()
+        out["near_far_" + tag] = smp.near_far.numpy()
+        out["invalid_" + tag] = np.array(sorted(smp.invalid_rays), np.int64)
+        out["bounds_" + tag] = bounds
+    np.savez(os.path.join(OUT, "raygen.npz"), intrinsics=np.stack(intr),
+             extrinsics=np.stack(ext), width=W, height=H, **out)
+
+    # ---------------- 2. sampling (a4) ---------------------------------------
+    bounds = (np.eye(4) * 2).astype(np.float32)
+    S = 16
+    out = {}
+    with contextlib.redirect_stdout(io.StringIO()):
+        smp_u = ffn.RaySampler(bounds, cams, S, False, None, 4096, 0.2, 2000)
+        smp_s = ffn.RaySampler(bounds, cams, S, True, None, 4096, 0.2, 2000)
+    valid = smp_u.to_valid(list(range(len(smp_u))))
+    rng = np.random.RandomState(5)
+    idx = rng.choice(valid, 96, replace=False).tolist()
+    out["idx"] = np.array(idx, np.int64)
+    out["linspace01"] = torch.linspace(0, 1, S).numpy()
+    for step in [None, 0, 500, 5000]:
+        key = "none" if step is None else str(step)
+        rs = smp_u.sample(idx, step)
+        out["u_t_" + key] = rs.t_values.numpy()
+        out["u_pos_" + key] = rs.positions.numpy()
+        out["u_view_" + key] = rs.view_directions.numpy()
+        out["u_rays_" + key] = rs.rays.numpy()
+        torch.manual_seed(100 + (0 if step is None else step))
+        noise = torch.rand((len(idx), S), dtype=torch.float32)
+        torch.manual_seed(100 + (0 if step is None else step))
+        rs = smp_s.sample(idx, step)
+        out["s_noise_" + key] = noise.numpy()
+        out["s_t_" + key] = rs.t_values.numpy()
+        out["s_pos_" + key] = rs.positions.numpy()
+    out["to_valid_in"] = np.arange(0, len(smp_u), 7, dtype=np.int64)
+    out["to_valid_out"] = np.array(smp_u.to_valid(out["to_valid_in"].tolist()), np.int64)
+    np.savez(os.path.join(OUT, "sampling.npz"), **out)
+
+    # ---------------- 3. focus sampling (a5) ---------------------------------
+    torch.manual_seed(11)
+    vox = ffn.Voxels(8, 1.0)
+    with torch.no_grad():
+        vox.voxels.copy_(torch.randn_like(vox.voxels) * 2)
+    out = {"voxels": vox.voxels.detach().numpy(), "vox_bias": vox.bias.detach().numpy()}
+    for strat in [False, True]:
+        with contextlib.redirect_stdout(io.StringIO()):
+            smp_f = ffn.RaySampler(bounds, cams, S, strat, vox, 64, 0.5, 0)
+        tag = "s" if strat else "u"
+        out["cdfs"] = smp_f.cdfs.numpy()
+        torch.manual_seed(21)
+        if strat:
+            n_u = S // 2
+            noise = torch.rand((len(idx), n_u), dtype=torch.float32)
+            fu = torch.rand((len(idx), S - n_u), dtype=torch.float32)
+            out["noise_s"] = noise.numpy()
+            out["focus_u_s"] = fu.numpy()
+            torch.manual_seed(21)
+        rs = smp_f.sample(idx, None)
+        out["t_" + tag] = rs.t_values.numpy()
+        out["pos_" + tag] = rs.positions.numpy()
+    # the opacity probe the sampler feeds the coarse model (for the CDF restatement)
+    near, far = smp_f.near_far[:, :W * H]
+    tv = ref_utils.linspace(near, far, S - S // 2)
+    pos = smp_f.starts[:W * H].unsqueeze(1) + tv.unsqueeze(2) * smp_f.directions[:W * H].unsqueeze(1)
+    with torch.no_grad():
+        op = F.softplus(vox(pos.reshape(-1, 3))[:, -1]).reshape(W * H, -1)
+    out["probe_t"] = tv.numpy()
+    out["probe_opacity"] = op.numpy()
+    out["probe_cdf"] = _determine_cdf(tv, op).numpy()
+    np.savez(os.path.join(OUT, "focus.npz"), **out)
+
+    # ---------------- 4. models (a8, a9) --------------------------------------
+    torch.manual_seed(20080524)
+    x = torch.rand(257, 3) * 2 - 1
+    v = torch.randn(257, 3)
+    v = v / v.norm(dim=-1, keepdim=True)
+    out = {"x": x.numpy(), "v": v.numpy()}
+    models = {
+        "mlp": lambda: ffn.MLP(3, 4, num_channels=64),
+        "basic": lambda: ffn.BasicFourierMLP(3, 4, num_channels=64),
+        "positional": lambda: ffn.PositionalFourierMLP(3, 4, 5.5),
+        "gaussian": lambda: ffn.GaussianFourierMLP(3, 4, 6.05, num_channels=64,
+                                                   embedding_size=48),
+        "nerf": lambda: ffn.NeRF(8, 256, 9, 10, 3, 4, [4], True),
+        "nerf_small": lambda: ffn.NeRF(4, 64, 5, 6, 2, 3, [2], False),
+    }
+    full_size = {"positional", "nerf"}
+    for name, make in models.items():
+        torch.manual_seed(77)
+        model = make()
+        if name in full_size:
+            # full-size models: weights come from the closed-form fill below so the
+            # fixture only has to carry outputs (tests regenerate the same weights)
+            with torch.no_grad():
+                for salt, (key, par) in enumerate(model.named_parameters()):
+                    if par.requires_grad:
+                        par.copy_(torch.from_numpy(formula_fill(tuple(par.shape), salt)))
+        sd = model.state_dict()
+        for key, val in sd.items():
+            if name in full_size and not (key.endswith("encoding") or key.endswith("_values")):
+                continue
+            out["%s/%s" % (name, key)] = val.numpy()
+        out["%s/keys" % name] = np.array(list(sd.keys()))
+        out["%s/shapes" % name] = np.array([str(tuple(v.shape)) for v in sd.values()])
+        model.zero_grad()
+        y = model(x, v) if model.use_view else model(x)
+        out["%s/out" % name] = y.detach().numpy()
+        # gradient of a fixed scalar functional wrt every parameter
+        probe = torch.linspace(-1, 1, y.numel()).reshape(y.shape)
+        (y * probe).sum().backward()
+        for key, par in model.named_parameters():
+            if par.requires_grad:
+                if name in full_size and par.numel() > 20000:
+                    out["%s/gradsum/%s" % (name, key)] = par.grad.double().sum().numpy()
+                    out["%s/gradabs/%s" % (name, key)] = par.grad.double().abs().sum().numpy()
+                    out["%s/gradhead/%s" % (name, key)] = par.grad.reshape(-1)[:512].numpy()
+                else:
+                    out["%s/grad/%s" % (name, key)] = par.grad.numpy()
+        path = os.path.join(OUT, "_tmp_model.pt")
+        model.save(path)
+        loaded = ffn.load_model(path)
+        y2 = loaded(x, v) if loaded.use_view else loaded(x)
+        assert torch.equal(y2, y.detach())
+        saved = torch.load(path)
+        out["%s/saved_type" % name] = np.array(saved["type"])
+        os.remove(path)
+    np.savez(os.path.join(OUT, "models.npz"), **out)
+
+    # ---------------- 5. compositing + render + grads (a10, a11) --------------
+    torch.manual_seed(5)
+    R, S2 = 48, 16
+    t = torch.sort(torch.rand(R, S2) * 4 + 2, -1)[0]
+    logits = torch.randn(R, S2, 4) * 3
+    logits[0, :, 3] = -40.0          # sigma ~ 0  -> ties in minimum, alpha < 0.1
+    logits[1, :, 3] = 30.0           # huge sigma -> alpha == 1 early
+    logits[2, 5:, 3] = 25.0
+    logits[3, :, 3] = -5.0
+    logits = logits.requires_grad_(True)
+
+    class _Const(torch.nn.Module):
+        use_view = False
+
+        def __init__(self, value):
+            super().__init__()
+            self.value = value
+            self.w = torch.nn.Parameter(torch.zeros(1))
+
+        def forward(self, positions):
+            return self.value.reshape(-1, 4) + 0 * self.w
+
+    caster = ffn.Raycaster(_Const(logits))
+    rs = ffn.RaySamples(torch.zeros(R, S2, 3), torch.zeros(R, S2, 3), t, torch.arange(R))
+    rr = caster.render(rs, True)
+    sig = F.softplus(logits[..., 3])
+    w = ffn.calculate_blend_weights(t, sig)
+    gt_c = torch.rand(R, 3)
+    gt_a = (torch.rand(R) > 0.4).float()
+    loss = (gt_c - rr.color).square().mean() + 0.1 * (gt_a - rr.alpha).square().mean()
+    loss.backward()
+    np.savez(os.path.join(OUT, "composite.npz"), t=t.numpy(), logits=logits.detach().numpy(),
+             weights=w.detach().numpy(), color=rr.color.detach().numpy(),
+             alpha=rr.alpha.detach().numpy(), depth=rr.depth.detach().numpy(),
+             gt_color=gt_c.numpy(), gt_alpha=gt_a.numpy(), loss=loss.detach().numpy(),
+             dlogits=logits.grad.numpy())
+
+    # ---------------- 6/8. dataset index modes, loss, to_image ----------------
+    scene = os.path.join(OUT, "scene16.npz")
+    scene_npz(scene)
+    with contextlib.redirect_stdout(io.StringIO()):
+        ds = ffn.ImageDataset.load(scene, "train", 8, True, False)
+        ds400 = None
+    out = {"crop_index": ds.crop_index.numpy(), "sparse_index": ds.sparse_index.numpy(),
+           "colors": ds.colors.numpy(), "alphas": ds.alphas.numpy(),
+           "invalid": np.array(sorted(ds.sampler.invalid_rays), np.int64),
+           "len_full": len(ds)}
+    ds.mode = ffn.RayDataset.Mode.Center
+    out["len_center"] = len(ds)
+    rs = ds.get_rays(list(range(0, len(ds), 3)), None)
+    out["center_rays"] = rs.rays.numpy()
+    ds.mode = ffn.RayDataset.Mode.Sparse
+    out["len_sparse"] = len(ds)
+    rs = ds.get_rays(list(range(0, len(ds), 5)), None)
+    out["sparse_rays"] = rs.rays.numpy()
+    ds.mode = ffn.RayDataset.Mode.Full
+    rs = ds.get_rays(list(range(0, len(ds), 11)), None)
+    gt = ds.render(rs)
+    out["full_rays"] = rs.rays.numpy()
+    out["gt_color"] = gt.color.numpy()
+    out["gt_alpha"] = gt.alpha.numpy()
+    torch.manual_seed(9)
+    pred = ref_utils.RenderResult(torch.rand_like(gt.color), torch.rand_like(gt.alpha), None)
+    out["pred_color"] = pred.color.numpy()
+    out["pred_alpha"] = pred.alpha.numpy()
+    out["loss_rgba"] = ds.loss(0, rs, pred).numpy()
+    ds.alpha_weight = 0
+    out["loss_rgb"] = ds.loss(0, rs, pred).numpy()
+    ds.alpha_weight = 0.1
+    cam_rs = ds.sampler.rays_for_camera(1)
+    cols = np.linspace(0, 1.2, len(cam_rs.rays) * 3, dtype=np.float32).reshape(-1, 3)
+    cols[::7] = 0.9999
+    with np.errstate(invalid="ignore"):
+        out["to_image_colors"] = cols
+        out["to_image_rays"] = cam_rs.rays.numpy()
+        out["to_image"] = ds.sampler.to_image(1, cols, "RGB")
+    # closed-form index sets at the real 400x400 size: lengths + checksums only
+    big = np.zeros((1, 400, 400, 4), np.uint8)
+    big[..., 3] = 255
+    k_mat, e_mat = look_at_camera([0, 0.5, -4], 400, 400)
+    with contextlib.redirect_stdout(io.StringIO()):
+        ds400 = ffn.ImageDataset("big", big, bounds,
+                                 [ffn.CameraInfo.create("b", ffn.Resolution(400, 400), k_mat, e_mat)],
+                                 8)
+    out["crop400_len"] = len(ds400.crop_index)
+    out["crop400_sum"] = int(ds400.crop_index.sum())
+    out["sparse400_len"] = len(ds400.sparse_index)
+    out["sparse400_sum"] = int(ds400.sparse_index.sum())
+    out["sparse400_head"] = ds400.sparse_index[:64].numpy()
+    np.savez(os.path.join(OUT, "dataset.npz"), **out)
+
+    # ---------------- 7. lr table + short fit trajectory (a14) ----------------
+    class _Opt:
+        param_groups = [{"lr": 0.0}]
+
+    lrs = []
+    for step in [0, 1, 10, 1000, 25000, 50000]:
+        ffn.exponential_lr_decay(_Opt, 5e-4, step, 0.1, 25000)
+        lrs.append(_Opt.param_groups[0]["lr"])
+    out = {"lr_steps": np.array([0, 1, 10, 1000, 25000, 50000]), "lr_values": np.array(lrs)}
+
+    # three optimiser steps of clip + Adam on a small problem, state captured
+    torch.manual_seed(13)
+    par = [torch.nn.Parameter(torch.randn(7, 5)), torch.nn.Parameter(torch.randn(7))]
+    init = [p.detach().clone().numpy() for p in par]
+    opt = torch.optim.Adam(par, 5e-4, weight_decay=1e-3)
+    grads_log, par_log = [], []
+    for it in range(3):
+        opt.zero_grad()
+        g0 = torch.randn(7, 5) * (0.5 if it else 0.05)
+        g1 = torch.randn(7) * 0.01
+        par[0].grad = g0.clone()
+        par[1].grad = g1.clone()
+        grads_log.append([g0.numpy(), g1.numpy()])
+        torch.nn.utils.clip_grad_value_(par, 0.1)
+        torch.nn.utils.clip_grad_norm_(par, 0.1)
+        ffn.exponential_lr_decay(opt, 5e-4, it, 0.1, 25000)
+        opt.step()
+        par_log.append([p.detach().clone().numpy() for p in par])
+    out["adam_init0"], out["adam_init1"] = init
+    for it in range(3):
+        out["adam_g0_%d" % it], out["adam_g1_%d" % it] = grads_log[it]
+        out["adam_p0_%d" % it], out["adam_p1_%d" % it] = par_log[it]
+
+    # 12-step fit in Center mode; both RNGs seeded; per-step losses captured by
+    # wrapping the dataset loss.  (The reference _validate crashes on datasets
+    # with <102400 rays in Full mode, so the run stays inside the crop phase.)
+    torch.manual_seed(20080524)
+    np.random.seed(20080524)
+    model = ffn.PositionalFourierMLP(3, 4, 5.5, num_channels=64, embedding_size=48)
+    init_state = {k: v.clone().numpy() for k, v in model.state_dict().items()}
+    with contextlib.redirect_stdout(io.StringIO()):
+        train = ffn.ImageDataset.load(scene, "train", 16, True, True,
+                                      anneal_start=0.2, num_anneal_steps=8)
+        val = ffn.ImageDataset.load(scene, "val", 16, True, False)
+    # re-seed both generators right before fit() so a test can replay the exact
+    # permutation / stratified-noise streams without re-creating the model init draws
+    torch.manual_seed(4242)
+    np.random.seed(4242)
+    losses = []
+    orig_loss = ffn.ImageDataset.loss
+
+    def spy(self, step, rays, render):
+        value = orig_loss(self, step, rays, render)
+        if torch.is_grad_enabled() and value.requires_grad:
+            losses.append(float(value))
+        return value
+
+    ffn.ImageDataset.loss = spy
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        log = ffn.Raycaster(model).fit(train, val, 64, 5e-4, 11, 1000, 4, 0.1, 25000, 0.0, [],
+                                       disable_aml=True)
+    ffn.ImageDataset.loss = orig_loss
+    out["fit_losses"] = np.array(losses, np.float64)
+    out["fit_stdout"] = np.array(buf.getvalue())
+    out["fit_log_steps"] = np.array([e.step for e in log])
+    out["fit_log_train_psnr"] = np.array([e.train_psnr for e in log])
+    out["fit_log_val_psnr"] = np.array([e.val_psnr for e in log])
+    for key, val_t in model.state_dict().items():
+        out["fit_final/" + key] = val_t.numpy()
+    for key, val_t in init_state.items():
+        out["fit_init/" + key] = val_t
+    np.savez(os.path.join(OUT, "training.npz"), **out)
+    print("goldens written to", OUT)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,324 @@
+"""Pins the CPU oracle (oracle/ffn_oracle.py) to fixtures generated from the reference.
+
+No GPU needed.  Bit equality is asserted wherever the reference arithmetic is a fixed
+sequence of IEEE ops (ray state, t-values, positions, indices); everything that sits
+behind a GEMM or a transcendental is compared with a stated tolerance.
+"""
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ffn_oracle as orc
+from tests.helpers import formula_fill
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+# ----------------------------------------------------------------------------- a1/a2
+@pytest.mark.parametrize("tag", ["eye2", "scale2"])
+def test_ray_state_bit_exact(golden, tag):
+    g = golden("raygen")
+    st = orc.sampler_state(g["bounds_" + tag], g["intrinsics"], g["extrinsics"],
+                           int(g["width"]), int(g["height"]))
+    assert np.array_equal(st["starts"].numpy(), g["starts_" + tag])
+    assert np.array_equal(st["directions"].numpy(), g["directions_" + tag])
+    assert np.array_equal(st["near_far"].numpy(), g["near_far_" + tag], equal_nan=True)
+    assert np.array_equal(st["invalid"], g["invalid_" + tag])
+    assert 0 < len(st["invalid"]) < st["num_rays"]
+
+
+# ----------------------------------------------------------------------------- a4
+def _state(golden):
+    g = golden("raygen")
+    return orc.sampler_state(g["bounds_eye2"], g["intrinsics"], g["extrinsics"],
+                             int(g["width"]), int(g["height"]))
+
+
+@pytest.mark.parametrize("step", [None, 0, 500, 5000])
+def test_uniform_sampling_bit_exact(golden, step):
+    g = golden("sampling")
+    key = "none" if step is None else str(step)
+    pos, view, t, rays = orc.sample(_state(golden), g["idx"], step, 16, 0.2, 2000)
+    assert np.array_equal(t.numpy(), g["u_t_" + key])
+    assert np.array_equal(pos.numpy(), g["u_pos_" + key])
+    assert np.array_equal(view.numpy(), g["u_view_" + key])
+    assert np.array_equal(rays.numpy(), g["u_rays_" + key])
+    assert rays.dtype == torch.int64
+
+
+@pytest.mark.parametrize("step", [None, 0, 500, 5000])
+def test_stratified_sampling_bit_exact(golden, step):
+    g = golden("sampling")
+    key = "none" if step is None else str(step)
+    pos, _, t, _ = orc.sample(_state(golden), g["idx"], step, 16, 0.2, 2000,
+                              noise=_t(g["s_noise_" + key]))
+    assert np.array_equal(t.numpy(), g["s_t_" + key])
+    assert np.array_equal(pos.numpy(), g["s_pos_" + key])
+
+
+def test_to_valid_set(golden):
+    g = golden("sampling")
+    st = _state(golden)
+    bad = set(st["invalid"].tolist())
+    kept = [i for i in g["to_valid_in"].tolist() if i not in bad]
+    assert kept == g["to_valid_out"].tolist()
+
+
+# ----------------------------------------------------------------------------- a5
+def test_cdf_and_focus_sampling(golden):
+    g = golden("focus")
+    s = golden("sampling")
+    cdf = orc.determine_cdf(_t(g["probe_t"]), _t(g["probe_opacity"]))
+    assert np.array_equal(cdf.numpy(), g["probe_cdf"])
+    st = _state(golden)
+    cdfs = _t(g["cdfs"])
+    n_focus = 16 - 8
+    u_lin = torch.linspace(0., 1., n_focus).unsqueeze(0).repeat(len(s["idx"]), 1)
+    pos, _, t, _ = orc.sample(st, s["idx"], None, 16, 0.5, 0, None, cdfs, u_lin)
+    assert np.array_equal(t.numpy(), g["t_u"])
+    assert np.array_equal(pos.numpy(), g["pos_u"])
+    pos, _, t, _ = orc.sample(st, s["idx"], None, 16, 0.5, 0, _t(g["noise_s"]), cdfs,
+                              _t(g["focus_u_s"]))
+    assert np.array_equal(t.numpy(), g["t_s"])
+    assert np.array_equal(pos.numpy(), g["pos_s"])
+
+
+# ----------------------------------------------------------------------------- a8/a9
+def _fourier_params(g, name):
+    keys = [str(k) for k in g[name + "/keys"]]
+    n_layers = len([k for k in keys if k.startswith("layers.") and k.endswith("weight")])
+    full = (name + "/layers.0.weight") not in g.files
+    ws, bs = [], []
+    shapes = {str(k): eval(str(s)) for k, s in zip(g[name + "/keys"], g[name + "/shapes"])} \
+        if (name + "/shapes") in g.files else {}
+    for i in range(n_layers):
+        for kind, dst in (("weight", ws), ("bias", bs)):
+            key = "layers.%d.%s" % (i, kind)
+            if full:
+                dst.append(_t(formula_fill(shapes[key], keys.index(key))))
+            else:
+                dst.append(_t(g["%s/%s" % (name, key)]))
+    a = _t(g[name + "/a_values"]) if (name + "/a_values") in g.files else None
+    b = _t(g[name + "/b_values"]) if (name + "/b_values") in g.files else None
+    return a, b, ws, bs
+
+
+@pytest.mark.parametrize("name", ["mlp", "basic", "positional", "gaussian"])
+def test_fourier_mlp_forward_and_grads(golden, name):
+    g = golden("models")
+    a, b, ws, bs = _fourier_params(g, name)
+    model = orc.OracleFourierMLP(a, b, ws, bs)
+    x = _t(g["x"])
+    y = model(x)
+    # same ATen ops in the same order as the reference => identical on one machine;
+    # the tolerance covers a different BLAS kernel choice on another host CPU
+    np.testing.assert_allclose(y.detach().numpy(), g[name + "/out"], rtol=2e-5, atol=2e-5)
+    probe = torch.linspace(-1, 1, y.numel()).reshape(y.shape)
+    (y * probe).sum().backward()
+    for i, (w, bias) in enumerate(zip(model.weights, model.biases)):
+        for kind, par in (("weight", w), ("bias", bias)):
+            key = "%s/grad/layers.%d.%s" % (name, i, kind)
+            if key in g.files:
+                np.testing.assert_allclose(par.grad.numpy(), g[key], rtol=2e-4, atol=2e-4)
+            else:
+                head = g["%s/gradhead/layers.%d.%s" % (name, i, kind)]
+                np.testing.assert_allclose(par.grad.reshape(-1)[:512].numpy(), head,
+                                           rtol=2e-4, atol=2e-4)
+                total = float(g["%s/gradsum/layers.%d.%s" % (name, i, kind)])
+                scale = float(g["%s/gradabs/layers.%d.%s" % (name, i, kind)])
+                assert abs(float(par.grad.double().sum()) - total) <= 1e-5 * scale
+
+
+def test_positional_b_values_layout(golden):
+    g = golden("models")
+    b = orc.positional_b_values(5.5, 256, 3)
+    assert b.shape == (3, 255)
+    assert np.array_equal(b.numpy(), g["positional/b_values"])
+    enc = orc.axis_frequency_matrix(9, 10)
+    assert np.array_equal(enc.numpy(), g["nerf/pos_encoding"])
+    assert np.array_equal(orc.axis_frequency_matrix(3, 4).numpy(), g["nerf/view_encoding"])
+
+
+def _nerf_params(g, name):
+    keys = [str(k) for k in g[name + "/keys"]]
+    shapes = {str(k): eval(str(s)) for k, s in zip(g[name + "/keys"], g[name + "/shapes"])}
+    full = (name + "/layers.0.weight") not in g.files
+    p = {}
+    for key in keys:
+        if key.endswith("encoding"):
+            p[key] = _t(g["%s/%s" % (name, key)])
+        elif full:
+            p[key] = _t(formula_fill(shapes[key], keys.index(key)))
+        else:
+            p[key] = _t(g["%s/%s" % (name, key)])
+    return p
+
+
+@pytest.mark.parametrize("name,skips,inc", [("nerf", [4], True), ("nerf_small", [2], False)])
+def test_nerf_forward_and_grads(golden, name, skips, inc):
+    g = golden("models")
+    model = orc.OracleNeRF(_nerf_params(g, name), skips, inc)
+    y = model(_t(g["x"]), _t(g["v"]))
+    np.testing.assert_allclose(y.detach().numpy(), g[name + "/out"], rtol=2e-5, atol=2e-5)
+    probe = torch.linspace(-1, 1, y.numel()).reshape(y.shape)
+    (y * probe).sum().backward()
+    checked = 0
+    for key, par in model.p.items():
+        if not par.requires_grad:
+            continue
+        full_key = "%s/grad/%s" % (name, key)
+        if full_key in g.files:
+            np.testing.assert_allclose(par.grad.numpy(), g[full_key], rtol=3e-4, atol=3e-4)
+            checked += 1
+        else:
+            head = g["%s/gradhead/%s" % (name, key)]
+            np.testing.assert_allclose(par.grad.reshape(-1)[:512].numpy(), head,
+                                       rtol=3e-4, atol=3e-4)
+    assert checked >= 8
+
+
+def test_state_dict_key_listing(golden):
+    g = golden("models")
+    keys = [str(k) for k in g["nerf/keys"]]
+    assert keys[:2] == ["pos_encoding", "view_encoding"]
+    assert "layers.4.weight" in keys and "hidden_view.weight" in keys
+    shapes = {str(k): eval(str(s)) for k, s in zip(g["nerf/keys"], g["nerf/shapes"])}
+    assert shapes["layers.0.weight"] == (256, 63)
+    assert shapes["layers.4.weight"] == (256, 319)
+    assert shapes["hidden_view.weight"] == (128, 283)
+    assert shapes["color_out.weight"] == (3, 128)
+    assert str(g["nerf/saved_type"]) == "nerf"
+    assert str(g["positional/saved_type"]) == "fourier"
+
+
+# ----------------------------------------------------------------------------- a10/a11/a12
+def test_blend_weights_render_and_gradient(golden):
+    g = golden("composite")
+    t = _t(g["t"])
+    logits = _t(g["logits"]).clone().requires_grad_(True)
+    sigma = torch.nn.functional.softplus(logits[..., 3])
+    w = orc.blend_weights(t, sigma)
+    assert np.array_equal(w.detach().numpy(), g["weights"])
+    color, alpha, depth = orc.render(logits, t, True)
+    assert np.array_equal(color.detach().numpy(), g["color"])
+    assert np.array_equal(alpha.detach().numpy(), g["alpha"])
+    assert np.array_equal(depth.numpy(), g["depth"])
+    # edge rows: empty ray reports the last t as depth
+    assert float(alpha[0].detach()) < 0.1 and float(depth[0]) == float(t[0, -1])
+    loss = orc.mse_loss(color, alpha, _t(g["gt_color"]), _t(g["gt_alpha"]), 0.1)
+    assert float(loss) == float(g["loss"])
+    loss.backward()
+    assert np.array_equal(logits.grad.numpy(), g["dlogits"])
+
+
+def test_dataset_loss_and_ground_truth(golden):
+    g = golden("dataset")
+    colors, alphas = _t(g["colors"]), _t(g["alphas"])
+    gc, ga = orc.ground_truth(colors, alphas, _t(g["full_rays"]))
+    assert np.array_equal(gc.numpy(), g["gt_color"])
+    assert np.array_equal(ga.numpy(), g["gt_alpha"])
+    pc, pa = _t(g["pred_color"]), _t(g["pred_alpha"])
+    assert float(orc.mse_loss(pc, pa, gc, ga, 0.1)) == float(g["loss_rgba"])
+    assert float(orc.mse_loss(pc, pa, gc, ga, 0.0)) == float(g["loss_rgb"])
+
+
+def test_index_modes(golden):
+    g = golden("dataset")
+    crop = orc.crop_points(16, 16)
+    sparse = orc.sparse_points(16, 16, 50)
+    n_cam = len(g["crop_index"]) // len(crop)
+    exp_crop = np.concatenate([crop + c * 256 for c in range(n_cam)])
+    exp_sparse = np.concatenate([sparse + c * 256 for c in range(n_cam)])
+    assert np.array_equal(exp_crop, g["crop_index"])
+    assert np.array_equal(exp_sparse, g["sparse_index"])
+    bad = set(g["invalid"].tolist())
+    center_sel = exp_crop[np.arange(0, int(g["len_center"]), 3)]
+    assert [i for i in center_sel.tolist() if i not in bad] == g["center_rays"].tolist()
+    sparse_sel = exp_sparse[np.arange(0, int(g["len_sparse"]), 5)]
+    assert [i for i in sparse_sel.tolist() if i not in bad] == g["sparse_rays"].tolist()
+    # closed form at the real image size
+    crop400 = orc.crop_points(400, 400)
+    assert len(crop400) == int(g["crop400_len"]) == 40000
+    assert int(crop400.sum()) == int(g["crop400_sum"])
+    sp400 = orc.sparse_points(400, 400, 50)
+    assert len(sp400) == int(g["sparse400_len"]) == 2500
+    assert int(sp400.sum()) == int(g["sparse400_sum"])
+    assert np.array_equal(sp400[:64], g["sparse400_head"])
+
+
+def test_to_image_truncates(golden):
+    g = golden("dataset")
+    local = g["to_image_rays"] - 256
+    with np.errstate(invalid="ignore"):
+        img = orc.to_image(local, g["to_image_colors"], 16, 16)
+    assert img.dtype == np.uint8
+    assert np.array_equal(img, g["to_image"])
+
+
+# ----------------------------------------------------------------------------- a14
+def test_lr_decay_table(golden):
+    g = golden("training")
+    for step, lr in zip(g["lr_steps"], g["lr_values"]):
+        assert orc.lr_decay(5e-4, int(step), 0.1, 25000) == float(lr)
+
+
+def test_clip_and_adam_match_torch(golden):
+    g = golden("training")
+    p = [_t(g["adam_init0"]).clone(), _t(g["adam_init1"]).clone()]
+    m = [torch.zeros_like(x) for x in p]
+    v = [torch.zeros_like(x) for x in p]
+    for it in range(3):
+        grads = [_t(g["adam_g0_%d" % it]).clone(), _t(g["adam_g1_%d" % it]).clone()]
+        orc.clip_gradients(grads, 0.1, 0.1)
+        lr = orc.lr_decay(5e-4, it, 0.1, 25000)
+        for k in range(2):
+            orc.adam_update(p[k], grads[k], m[k], v[k], it + 1, lr, weight_decay=1e-3)
+        np.testing.assert_allclose(p[0].numpy(), g["adam_p0_%d" % it], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(p[1].numpy(), g["adam_p1_%d" % it], rtol=1e-6, atol=1e-7)
+
+
+def test_fit_trajectory(golden):
+    """Replays the reference's 12-step fit() (Center mode, stratified, annealed) with
+    the oracle from the same inputs: init weights, numpy epoch permutations, torch
+    stratified-noise stream.  Per-step losses and final weights must agree."""
+    g = golden("training")
+    scene = golden("scene16")
+    n_train = int(scene["split_counts"][0])
+    st = orc.sampler_state(scene["bounds"], scene["intrinsics"][:n_train],
+                           scene["extrinsics"][:n_train], 16, 16)
+    crop = orc.crop_points(16, 16)
+    crop_index = np.concatenate([crop + c * 256 for c in range(n_train)])
+    bad = set(st["invalid"].tolist())
+    images = scene["images"][:n_train]
+    colors = _t(images[..., :3].astype(np.float32) / 255).reshape(-1, 3)
+    alphas = _t(images[..., 3].astype(np.float32) / 255).reshape(-1)
+    ws = [_t(g["fit_init/layers.%d.weight" % i]) for i in range(4)]
+    bs = [_t(g["fit_init/layers.%d.bias" % i]) for i in range(4)]
+    model = orc.OracleFourierMLP(_t(g["fit_init/a_values"]), _t(g["fit_init/b_values"]), ws, bs)
+    trainer = orc.OracleTrainer(model, 5e-4)
+    np.random.seed(4242)
+    torch.manual_seed(4242)
+    step, losses = 0, []
+    while step <= 11:
+        order = np.arange(len(crop_index))
+        np.random.shuffle(order)
+        for start in range(0, len(order), 64):
+            if step > 11:
+                break
+            batch = crop_index[order[start:start + 64]].tolist()
+            batch = [i for i in batch if i not in bad]
+            noise = torch.rand((len(batch), 16), dtype=torch.float32)
+            pos, view, t, rays = orc.sample(st, batch, step, 16, 0.2, 8, noise=noise)
+            gc, ga = orc.ground_truth(colors, alphas, rays)
+            losses.append(trainer.step(pos, view, t, gc, ga,
+                                       orc.lr_decay(5e-4, step, 0.1, 25000)))
+            step += 1
+    np.testing.assert_allclose(losses, g["fit_losses"], rtol=2e-5, atol=1e-7)
+    for i in range(4):
+        np.testing.assert_allclose(model.weights[i].detach().numpy(),
+                                   g["fit_final/layers.%d.weight" % i], rtol=1e-4, atol=2e-6)
+        np.testing.assert_allclose(model.biases[i].detach().numpy(),
+                                   g["fit_final/layers.%d.bias" % i], rtol=1e-4, atol=2e-6)
