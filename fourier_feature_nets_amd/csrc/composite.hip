@@ -1,0 +1,288 @@
+// Activations + front-to-back alpha compositing, forward and backward, and the MSE loss.
+//
+// One wavefront per ray.  Sample s of a ray lives on lane (s & 63) of "row" (s >> 6), so
+// every load is a coalesced 1 KiB (float4 logits) or 256 B (t) wave access, and the
+// exclusive transmittance product is a 6-step cross-lane scan per row with a scalar
+// carry between rows.  HBM-bound: 20*S bytes read + 20 bytes written per ray forward.
+#include "common.h"
+
+namespace ffn {
+
+__device__ __forceinline__ float softplus_torch(float x) {
+    // F.softplus, beta = 1, threshold = 20
+    return x > 20.0f ? x : log1pf(expf(x));
+}
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// inclusive multiplicative scan over the 64 lanes of a wave
+__device__ __forceinline__ float wave_scan_mul(float v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float up = __shfl_up(v, off, 64);
+        if (lane >= off) v *= up;
+    }
+    return v;
+}
+// inclusive additive suffix scan (lane i gets sum over lanes >= i)
+__device__ __forceinline__ float wave_suffix_add(float v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float dn = __shfl_down(v, off, 64);
+        if (lane + off < 64) v += dn;
+    }
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+struct SampleTerms {
+    float r, g, b;      // sigmoid(rgb logits)
+    float sigma_logit;  // raw
+    float delta, e, alpha, u, tau;
+};
+
+__device__ __forceinline__ SampleTerms load_terms(const float4* __restrict__ logits,
+                                                   const float* __restrict__ t, int s, int S,
+                                                   bool active, int32_t* nan_flag) {
+    SampleTerms o;
+    if (!active) {
+        o.r = o.g = o.b = 0.f; o.sigma_logit = 0.f; o.delta = 0.f; o.e = 1.f; o.alpha = 0.f;
+        o.u = 1.f; o.tau = 1.f;
+        return o;
+    }
+    const float4 l = logits[s];
+    o.r = sigmoid_f(l.x); o.g = sigmoid_f(l.y); o.b = sigmoid_f(l.z);
+    o.sigma_logit = l.w;
+    const float sigma = softplus_torch(l.w);
+    if (nan_flag != nullptr && (o.r != o.r || o.g != o.g || o.b != o.b || sigma != sigma))
+        atomicOr(nan_flag, 1);
+    o.delta = (s == S - 1) ? 1e10f : t[s + 1] - t[s];
+    o.e = expf(-(sigma * o.delta));
+    o.alpha = 1.0f - o.e;
+    o.u = (1.0f - o.alpha) + 1e-10f;
+    o.tau = o.u < 1.0f ? o.u : 1.0f;
+    return o;
+}
+
+// ---------------------------------------------------------------------------------- K5
+__global__ void __launch_bounds__(256)
+composite_fwd_kernel(const float4* __restrict__ logits, const float* __restrict__ t, int R, int S,
+                     float* __restrict__ color, float* __restrict__ alpha_out,
+                     float* __restrict__ depth, int32_t* nan_flag) {
+    const int lane = lane_id();
+    const int wave = (int)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6);
+    const int waves = (int)((gridDim.x * (int64_t)blockDim.x) >> 6);
+    const int rows = (S + 63) >> 6;
+    for (int ray = wave; ray < R; ray += waves) {
+        const float4* lg = logits + (int64_t)ray * S;
+        const float* tr = t + (int64_t)ray * S;
+        float carry = 1.0f;       // product of tau over all previous rows
+        float cr = 0.f, cg = 0.f, cb = 0.f, asum = 0.f;
+        float best_w = -1.0f;     // weights are >= 0, so -1 means "none yet"
+        int best_s = 0;
+        for (int row = 0; row < rows; ++row) {
+            const int s = row * 64 + lane;
+            const bool active = s < S;
+            const SampleTerms q = load_terms(lg, tr, s, S, active, nan_flag);
+            const float incl = wave_scan_mul(q.tau, lane);
+            float excl = __shfl_up(incl, 1, 64);
+            if (lane == 0) excl = 1.0f;
+            const float T = carry * excl;
+            const float w = q.alpha * T;
+            cr += w * q.r; cg += w * q.g; cb += w * q.b;
+            const bool inner = active && s < S - 1;
+            if (inner) {
+                asum += w;
+                if (w > best_w) { best_w = w; best_s = s; }
+            }
+            carry *= __shfl(incl, 63, 64);
+        }
+        cr = wave_sum(cr); cg = wave_sum(cg); cb = wave_sum(cb); asum = wave_sum(asum);
+        // argmax with first-occurrence tie break
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ow = __shfl_xor(best_w, off, 64);
+            const int os = __shfl_xor(best_s, off, 64);
+            if (ow > best_w || (ow == best_w && os < best_s)) { best_w = ow; best_s = os; }
+        }
+        if (lane == 0) {
+            color[ray * 3 + 0] = cr; color[ray * 3 + 1] = cg; color[ray * 3 + 2] = cb;
+            alpha_out[ray] = asum;
+            if (depth != nullptr) {
+                const int pick = (asum < 0.1f || best_w < 0.0f) ? S - 1 : best_s;
+                depth[ray] = tr[pick];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------- K5b
+// Recomputes the forward terms (cheaper than storing 12 B/sample) and walks the rows in
+// reverse to form Q_s = sum_{j>s} g_j w_j, the quantity cumprod's backward needs.
+template <int ROWS>
+__global__ void __launch_bounds__(256)
+composite_bwd_kernel(const float4* __restrict__ logits, const float* __restrict__ t,
+                     const float* __restrict__ d_color, const float* __restrict__ d_alpha,
+                     int R, int S, float4* __restrict__ d_logits) {
+    const int lane = lane_id();
+    const int wave = (int)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6);
+    const int waves = (int)((gridDim.x * (int64_t)blockDim.x) >> 6);
+    for (int ray = wave; ray < R; ray += waves) {
+        const float4* lg = logits + (int64_t)ray * S;
+        const float* tr = t + (int64_t)ray * S;
+        const float dcr = d_color[ray * 3 + 0], dcg = d_color[ray * 3 + 1], dcb = d_color[ray * 3 + 2];
+        const float da = d_alpha[ray];
+        SampleTerms q[ROWS];
+        float T[ROWS];
+        float carry = 1.0f;
+#pragma unroll
+        for (int row = 0; row < ROWS; ++row) {
+            const int s = row * 64 + lane;
+            q[row] = load_terms(lg, tr, s, S, s < S, nullptr);
+            const float incl = wave_scan_mul(q[row].tau, lane);
+            float excl = __shfl_up(incl, 1, 64);
+            if (lane == 0) excl = 1.0f;
+            T[row] = carry * excl;
+            carry *= __shfl(incl, 63, 64);
+        }
+        float tail = 0.0f;  // sum of g*w over all later rows
+#pragma unroll
+        for (int row = ROWS - 1; row >= 0; --row) {
+            const int s = row * 64 + lane;
+            const bool active = s < S;
+            const SampleTerms& p = q[row];
+            const float w = p.alpha * T[row];
+            const float g = active ? (dcr * p.r + dcg * p.g + dcb * p.b) + (s < S - 1 ? da : 0.0f)
+                                   : 0.0f;
+            const float gw = g * w;
+            const float incl = wave_suffix_add(gw, lane);
+            const float Q = (incl - gw) + tail;          // strictly-after sum
+            tail += __shfl(incl, 0, 64);
+            if (active) {
+                // tau = min(1, u): gradient 1 below the clamp, 1/2 on a tie, 0 above it
+                const float dtau_du = p.u < 1.0f ? 1.0f : (p.u == 1.0f ? 0.5f : 0.0f);
+                const float dL_dtau = (s < S - 1) ? Q / p.tau : 0.0f;
+                const float dL_dalpha = g * T[row] - dtau_du * dL_dtau;
+                const float dL_dsigma = dL_dalpha * p.e * p.delta;
+                const float x = p.sigma_logit;
+                const float z = expf(x);
+                const float dsig = x > 20.0f ? 1.0f : z / (z + 1.0f);   // softplus' as torch: z/(z+1)
+                float4 out;
+                out.x = w * dcr * p.r * (1.0f - p.r);
+                out.y = w * dcg * p.g * (1.0f - p.g);
+                out.z = w * dcb * p.b * (1.0f - p.b);
+                out.w = dL_dsigma * dsig;
+                d_logits[(int64_t)ray * S + s] = out;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------- K6
+__global__ void __launch_bounds__(256)
+mse_partial_kernel(const float* __restrict__ color, const float* __restrict__ alpha,
+                   const float* __restrict__ gt_colors, const float* __restrict__ gt_alphas,
+                   const int64_t* __restrict__ ray_index, int R, float color_scale,
+                   float alpha_scale, float* __restrict__ d_color, float* __restrict__ d_alpha,
+                   float* __restrict__ scratch) {
+    __shared__ float red[2][4];
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    float ec = 0.0f, ea = 0.0f;
+    if (r < R) {
+        const int64_t ray = ray_index[r];
+        float gr = gt_colors[ray * 3 + 0], gg = gt_colors[ray * 3 + 1], gb = gt_colors[ray * 3 + 2];
+        if (gt_alphas != nullptr) {
+            const float ga = gt_alphas[ray];
+            if (!(ga > 0.0f)) { gr = 0.f; gg = 0.f; gb = 0.f; }
+            const float diff = alpha[r] - ga;
+            ea = diff * diff;
+            if (d_alpha != nullptr) d_alpha[r] = alpha_scale * 2.0f * diff;
+        } else if (d_alpha != nullptr) {
+            d_alpha[r] = 0.0f;
+        }
+        const float d0 = color[r * 3 + 0] - gr, d1 = color[r * 3 + 1] - gg, d2 = color[r * 3 + 2] - gb;
+        ec = (d0 * d0 + d1 * d1) + d2 * d2;
+        if (d_color != nullptr) {
+            d_color[r * 3 + 0] = color_scale * 2.0f * d0;
+            d_color[r * 3 + 1] = color_scale * 2.0f * d1;
+            d_color[r * 3 + 2] = color_scale * 2.0f * d2;
+        }
+    }
+    ec = wave_sum(ec); ea = wave_sum(ea);
+    const int w = threadIdx.x >> 6;
+    if (lane_id() == 0) { red[0][w] = ec; red[1][w] = ea; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        scratch[blockIdx.x * 2 + 0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        scratch[blockIdx.x * 2 + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+}
+
+__global__ void __launch_bounds__(64)
+mse_final_kernel(const float* __restrict__ scratch, int blocks, float* __restrict__ sums) {
+    float ec = 0.0f, ea = 0.0f;
+    for (int i = threadIdx.x; i < blocks; i += 64) { ec += scratch[i * 2]; ea += scratch[i * 2 + 1]; }
+    ec = wave_sum(ec); ea = wave_sum(ea);
+    if (threadIdx.x == 0) { sums[0] = ec; sums[1] = ea; }
+}
+
+}  // namespace ffn
+
+using namespace ffn;
+
+static inline int ray_grid(int R) {
+    int64_t blocks = ((int64_t)R + 3) / 4;  // 4 waves (rays) per 256-thread block
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    return (int)(blocks < 1 ? 1 : blocks);
+}
+
+extern "C" int ffn_composite_fwd(const float* logits, const float* t, int num_rays,
+                                 int num_samples, float* color, float* alpha, float* depth,
+                                 int32_t* nan_flag, void* stream) {
+    if (num_rays == 0) return 0;
+    if (num_rays < 0 || num_samples < 1) return fail_arg("ffn_composite_fwd: shape");
+    hipLaunchKernelGGL(composite_fwd_kernel, dim3(ray_grid(num_rays)), dim3(256), 0,
+                       (hipStream_t)stream, (const float4*)logits, t, num_rays, num_samples, color,
+                       alpha, depth, nan_flag);
+    return check_launch("ffn_composite_fwd");
+}
+
+extern "C" int ffn_composite_bwd(const float* logits, const float* t, const float* d_color,
+                                 const float* d_alpha, int num_rays, int num_samples,
+                                 float* d_logits, void* stream) {
+    if (num_rays == 0) return 0;
+    if (num_rays < 0 || num_samples < 1) return fail_arg("ffn_composite_bwd: shape");
+    const int rows = (num_samples + 63) / 64;
+    const dim3 grid(ray_grid(num_rays)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define FFN_BWD(ROWS)                                                                          \
+    hipLaunchKernelGGL(composite_bwd_kernel<ROWS>, grid, block, 0, st, (const float4*)logits, t, \
+                       d_color, d_alpha, num_rays, num_samples, (float4*)d_logits)
+    switch (rows) {
+        case 1: FFN_BWD(1); break;
+        case 2: FFN_BWD(2); break;
+        case 3: FFN_BWD(3); break;
+        case 4: FFN_BWD(4); break;
+        case 5: case 6: case 7: case 8: FFN_BWD(8); break;
+        default: return fail_arg("ffn_composite_bwd: num_samples > 512");
+    }
+#undef FFN_BWD
+    return check_launch("ffn_composite_bwd");
+}
+
+extern "C" int ffn_mse_loss(const float* color, const float* alpha, const float* gt_colors,
+                            const float* gt_alphas, const int64_t* ray_index, int num_rays,
+                            float color_scale, float alpha_scale, float* sums, float* d_color,
+                            float* d_alpha, float* scratch, void* stream) {
+    if (num_rays <= 0) return fail_arg("ffn_mse_loss: empty batch");
+    const int blocks = (num_rays + 255) / 256;
+    hipLaunchKernelGGL(mse_partial_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, color,
+                       alpha, gt_colors, gt_alphas, ray_index, num_rays, color_scale, alpha_scale,
+                       d_color, d_alpha, scratch);
+    hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scratch, blocks,
+                       sums);
+    return check_launch("ffn_mse_loss");
+}

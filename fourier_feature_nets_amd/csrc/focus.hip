@@ -1,0 +1,178 @@
+// Opacity-guided ("focus") sampling: per-ray CDF build, inverse-transform sampling, and the
+// merge + sort with the uniform half.  One wavefront per ray; compiled with
+// -ffp-contract=off (the lerp arithmetic is bit-identical to the reference's op sequence,
+// the CDF itself differs from torch.cumsum only by summation order).
+#include "common.h"
+
+namespace ffn {
+
+__device__ __forceinline__ float scan_mul(float v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float up = __shfl_up(v, off, 64);
+        if (lane >= off) v *= up;
+    }
+    return v;
+}
+__device__ __forceinline__ float scan_add(float v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float up = __shfl_up(v, off, 64);
+        if (lane >= off) v += up;
+    }
+    return v;
+}
+
+// ---------------------------------------------------------------------------------- K2c
+// cdf = [0, cumsum(w[1:-1] + 1e-5) / sum], w = blend weights of the probe (n samples).
+template <int ROWS>
+__global__ void __launch_bounds__(256)
+cdf_build_kernel(const float* __restrict__ t_probe, const float* __restrict__ opacity,
+                 int64_t num_rays, int n, float* __restrict__ cdf) {
+    const int lane = lane_id();
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t ray = wave; ray < num_rays; ray += waves) {
+        const float* tr = t_probe + ray * n;
+        const float* op = opacity + ray * n;
+        float w[ROWS];
+        float carry = 1.0f;
+#pragma unroll
+        for (int row = 0; row < ROWS; ++row) {
+            const int s = row * 64 + lane;
+            float alpha = 0.0f, tau = 1.0f;
+            if (s < n) {
+                const float delta = (s == n - 1) ? 1e10f : tr[s + 1] - tr[s];
+                alpha = 1.0f - expf(-(op[s] * delta));
+                const float u = (1.0f - alpha) + 1e-10f;
+                tau = u < 1.0f ? u : 1.0f;
+            }
+            const float incl = scan_mul(tau, lane);
+            float excl = __shfl_up(incl, 1, 64);
+            if (lane == 0) excl = 1.0f;
+            w[row] = alpha * (carry * excl);
+            carry *= __shfl(incl, 63, 64);
+        }
+        // interior weights + 1e-5, running sum
+        float run[ROWS];
+        float base = 0.0f;
+#pragma unroll
+        for (int row = 0; row < ROWS; ++row) {
+            const int s = row * 64 + lane;
+            const float v = (s >= 1 && s <= n - 2) ? w[row] + 1e-5f : 0.0f;
+            const float incl = scan_add(v, lane);
+            run[row] = base + incl;
+            base += __shfl(incl, 63, 64);
+        }
+        const float total = base;
+        float* out = cdf + ray * (n - 1);
+        if (lane == 0) out[0] = 0.0f;
+#pragma unroll
+        for (int row = 0; row < ROWS; ++row) {
+            const int s = row * 64 + lane;
+            if (s >= 1 && s <= n - 2) out[s] = run[row] / total;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------- K2d
+// LDS per wave: cdf row (<=255), merged t row (<=256).
+__global__ void __launch_bounds__(256)
+focus_merge_kernel(const float* __restrict__ near_far, int64_t total_rays,
+                   const float* __restrict__ cdfs, const int64_t* __restrict__ ray_index,
+                   const float* __restrict__ u, const float* __restrict__ unit_focus, int R, int S,
+                   int n_focus, float* __restrict__ t_io) {
+    __shared__ float lds_cdf[4][256];
+    __shared__ float lds_t[4][256];
+    const int lane = lane_id();
+    const int wslot = threadIdx.x >> 6;
+    float* c = lds_cdf[wslot];
+    float* tv = lds_t[wslot];
+    const int wave = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int waves = (int)(((int64_t)gridDim.x * blockDim.x) >> 6);
+    const int width = n_focus - 1;
+    const int n_uniform = S - n_focus;
+    for (int r = wave; r < R; r += waves) {
+        const int64_t ray = ray_index[r];
+        const float near = near_far[ray];
+        const float far = near_far[total_rays + ray];
+        const float span = far - near;
+        for (int i = lane; i < width; i += 64) c[i] = cdfs[ray * width + i];
+        float* row = t_io + (int64_t)r * S;
+        for (int i = lane; i < n_uniform; i += 64) tv[i] = row[i];
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): LDS writes of this wave are done
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < n_focus; i += 64) {
+            const float uu = u[(int64_t)r * n_focus + i];
+            // searchsorted(right=True): number of cdf entries <= u (cdf is ascending)
+            int lo_b = 0, hi_b = width;
+            while (lo_b < hi_b) {
+                const int mid = (lo_b + hi_b) >> 1;
+                if (c[mid] <= uu) lo_b = mid + 1; else hi_b = mid;
+            }
+            const int k = lo_b;
+            const int lo = k - 1 > 0 ? k - 1 : 0;
+            const int hi = k < width - 1 ? k : width - 1;
+            const float c_lo = c[lo], c_hi = c[hi];
+            // bin centres of linspace(near, far, n_focus)
+            const float g_lo0 = near + unit_focus[lo] * span, g_lo1 = near + unit_focus[lo + 1] * span;
+            const float g_hi0 = near + unit_focus[hi] * span, g_hi1 = near + unit_focus[hi + 1] * span;
+            const float t_lo = 0.5f * (g_lo0 + g_lo1);
+            const float t_hi = 0.5f * (g_hi0 + g_hi1);
+            float denom = c_hi - c_lo;
+            if (denom < 1e-5f) denom = 1.0f;
+            const float frac = (uu - c_lo) / denom;
+            tv[n_uniform + i] = t_lo + frac * (t_hi - t_lo);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        // rank sort: position = #smaller + #equal-with-lower-index
+        for (int i = lane; i < S; i += 64) {
+            const float v = tv[i];
+            int rank = 0;
+            for (int j = 0; j < S; ++j) {
+                const float o = tv[j];
+                rank += (o < v || (o == v && j < i)) ? 1 : 0;
+            }
+            row[rank] = v;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+}  // namespace ffn
+
+using namespace ffn;
+
+extern "C" int ffn_cdf_build(const float* t_probe, const float* opacity, int64_t num_rays, int n,
+                             float* cdf, void* stream) {
+    if (num_rays == 0) return 0;
+    if (n < 3 || n > 256) return fail_arg("ffn_cdf_build: probe length must be in [3,256]");
+    int64_t blocks = (num_rays + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    const dim3 grid((int)blocks), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    const int rows = (n + 63) / 64;
+    switch (rows) {
+        case 1: hipLaunchKernelGGL(cdf_build_kernel<1>, grid, block, 0, st, t_probe, opacity, num_rays, n, cdf); break;
+        case 2: hipLaunchKernelGGL(cdf_build_kernel<2>, grid, block, 0, st, t_probe, opacity, num_rays, n, cdf); break;
+        default: hipLaunchKernelGGL(cdf_build_kernel<4>, grid, block, 0, st, t_probe, opacity, num_rays, n, cdf); break;
+    }
+    return check_launch("ffn_cdf_build");
+}
+
+extern "C" int ffn_focus_sample_merge(const float* near_far, int64_t num_rays_total,
+                                      const float* cdfs, const int64_t* ray_index, const float* u,
+                                      const float* unit_focus, int num_rays, int num_samples,
+                                      int n_focus, float* t_io, void* stream) {
+    if (num_rays == 0) return 0;
+    if (num_samples > 256 || n_focus < 2 || n_focus > num_samples)
+        return fail_arg("ffn_focus_sample_merge: need 2 <= n_focus <= S <= 256");
+    int64_t blocks = ((int64_t)num_rays + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(focus_merge_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream,
+                       near_far, num_rays_total, cdfs, ray_index, u, unit_focus, num_rays,
+                       num_samples, n_focus, t_io);
+    return check_launch("ffn_focus_sample_merge");
+}

@@ -1,0 +1,417 @@
+// Fused Fourier-feature MLP on the gfx950 matrix cores, exact-f32 mode
+// (v_mfma_f32_32x32x2_f32: f32 in, f32 accumulate, bitwise an fmaf chain).
+//
+// Work decomposition: ONE WAVEFRONT OWNS 32 CONSECUTIVE SAMPLES for the whole network.
+// The layer product is computed transposed, D[out][sample] = W[out][in] * X[in][sample]:
+// weights are the MFMA A operand, activations the B operand.  With that orientation the
+// accumulator layout of layer l (lane = (h, sample), registers = output channels
+// 8q+4h+p) IS the B-operand layout of layer l+1 for the K ordering c' = 8g+4h+p, so a
+// layer's output goes through bias+ReLU and one lane-linear ds_write_b128 into the wave's
+// private 32 KiB LDS slab and comes back as one lane-linear ds_read_b128 per 32 MFMAs --
+// no transposes, no inter-wave barriers, no HBM round trips between layers.
+// Weights are streamed from L2 in a pre-packed operand order (ffn_mlp_pack), 1 KiB
+// coalesced per wave-load, double buffered in registers against the 64-cycle MFMAs.
+// Fourier features are generated in registers (branch-free sincos) and interleaved with
+// the MFMAs of the previous K group.  The same interpreter runs the backward-data chain
+// (dZ_{l-1} = relu'(H_{l-1}) * W_l^T dZ_l) with transposed weight packs.
+#include "common.h"
+
+namespace ffn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kSamplesPerWave = 32;
+constexpr int kWavesPerBlock = 4;
+constexpr int kActBytesPerWave = 32 * 1024;  // 256 channels x 32 samples x 4 B
+
+enum Mode { kInfer = 0, kTrainFwd = 1, kBackward = 2 };
+
+// ---------------------------------------------------------------------------------- pack
+__global__ void __launch_bounds__(256)
+pack_kernel(const float* __restrict__ src, int rows, int cols, int ld, int transpose,
+            const int32_t* __restrict__ row_map, const int32_t* __restrict__ col_map, int groups,
+            int tiles, float* __restrict__ dst) {
+    const int64_t total = (int64_t)groups * tiles * 256;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int p = (int)(e & 3);
+        const int lane = (int)((e >> 2) & 63);
+        const int64_t go = e >> 8;
+        const int o = (int)(go % tiles);
+        const int g = (int)(go / tiles);
+        int r = 32 * o + (lane & 31);             // operand row  (M index)
+        int c = 8 * g + 4 * (lane >> 5) + p;      // operand col  (K index)
+        if (row_map != nullptr) r = row_map[r];
+        if (col_map != nullptr) c = col_map[c];
+        float v = 0.0f;
+        if (r >= 0 && c >= 0) {
+            const int sr = transpose ? c : r;
+            const int sc = transpose ? r : c;
+            if (sr < rows && sc < cols) v = src[(int64_t)sr * ld + sc];
+        }
+        dst[e] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------- features
+// Internal feature order of an encoding: channel c' = 2k + trig (trig 0 = cos, 1 = sin)
+// for k < F, then the raw inputs at c' = 2F..2F+2, then zero padding.  The float4 a lane
+// needs for K group g is channels 8g + 4h + {0,1,2,3}, i.e. frequencies 4g+2h and 4g+2h+1.
+// Branch-free: out-of-range frequencies are clamped for the table reads and masked after.
+struct EncRegs {
+    const float* b;
+    const float* a;
+    int F;        // real number of frequencies
+    int Fi;       // max(F, 1): row stride of the table actually allocated
+    int raw;      // raw inputs follow the trig block
+    float scale;
+};
+
+__device__ __forceinline__ EncRegs load_enc(const ffn_encoding& e) {
+    EncRegs r;
+    r.b = e.b; r.a = e.a; r.F = e.num_freq; r.Fi = e.num_freq > 0 ? e.num_freq : 1;
+    r.raw = (e.include_input != 0 || e.num_freq == 0) ? 1 : 0;
+    r.scale = e.scale;
+    return r;
+}
+
+__device__ __forceinline__ void feature_pair(const EncRegs& enc, int k, float s0, float s1,
+                                             float s2, float x0, float x1, float x2, float& even,
+                                             float& odd) {
+    const int kk = k < enc.Fi ? k : enc.Fi - 1;
+    float ang = s0 * enc.b[kk];
+    ang = __builtin_fmaf(s1, enc.b[enc.Fi + kk], ang);
+    ang = __builtin_fmaf(s2, enc.b[2 * enc.Fi + kk], ang);
+    float sn, cs;
+    fast_sincos(ang, sn, cs);
+    const float amp = enc.a[kk];
+    const int c = 2 * (k - enc.F);  // offset past the trig block
+    const float raw_even = (enc.raw && c == 0) ? x0 : ((enc.raw && c == 2) ? x2 : 0.0f);
+    const float raw_odd = (enc.raw && c == 0) ? x1 : 0.0f;
+    const bool trig = k < enc.F;
+    even = trig ? amp * cs : raw_even;
+    odd = trig ? amp * sn : raw_odd;
+}
+
+__device__ __forceinline__ f32x4 feature_group(const EncRegs& enc, int g, int h, float x0,
+                                               float x1, float x2) {
+    f32x4 v;
+    const int k0 = 4 * g + 2 * h;
+    const float s0 = enc.scale * x0, s1 = enc.scale * x1, s2 = enc.scale * x2;
+    float e0, o0, e1, o1;
+    feature_pair(enc, k0, s0, s1, s2, x0, x1, x2, e0, o0);
+    feature_pair(enc, k0 + 1, s0, s1, s2, x0, x1, x2, e1, o1);
+    v[0] = e0; v[1] = o0; v[2] = e1; v[3] = o1;
+    return v;
+}
+
+// ---------------------------------------------------------------------------------- MFMA block
+template <int OT>
+__device__ __forceinline__ void mma_group(f32x16 (&acc)[OT], const f32x4 (&a)[OT], f32x4 x) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int o = 0; o < OT; ++o)
+            acc[o] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[o][p], x[p], acc[o], 0, 0, 0);
+}
+
+// Ask the scheduler for "1 MFMA, then `valu` VALU ops" OT*4 times: spreads the feature
+// arithmetic of the next K group through this group's MFMA issue slots.
+template <int OT>
+__device__ __forceinline__ void interleave_hint(int valu_per_mfma) {
+#pragma unroll
+    for (int i = 0; i < OT * 4; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+    }
+    (void)valu_per_mfma;
+}
+
+template <int OT>
+__device__ __forceinline__ void load_weights(f32x4 (&a)[OT], const f32x4* __restrict__ wp, int g) {
+#pragma unroll
+    for (int o = 0; o < OT; ++o) a[o] = wp[(int64_t)(g * OT + o) * 64];
+}
+
+struct WaveCtx {
+    int lane, h, s;          // lane = 32*h + s
+    float x0, x1, x2;        // position of this lane's sample
+    float v0, v1, v2;        // view direction of this lane's sample
+    f32x4 dl;                // backward: d(loss)/d(logits) of this lane's sample
+    f32x4* act;              // this wave's LDS slab, indexed [group*64 + lane]
+    int64_t block;           // global 32-sample block id
+    int64_t num_blocks;
+    float logit[4];
+};
+
+// float4 index of (channel quad cq, sample s) inside a saved-activation block
+__device__ __forceinline__ int saved_index(int cq, int s) { return cq * 32 + (s ^ (cq & 15)); }
+
+__device__ __forceinline__ f32x4* slab_block(const ffn_mlp_chain& ch, float* base, int slot,
+                                             const WaveCtx& w) {
+    return reinterpret_cast<f32x4*>(base + ch.slot_offset[slot] * w.num_blocks * 32) +
+           w.block * (int64_t)(ch.slot_channels[slot] * 8);
+}
+
+template <int OT, int MODE>
+__device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step& L, WaveCtx& w,
+                                         const float* __restrict__ packed_w,
+                                         const float* __restrict__ bias,
+                                         float* __restrict__ slab_in,    // bwd: forward activations
+                                         float* __restrict__ slab_out) { // fwd: saved; bwd: dZ
+    f32x16 acc[OT];
+#pragma unroll
+    for (int o = 0; o < OT; ++o)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[o][r] = 0.0f;
+
+    const f32x4* wp = reinterpret_cast<const f32x4*>(packed_w + L.w_off) + w.lane;
+    const int GA = L.act_groups;   // multiple of 4
+    const int GX = L.aux_groups;   // even; encoding features (fwd) or d_logits columns (bwd)
+    f32x4 a0[OT], a1[OT];
+    f32x4 x0, x1;
+    load_weights<OT>(a0, wp, 0);
+
+    // ---- segment 1: K groups read back from the activation slab ------------------
+    if (GA > 0) {
+        f32x4* save = nullptr;
+        if (MODE != kInfer && L.save_in_slot >= 0) save = slab_block(ch, slab_out, L.save_in_slot, w);
+        x0 = w.act[w.lane];
+        for (int g = 0; g < GA; g += 2) {
+            load_weights<OT>(a1, wp, g + 1);
+            x1 = w.act[(g + 1) * 64 + w.lane];
+            if (MODE != kInfer && save != nullptr) save[saved_index(2 * g + w.h, w.s)] = x0;
+            mma_group<OT>(acc, a0, x0);
+            const int gn = g + 2 < GA + GX ? g + 2 : g;
+            load_weights<OT>(a0, wp, gn);
+            if (g + 2 < GA) x0 = w.act[(g + 2) * 64 + w.lane];
+            if (MODE != kInfer && save != nullptr) save[saved_index(2 * (g + 1) + w.h, w.s)] = x1;
+            mma_group<OT>(acc, a1, x1);
+        }
+    }
+
+    // ---- segment 2: generated operands --------------------------------------------
+    if (GX > 0) {
+        if (MODE == kBackward) {
+            // d_logits columns [lg_col, lg_col+lg_n) are K channels 0..lg_n-1: group 0, h == 0
+            f32x4 d = w.dl;
+            f32x4 sel;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                float v = 0.0f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v = (c == L.lg_col + p && p < L.lg_n) ? d[c] : v;
+                sel[p] = w.h == 0 ? v : 0.0f;
+            }
+            mma_group<OT>(acc, a0, sel);   // group GA (a0 was prefetched); group GA+1 is all zero
+        } else {
+            const EncRegs enc = load_enc(ch.enc[L.enc_id]);
+            const float p0 = L.enc_id == 0 ? w.x0 : w.v0;
+            const float p1 = L.enc_id == 0 ? w.x1 : w.v1;
+            const float p2 = L.enc_id == 0 ? w.x2 : w.v2;
+            x0 = feature_group(enc, 0, w.h, p0, p1, p2);
+            for (int e = 0; e < GX; e += 2) {
+                load_weights<OT>(a1, wp, GA + e + 1);
+                x1 = feature_group(enc, e + 1, w.h, p0, p1, p2);
+                mma_group<OT>(acc, a0, x0);
+                interleave_hint<OT>(3);
+                const int en = e + 2 < GX ? e + 2 : e;
+                load_weights<OT>(a0, wp, GA + en);
+                x0 = feature_group(enc, en, w.h, p0, p1, p2);
+                mma_group<OT>(acc, a1, x1);
+                interleave_hint<OT>(3);
+            }
+        }
+    }
+
+    // ---- epilogue: bias / activation / mask, hand-off -------------------------------
+    const float* bv = (MODE == kBackward) ? nullptr : bias + L.b_off + 4 * w.h;
+    const f32x4* mask = nullptr;
+    if (MODE == kBackward && L.mask_slot >= 0) mask = slab_block(ch, slab_in, L.mask_slot, w);
+    f32x4* save_out = nullptr;
+    if (MODE == kBackward && L.save_out_slot >= 0) save_out = slab_block(ch, slab_out, L.save_out_slot, w);
+#pragma unroll
+    for (int o = 0; o < OT; ++o) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int group = 4 * o + q;
+            f32x4 y;
+            if (MODE == kBackward) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) y[p] = acc[o][4 * q + p];
+                if (mask != nullptr) {
+                    const f32x4 hv = mask[saved_index(2 * group + w.h, w.s)];
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) y[p] = hv[p] > 0.0f ? y[p] : 0.0f;
+                }
+                w.act[group * 64 + w.lane] = y;
+                if (save_out != nullptr) save_out[saved_index(2 * group + w.h, w.s)] = y;
+            } else {
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(bv + 32 * o + 8 * q);
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    float t = acc[o][4 * q + p] + b4[p];
+                    if (L.relu) t = t > 0.0f ? t : 0.0f;
+                    y[p] = t;
+                }
+                if (L.dst == 0) {
+                    w.act[group * 64 + w.lane] = y;
+                } else if (o == 0 && q == 0) {
+                    // real outputs = rows 0..out_n-1 of tile 0 = registers 0..3 of h == 0
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {   // static register index, runtime select
+                        const int p = c - L.out_col;
+                        float val = w.logit[c];
+#pragma unroll
+                        for (int pp = 0; pp < 4; ++pp) val = (p == pp && pp < L.out_n) ? y[pp] : val;
+                        w.logit[c] = val;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ void dispatch_step(const ffn_mlp_chain& ch, const ffn_step& L,
+                                              WaveCtx& w, const float* packed_w, const float* bias,
+                                              float* slab_in, float* slab_out) {
+    switch (L.out_tiles) {
+        case 8: run_step<8, MODE>(ch, L, w, packed_w, bias, slab_in, slab_out); break;
+        case 4: run_step<4, MODE>(ch, L, w, packed_w, bias, slab_in, slab_out); break;
+        case 2: run_step<2, MODE>(ch, L, w, packed_w, bias, slab_in, slab_out); break;
+        default: run_step<1, MODE>(ch, L, w, packed_w, bias, slab_in, slab_out); break;
+    }
+}
+
+__device__ __forceinline__ bool wave_setup(WaveCtx& w, char* smem, int64_t n) {
+    w.lane = threadIdx.x & 63;
+    w.h = w.lane >> 5;
+    w.s = w.lane & 31;
+    const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    w.act = reinterpret_cast<f32x4*>(smem + wave_in_block * kActBytesPerWave);
+    w.num_blocks = (n + kSamplesPerWave - 1) / kSamplesPerWave;
+    w.block = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block;
+    return w.block < w.num_blocks;  // no barriers anywhere, an idle wave may simply leave
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256, 1)
+mlp_forward_kernel(const ffn_mlp_chain ch, const float* __restrict__ packed_w,
+                   const float* __restrict__ bias, const float* __restrict__ positions,
+                   const float* __restrict__ views, int64_t n, float* __restrict__ logits,
+                   float* __restrict__ saved) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    WaveCtx w;
+    if (!wave_setup(w, smem, n)) return;
+    const int64_t sample = w.block * kSamplesPerWave + w.s;
+    const int64_t src = sample < n ? sample : n - 1;  // tail lanes recompute the last sample
+    w.x0 = positions[src * 3 + 0]; w.x1 = positions[src * 3 + 1]; w.x2 = positions[src * 3 + 2];
+    if (views != nullptr) {
+        w.v0 = views[src * 3 + 0]; w.v1 = views[src * 3 + 1]; w.v2 = views[src * 3 + 2];
+    } else {
+        w.v0 = w.v1 = w.v2 = 0.0f;
+    }
+    w.logit[0] = w.logit[1] = w.logit[2] = w.logit[3] = 0.0f;
+    for (int li = 0; li < ch.num_steps; ++li)
+        dispatch_step<MODE>(ch, ch.step[li], w, packed_w, bias, nullptr, saved);
+    if (w.h == 0 && sample < n) {
+        f32x4 out;
+        out[0] = w.logit[0]; out[1] = w.logit[1]; out[2] = w.logit[2]; out[3] = w.logit[3];
+        reinterpret_cast<f32x4*>(logits)[sample] = out;
+    }
+}
+
+// Backward-data chain: consumes d_logits (N,4) and the saved forward activations, writes
+// dZ of every hidden layer (block layout) for the weight-gradient kernel.
+__global__ void __launch_bounds__(256, 1)
+mlp_backward_data_kernel(const ffn_mlp_chain ch, const float* __restrict__ packed_wt,
+                         const float* __restrict__ d_logits, int64_t n, float* __restrict__ saved,
+                         float* __restrict__ dz) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    WaveCtx w;
+    if (!wave_setup(w, smem, n)) return;
+    const int64_t sample = w.block * kSamplesPerWave + w.s;
+    f32x4 zero; zero[0] = zero[1] = zero[2] = zero[3] = 0.0f;
+    w.dl = sample < n ? reinterpret_cast<const f32x4*>(d_logits)[sample] : zero;
+    w.x0 = w.x1 = w.x2 = w.v0 = w.v1 = w.v2 = 0.0f;
+    for (int li = 0; li < ch.num_steps; ++li)
+        dispatch_step<kBackward>(ch, ch.step[li], w, packed_wt, nullptr, saved, dz);
+}
+
+}  // namespace ffn
+
+using namespace ffn;
+
+extern "C" int ffn_mlp_pack(const float* src, int rows, int cols, int ld, int transpose,
+                            const int32_t* row_map, const int32_t* col_map, int groups, int tiles,
+                            float* dst, void* stream) {
+    if (groups <= 0 || tiles <= 0) return fail_arg("ffn_mlp_pack: shape");
+    const int64_t total = (int64_t)groups * tiles * 256;
+    int64_t grid = (total + 255) / 256;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(pack_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, src, rows,
+                       cols, ld, transpose, row_map, col_map, groups, tiles, dst);
+    return check_launch("ffn_mlp_pack");
+}
+
+static int validate_chain(const ffn_mlp_chain* ch, bool backward) {
+    if (ch == nullptr || ch->num_steps < 1 || ch->num_steps > FFN_MAX_STEPS) return 1;
+    for (int i = 0; i < ch->num_steps; ++i) {
+        const ffn_step& L = ch->step[i];
+        const int ot = L.out_tiles;
+        if (!(ot == 1 || ot == 2 || ot == 4 || ot == 8)) return 1;
+        if (L.act_groups < 0 || L.aux_groups < 0 || L.act_groups > 32) return 1;
+        if ((L.act_groups & 3) || (L.aux_groups & 1) || L.act_groups + L.aux_groups == 0) return 1;
+        if (!backward && L.aux_groups > 0 && (L.enc_id < 0 || L.enc_id > 1)) return 1;
+        if (backward && L.aux_groups != 0 && L.aux_groups != 2) return 1;
+        if (backward && L.aux_groups && (L.lg_n < 1 || L.lg_col < 0 || L.lg_col + L.lg_n > 4)) return 1;
+        if (!backward && L.dst == 1 &&
+            (L.out_n < 1 || L.out_n > 4 || L.out_col < 0 || L.out_col + L.out_n > 4))
+            return 1;
+    }
+    return 0;
+}
+
+static const size_t kLdsBytes = (size_t)kWavesPerBlock * kActBytesPerWave;
+
+template <typename K>
+static void allow_big_lds(K kernel) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+}
+
+extern "C" int ffn_mlp_forward(const ffn_mlp_chain* chain, const float* packed_w,
+                               const float* bias, const float* positions, const float* views,
+                               int64_t n, float* logits, float* saved, void* stream) {
+    if (n == 0) return 0;
+    if (n < 0 || validate_chain(chain, false)) return fail_arg("ffn_mlp_forward: bad chain or size");
+    const int64_t blocks32 = (n + kSamplesPerWave - 1) / kSamplesPerWave;
+    const int64_t grid = (blocks32 + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (saved != nullptr) {
+        allow_big_lds(&mlp_forward_kernel<kTrainFwd>);
+        hipLaunchKernelGGL(mlp_forward_kernel<kTrainFwd>, dim3((unsigned)grid), dim3(256), kLdsBytes,
+                           (hipStream_t)stream, *chain, packed_w, bias, positions, views, n, logits,
+                           saved);
+    } else {
+        allow_big_lds(&mlp_forward_kernel<kInfer>);
+        hipLaunchKernelGGL(mlp_forward_kernel<kInfer>, dim3((unsigned)grid), dim3(256), kLdsBytes,
+                           (hipStream_t)stream, *chain, packed_w, bias, positions, views, n, logits,
+                           saved);
+    }
+    return check_launch("ffn_mlp_forward");
+}
+
+extern "C" int ffn_mlp_backward_data(const ffn_mlp_chain* chain, const float* packed_wt,
+                                     const float* d_logits, int64_t n, float* saved, float* dz,
+                                     void* stream) {
+    if (n == 0) return 0;
+    if (n < 0 || validate_chain(chain, true)) return fail_arg("ffn_mlp_backward_data: bad chain or size");
+    const int64_t blocks32 = (n + kSamplesPerWave - 1) / kSamplesPerWave;
+    const int64_t grid = (blocks32 + kWavesPerBlock - 1) / kWavesPerBlock;
+    allow_big_lds(&mlp_backward_data_kernel);
+    hipLaunchKernelGGL(mlp_backward_data_kernel, dim3((unsigned)grid), dim3(256), kLdsBytes,
+                       (hipStream_t)stream, *chain, packed_wt, d_logits, n, saved, dz);
+    return check_launch("ffn_mlp_backward_data");
+}

@@ -1,0 +1,445 @@
+"""Host side of the fused MLP kernels: turns a chain of nn.Linear layers + encodings into
+the ``ffn_mlp_chain`` programs the kernels interpret (forward and backward-data), the
+weight-gradient job list, and owns the packed-operand buffers and workspaces.
+
+Gradient layout: one flat fp32 buffer holding, for every layer in chain order, the weight
+gradient (out, in) row-major followed by the bias gradient -- the same order as the
+models' flat parameter buffer, so one RCCL all-reduce and one fused clip+Adam launch cover
+the whole model.
+"""
+
+import ctypes
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import c_i, c_i64, c_p
+from .ops import _dev, _stream
+
+MAX_STEPS = 16
+WGRAD_WAVES = 1024          # one persistent wave per SIMD: 256 CUs x 4
+COST_FULL = 256             # MFMAs per 32-sample block of a 128x128 patch
+COST_HEAD = 64
+
+
+class FfnEncoding(ctypes.Structure):
+    _fields_ = [("b", ctypes.c_void_p), ("a", ctypes.c_void_p), ("num_freq", ctypes.c_int32),
+                ("include_input", ctypes.c_int32), ("scale", ctypes.c_float),
+                ("width", ctypes.c_int32)]
+
+
+class FfnStep(ctypes.Structure):
+    _fields_ = [("act_groups", ctypes.c_int32), ("aux_groups", ctypes.c_int32),
+                ("enc_id", ctypes.c_int32), ("lg_col", ctypes.c_int32), ("lg_n", ctypes.c_int32),
+                ("out_tiles", ctypes.c_int32), ("relu", ctypes.c_int32), ("dst", ctypes.c_int32),
+                ("out_col", ctypes.c_int32), ("out_n", ctypes.c_int32),
+                ("save_in_slot", ctypes.c_int32), ("save_out_slot", ctypes.c_int32),
+                ("mask_slot", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("w_off", ctypes.c_int64), ("b_off", ctypes.c_int64)]
+
+
+class FfnMlpChain(ctypes.Structure):
+    _fields_ = [("enc", FfnEncoding * 2), ("step", FfnStep * MAX_STEPS),
+                ("num_steps", ctypes.c_int32), ("num_slots", ctypes.c_int32),
+                ("slot_channels", ctypes.c_int32 * MAX_STEPS),
+                ("slot_offset", ctypes.c_int64 * MAX_STEPS)]
+
+
+class FfnWgradJob(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int32), ("m_slot", ctypes.c_int32), ("m_cq0", ctypes.c_int32),
+                ("m_quads", ctypes.c_int32), ("n_kind", ctypes.c_int32),
+                ("n_slot", ctypes.c_int32), ("n_cq0", ctypes.c_int32), ("n_quads", ctypes.c_int32),
+                ("lg_col", ctypes.c_int32), ("lg_n", ctypes.c_int32),
+                ("reserved0", ctypes.c_int32), ("reserved1", ctypes.c_int32)]
+
+
+class FfnWgradSegment(ctypes.Structure):
+    _fields_ = [("job", ctypes.c_int32), ("slot", ctypes.c_int32),
+                ("blk_begin", ctypes.c_int64), ("blk_end", ctypes.c_int64)]
+
+
+class FfnReduceJob(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int32), ("slot_begin", ctypes.c_int32),
+                ("slot_end", ctypes.c_int32), ("m_ch0", ctypes.c_int32), ("rows", ctypes.c_int32),
+                ("n_quad0", ctypes.c_int32), ("n_quads", ctypes.c_int32),
+                ("k_base", ctypes.c_int32), ("ld", ctypes.c_int32), ("has_bias", ctypes.c_int32),
+                ("lg_n", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("w_grad_off", ctypes.c_int64), ("b_grad_off", ctypes.c_int64),
+                ("col_map", ctypes.c_void_p)]
+
+
+def _struct_array_to_device(items, device):
+    if not items:
+        return torch.zeros((0,), dtype=torch.uint8, device=device)
+    arr = (type(items[0]) * len(items))(*items)
+    host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+    return host.to(device)
+
+
+class EncodingSpec:
+    """A sin/cos feature map of a 3-vector: [a cos(s x B), a sin(s x B)] (+ x)."""
+
+    def __init__(self, b: Optional[torch.Tensor], a: Optional[torch.Tensor], scale: float,
+                 include_input: bool, device: Optional[torch.device] = None):
+        self.num_freq = 0 if b is None else int(b.shape[1])
+        dev = device if device is not None else (b.device if b is not None else None)
+        if b is None:
+            b = torch.zeros((3, 1), dtype=torch.float32, device=dev)
+        if a is None:
+            a = torch.ones((max(self.num_freq, 1),), dtype=torch.float32, device=dev)
+        self.b = b.contiguous()
+        self.a = a.contiguous()
+        self.scale = float(scale)
+        self.include_input = bool(include_input) or self.num_freq == 0
+        natural = 2 * self.num_freq + (3 if self.include_input else 0)
+        self.natural_width = natural
+        self.width = ((natural + 15) // 16) * 16
+
+    def natural_index(self, internal: int) -> int:
+        """Natural column ([cos F][sin F][x 3]) of internal channel 2k+trig / 2F+d, or -1."""
+        freq = self.num_freq
+        if internal < 2 * freq:
+            k = internal >> 1
+            return k if (internal & 1) == 0 else freq + k
+        if self.include_input and internal < 2 * freq + 3:
+            return internal
+        return -1
+
+
+class DenseSpec:
+    """One nn.Linear of the chain.  Input = [previous activations (act_in channels),
+    encoding `enc_id` (its natural width)] in that column order."""
+
+    def __init__(self, weight, bias, act_in: int, enc_id: Optional[int], relu: bool,
+                 to_logits: Optional[tuple] = None):
+        self.weight = weight
+        self.bias = bias
+        self.act_in = int(act_in)
+        self.enc_id = enc_id
+        self.relu = bool(relu)
+        self.to_logits = to_logits     # (first column, count) or None
+        self.out = int(weight.shape[0])
+        self.ld = int(weight.shape[1])
+
+
+def _tiles(channels: int) -> int:
+    tiles = (channels + 31) // 32
+    if tiles not in (1, 2, 4, 8):
+        raise NotImplementedError(
+            "fused MLP kernels support layer widths of 32/64/128/256 channels (got %d)" % channels)
+    return tiles
+
+
+class Workspace:
+    """Per-batch-size device buffers of the training path."""
+
+    def __init__(self, prog: "MlpProgram", n: int):
+        dev = prog.device
+        self.n = n
+        blocks = (n + 31) // 32
+        slab = prog.saved_channels * 32 * blocks
+        self.dz = torch.empty((slab,), dtype=torch.float32, device=dev)
+        segs, starts, reduce_jobs, slots = prog._plan_wgrad(blocks)
+        self.segments = _struct_array_to_device(segs, dev)
+        self.seg_start = torch.tensor(starts, dtype=torch.int32, device=dev)
+        self.reduce_jobs = _struct_array_to_device(reduce_jobs, dev)
+        self.num_reduce_jobs = len(reduce_jobs)
+        self.partials = torch.empty((slots * prog.partial_floats,), dtype=torch.float32, device=dev)
+
+
+class MlpProgram:
+    """Chains + device buffers for one model.  All tensors live on ``device`` (a GPU)."""
+
+    def __init__(self, encodings: Sequence[EncodingSpec], layers: Sequence[DenseSpec],
+                 device: torch.device, planning_only: bool = False):
+        """``planning_only`` builds the chains / job lists on any device without touching
+        the library (host-logic tests); every launch method then raises."""
+        if device.type != "cuda" and not planning_only:
+            raise RuntimeError("MlpProgram needs a GPU device; there is no CPU fallback")
+        if len(layers) > MAX_STEPS:
+            raise NotImplementedError("at most %d dense layers" % MAX_STEPS)
+        self.partial_floats = 16 * 16 * 64 + 256
+        if not planning_only:
+            lib = _lib.load()
+            lib.ffn_mlp_wgrad_partial_floats.restype = ctypes.c_int64
+            assert int(lib.ffn_mlp_wgrad_partial_floats()) == self.partial_floats
+        self.device = device
+        self.encodings = list(encodings)
+        self.layers = list(layers)
+        self._workspaces: Dict[int, Workspace] = {}
+        self._build_forward()
+        self._build_backward()
+        self._build_wgrad_jobs()
+
+    # ------------------------------------------------------------------ chains
+    def _fill_encodings(self, chain):
+        for i, enc in enumerate(self.encodings):
+            e = chain.enc[i]
+            e.b = enc.b.data_ptr()
+            e.a = enc.a.data_ptr()
+            e.num_freq = enc.num_freq
+            e.include_input = 1 if enc.include_input else 0
+            e.scale = enc.scale
+            e.width = enc.width
+        for i in range(len(self.encodings), 2):     # unused entries still need valid pointers
+            src = chain.enc[0]
+            chain.enc[i].b, chain.enc[i].a = src.b, src.a
+            chain.enc[i].num_freq, chain.enc[i].include_input = src.num_freq, src.include_input
+            chain.enc[i].scale, chain.enc[i].width = src.scale, src.width
+
+    def _build_forward(self):
+        fwd = FfnMlpChain()
+        self._fill_encodings(fwd)
+        w_off = b_off = 0
+        self.col_maps: List[torch.Tensor] = []
+        self.fwd_shapes = []
+        self.grad_w_off, self.grad_b_off = [], []
+        self.slot_of: Dict[int, int] = {}      # producer layer index -> slab slot
+        self.producer_of: List[int] = []       # layer index -> layer whose output it consumes
+        slot_off = 0
+        g_off = 0
+        last_producer = -1
+        saved_already = set()
+        for i, spec in enumerate(self.layers):
+            L = fwd.step[i]
+            if spec.act_in % 32:
+                raise NotImplementedError("activation widths must be multiples of 32")
+            enc = None if spec.enc_id is None else self.encodings[spec.enc_id]
+            L.act_groups = spec.act_in // 8
+            L.aux_groups = 0 if enc is None else enc.width // 8
+            L.enc_id = 0 if spec.enc_id is None else spec.enc_id
+            L.out_tiles = _tiles(spec.out)
+            L.relu = 1 if spec.relu else 0
+            L.save_in_slot = L.save_out_slot = L.mask_slot = -1
+            self.producer_of.append(last_producer if spec.act_in > 0 else -1)
+            if spec.act_in > 0:
+                if last_producer < 0 or self.layers[last_producer].out != spec.act_in:
+                    raise ValueError("layer %d consumes %d channels but the previous producer "
+                                     "wrote a different width" % (i, spec.act_in))
+                if last_producer not in saved_already:
+                    L.save_in_slot = self.slot_of[last_producer]
+                    saved_already.add(last_producer)
+            if spec.to_logits is None:
+                L.dst, L.out_col, L.out_n = 0, 0, 0
+                if spec.out % 32:
+                    raise NotImplementedError("hidden widths must be multiples of 32")
+                slot = len(self.slot_of)
+                self.slot_of[i] = slot
+                fwd.slot_channels[slot] = spec.out
+                fwd.slot_offset[slot] = slot_off
+                slot_off += spec.out
+                last_producer = i
+            else:
+                L.dst, L.out_col, L.out_n = 1, spec.to_logits[0], spec.to_logits[1]
+            groups = L.act_groups + L.aux_groups
+            L.w_off, L.b_off = w_off, b_off
+            cmap = [c if c < spec.act_in else -1 for c in range(8 * L.act_groups)]
+            if enc is not None:
+                for c in range(enc.width):
+                    nat = enc.natural_index(c)
+                    cmap.append(-1 if nat < 0 else spec.act_in + nat)
+            self.col_maps.append(torch.tensor(cmap, dtype=torch.int32, device=self.device))
+            self.fwd_shapes.append((groups, L.out_tiles))
+            w_off += groups * L.out_tiles * 256
+            b_off += 32 * L.out_tiles
+            self.grad_w_off.append(g_off)
+            g_off += spec.out * spec.ld
+            self.grad_b_off.append(g_off)
+            g_off += spec.out
+        fwd.num_steps = len(self.layers)
+        fwd.num_slots = len(self.slot_of)
+        self.fwd = fwd
+        self.saved_channels = slot_off
+        self.num_grad_floats = g_off
+        self.packed_fwd = torch.zeros((w_off,), dtype=torch.float32, device=self.device)
+        self.bias_buf = torch.zeros((b_off,), dtype=torch.float32, device=self.device)
+
+    def _build_backward(self):
+        """Backward-data chain: one step per producer layer that has consumers, walking
+        the network from the outputs to the first layer."""
+        bwd = FfnMlpChain()
+        self._fill_encodings(bwd)
+        for s in range(self.fwd.num_slots):
+            bwd.slot_channels[s] = self.fwd.slot_channels[s]
+            bwd.slot_offset[s] = self.fwd.slot_offset[s]
+        bwd.num_slots = self.fwd.num_slots
+        consumers: Dict[int, List[int]] = {}
+        for i, prod in enumerate(self.producer_of):
+            if prod >= 0:
+                consumers.setdefault(prod, []).append(i)
+        self.bwd_packs = []        # (layer index, groups, tiles, w_off) transposed packs
+        steps = []
+        wt_off = 0
+        producers = sorted(consumers.keys(), reverse=True)
+        for j in producers:
+            hidden = [c for c in consumers[j] if self.layers[c].to_logits is None]
+            heads = [c for c in consumers[j] if self.layers[c].to_logits is not None]
+            if len(hidden) > 1 or len(heads) > 1:
+                raise NotImplementedError("a layer may feed at most one hidden layer and one head")
+            st = FfnStep()
+            st.out_tiles = _tiles(self.layers[j].out)
+            st.act_groups = 0 if not hidden else self.layers[hidden[0]].out // 8
+            st.aux_groups = 2 if heads else 0
+            st.relu = 0
+            st.mask_slot = self.slot_of[j] if self.layers[j].relu else -1
+            st.save_in_slot = self.slot_of[hidden[0]] if hidden else -1
+            st.save_out_slot = -1
+            st.w_off = wt_off
+            if hidden:
+                c = hidden[0]
+                self.bwd_packs.append((c, st.act_groups, st.out_tiles, wt_off))
+                wt_off += st.act_groups * st.out_tiles * 256
+            if heads:
+                c = heads[0]
+                st.lg_col, st.lg_n = self.layers[c].to_logits
+                self.bwd_packs.append((c, 2, st.out_tiles, wt_off))
+                wt_off += 2 * st.out_tiles * 256
+            steps.append(st)
+        if steps:
+            # the last step's output (dZ of the first producer) has no consumer step
+            steps[-1].save_out_slot = self.slot_of[producers[-1]]
+        if len(steps) > MAX_STEPS:
+            raise NotImplementedError("backward chain too long")
+        for k, st in enumerate(steps):
+            bwd.step[k] = st
+        bwd.num_steps = len(steps)
+        self.bwd = bwd
+        self.packed_bwd = torch.zeros((max(wt_off, 1),), dtype=torch.float32, device=self.device)
+
+    def _build_wgrad_jobs(self):
+        self.wgrad_jobs: List[FfnWgradJob] = []
+        self.job_meta = []      # per job: dict for the reducer
+        for i, spec in enumerate(self.layers):
+            enc = None if spec.enc_id is None else self.encodings[spec.enc_id]
+            panels = []         # (n_kind, n_slot, first quad, quads, k_base)
+            if spec.act_in > 0:
+                slot = self.slot_of[self.producer_of[i]]
+                quads = spec.act_in // 4
+                for q0 in range(0, quads, 32):
+                    panels.append((0, slot, q0, min(32, quads - q0), 0))
+            if enc is not None:
+                quads = enc.width // 4
+                for q0 in range(0, quads, 32):
+                    panels.append((1, spec.enc_id, q0, min(32, quads - q0), spec.act_in))
+            if spec.to_logits is None:
+                m_slot = self.slot_of[i]
+                out_quads = spec.out // 4
+                for m0 in range(0, out_quads, 32):
+                    for pi, (nk, ns, q0, nq, kb) in enumerate(panels):
+                        job = FfnWgradJob(0, m_slot, m0, min(32, out_quads - m0), nk, ns, q0, nq,
+                                          0, 0, 0, 0)
+                        self.wgrad_jobs.append(job)
+                        self.job_meta.append(dict(layer=i, kind=0, m_ch0=4 * m0, n_quad0=q0,
+                                                  n_quads=nq, k_base=kb, has_bias=int(pi == 0),
+                                                  lg_n=0, cost=COST_FULL))
+            else:
+                col, cnt = spec.to_logits
+                for pi, (nk, ns, q0, nq, kb) in enumerate(panels):
+                    job = FfnWgradJob(1, 0, 0, 0, nk, ns, q0, nq, col, cnt, 0, 0)
+                    self.wgrad_jobs.append(job)
+                    self.job_meta.append(dict(layer=i, kind=1, m_ch0=0, n_quad0=q0, n_quads=nq,
+                                              k_base=kb, has_bias=int(pi == 0), lg_n=cnt,
+                                              cost=COST_HEAD))
+        self.wgrad_jobs_dev = _struct_array_to_device(self.wgrad_jobs, self.device)
+
+    def _plan_wgrad(self, blocks: int):
+        """Cost-balanced split of (job, block-range) work over the persistent waves."""
+        costs = [m["cost"] for m in self.job_meta]
+        total = sum(c * blocks for c in costs)
+        waves = WGRAD_WAVES
+        target = -(-total // waves)
+        segs, starts = [], [0]
+        job_slots = [[] for _ in self.job_meta]
+        job, blk = 0, 0
+        slot = 0
+        for w in range(waves):
+            budget = target
+            last = w == waves - 1
+            while job < len(costs) and (budget > 0 or last):
+                left = blocks - blk
+                take = left if last else min(left, budget // costs[job])
+                if take <= 0:
+                    break
+                segs.append(FfnWgradSegment(job, slot, blk, blk + take))
+                job_slots[job].append(slot)
+                slot += 1
+                budget -= take * costs[job]
+                blk += take
+                if blk == blocks:
+                    job, blk = job + 1, 0
+            starts.append(len(segs))
+        assert job == len(costs), "work left unassigned"
+        reduce_jobs = []
+        for j, meta in enumerate(self.job_meta):
+            spec = self.layers[meta["layer"]]
+            sl = job_slots[j]
+            assert sl == list(range(sl[0], sl[-1] + 1))
+            reduce_jobs.append(FfnReduceJob(
+                meta["kind"], sl[0], sl[-1] + 1, meta["m_ch0"], spec.out, meta["n_quad0"],
+                meta["n_quads"], meta["k_base"], spec.ld, meta["has_bias"], meta["lg_n"], 0,
+                self.grad_w_off[meta["layer"]], self.grad_b_off[meta["layer"]],
+                self.col_maps[meta["layer"]].data_ptr()))
+        return segs, starts, reduce_jobs, slot
+
+    # ------------------------------------------------------------------ packing
+    def pack(self):
+        """Re-derives the MFMA-operand copies from the current nn.Linear weights."""
+        for i, spec in enumerate(self.layers):
+            L = self.fwd.step[i]
+            groups, tiles = self.fwd_shapes[i]
+            w = spec.weight.detach()
+            dst = self.packed_fwd[L.w_off:L.w_off + groups * tiles * 256]
+            _lib.call("ffn_mlp_pack", _dev(w), c_i(w.shape[0]), c_i(w.shape[1]), c_i(w.stride(0)),
+                      c_i(0), c_p(0), _dev(self.col_maps[i], torch.int32), c_i(groups), c_i(tiles),
+                      _dev(dst), _stream())
+            self.bias_buf[L.b_off:L.b_off + spec.out].copy_(spec.bias.detach())
+        for (c, groups, tiles, off) in self.bwd_packs:
+            w = self.layers[c].weight.detach()
+            dst = self.packed_bwd[off:off + groups * tiles * 256]
+            # operand rows = input channels (act part), operand K = output rows of layer c
+            _lib.call("ffn_mlp_pack", _dev(w), c_i(w.shape[0]), c_i(self.layers[c].act_in),
+                      c_i(w.stride(0)), c_i(1), c_p(0), c_p(0), c_i(groups), c_i(tiles),
+                      _dev(dst), _stream())
+
+    # ------------------------------------------------------------------ launches
+    def workspace(self, n: int) -> Workspace:
+        ws = self._workspaces.get(n)
+        if ws is None:
+            if len(self._workspaces) >= 4:
+                self._workspaces.clear()
+            ws = Workspace(self, n)
+            self._workspaces[n] = ws
+        return ws
+
+    def saved_floats(self, n: int) -> int:
+        return self.saved_channels * 32 * ((n + 31) // 32)
+
+    def forward(self, positions: torch.Tensor, views: Optional[torch.Tensor],
+                saved: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """positions (N,3) [views (N,3)] -> raw logits (N,4).  ``saved`` (a flat float
+        buffer of ``saved_floats(N)`` elements) receives the activations for backward."""
+        n = positions.shape[0]
+        logits = torch.empty((n, 4), dtype=torch.float32, device=self.device)
+        _lib.call("ffn_mlp_forward", ctypes.byref(self.fwd), _dev(self.packed_fwd),
+                  _dev(self.bias_buf), _dev(positions, name="positions"),
+                  _dev(views, name="views"), c_i64(n), _dev(logits), _dev(saved), _stream())
+        return logits
+
+    def backward(self, d_logits: torch.Tensor, positions: torch.Tensor,
+                 views: Optional[torch.Tensor], saved: torch.Tensor, grads: torch.Tensor):
+        """Fills ``grads`` (flat, num_grad_floats) from d(loss)/d(logits) (N,4) and the
+        activations ``saved`` by the matching forward call."""
+        n = positions.shape[0]
+        ws = self.workspace(n)
+        if self.bwd.num_steps > 0:
+            _lib.call("ffn_mlp_backward_data", ctypes.byref(self.bwd), _dev(self.packed_bwd),
+                      _dev(d_logits), c_i64(n), _dev(saved), _dev(ws.dz), _stream())
+        _lib.call("ffn_mlp_wgrad", ctypes.byref(self.fwd), _dev(self.wgrad_jobs_dev, torch.uint8),
+                  _dev(ws.segments, torch.uint8), _dev(ws.seg_start, torch.int32),
+                  c_i(WGRAD_WAVES), _dev(saved), _dev(ws.dz), _dev(d_logits), _dev(positions),
+                  _dev(views), c_i64(n), _dev(ws.partials), _stream())
+        _lib.call("ffn_mlp_wgrad_reduce", _dev(ws.reduce_jobs, torch.uint8),
+                  c_i(ws.num_reduce_jobs), _dev(ws.partials), _dev(grads), _stream())
+        return grads

@@ -1,0 +1,309 @@
+"""Radiance-field models behind the reference's class surface, computed by the fused HIP MLP.
+
+Constructor signatures, attribute names, state-dict keys/shapes and the checkpoint format
+mirror ``fourier_feature_models.py:10-191`` and ``nerf_model.py:12-135`` of the reference so
+that its scripts and checkpoints see a drop-in.  ``forward`` does not run ATen GEMMs: it hands
+the whole layer chain to ``MlpProgram`` (fourier_feature_nets_amd/mlp_engine.py) and raises
+when the module is not on a GPU.
+"""
+
+import math
+from typing import List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from .mlp_engine import DenseSpec, EncodingSpec, MlpProgram
+
+
+class _FusedChainFunction(torch.autograd.Function):
+    """logits = chain(positions[, views]); backward = dgrad + wgrad + reduce kernels."""
+
+    @staticmethod
+    def forward(ctx, module, positions, views, *params):
+        prog = module.program()
+        positions = positions.contiguous()
+        views = None if views is None else views.contiguous()
+        track = any(ctx.needs_input_grad[3:])
+        saved = None
+        if track:
+            saved = torch.empty((prog.saved_floats(positions.shape[0]),), dtype=torch.float32,
+                                device=positions.device)
+        logits = prog.forward(positions, views, saved)
+        ctx.module = module
+        ctx.saved_acts = saved
+        ctx.save_for_backward(positions, views)
+        return logits
+
+    @staticmethod
+    def backward(ctx, d_logits):
+        positions, views = ctx.saved_tensors
+        prog = ctx.module.program()
+        grads = torch.empty((prog.num_grad_floats,), dtype=torch.float32, device=positions.device)
+        prog.backward(d_logits.contiguous(), positions, views, ctx.saved_acts, grads)
+        ctx.saved_acts = None
+        outs = []
+        for i, spec in enumerate(prog.layers):
+            w0 = prog.grad_w_off[i]
+            outs.append(grads[w0:w0 + spec.out * spec.ld].view(spec.out, spec.ld))
+            b0 = prog.grad_b_off[i]
+            outs.append(grads[b0:b0 + spec.out])
+        return (None, None, None) + tuple(outs)
+
+
+class _FusedModel(nn.Module):
+    """Shared machinery: lazily built MlpProgram, re-packed when the weights change."""
+
+    def __init__(self):
+        nn.Module.__init__(self)
+        self._prog: Optional[MlpProgram] = None
+        self._packed_key = None
+
+    def _chain(self, device):   # -> (encodings, dense specs)
+        raise NotImplementedError
+
+    def _dense_params(self) -> List[nn.Parameter]:
+        raise NotImplementedError
+
+    def invalidate_packed(self):
+        """Call after the weights were changed behind autograd's back (e.g. by the fused
+        optimiser kernel) so the next forward re-derives the MFMA operand copies."""
+        self._packed_key = None
+
+    def program(self) -> MlpProgram:
+        params = self._dense_params()
+        device = params[0].device
+        if device.type != "cuda":
+            raise RuntimeError(
+                "%s runs on the HIP kernels only: move the model to a GPU (.to('cuda')); there "
+                "is no CPU fallback" % type(self).__name__)
+        ptrs = tuple(p.data_ptr() for p in params)
+        if self._prog is None or self._prog.device != device or self._prog_ptrs != ptrs:
+            encodings, specs = self._chain(device)
+            self._prog = MlpProgram(encodings, specs, device)
+            self._prog_ptrs = ptrs
+            self._packed_key = None
+        key = tuple(p._version for p in params)
+        if self._packed_key != key:
+            self._prog.pack()
+            self._packed_key = key
+        return self._prog
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._prog = None
+        return out
+
+    def __getstate__(self):          # keep deepcopy / pickling of modules working
+        state = dict(self.__dict__)
+        state["_prog"] = None
+        state["_packed_key"] = None
+        return state
+
+
+class FourierFeatureMLP(_FusedModel):
+    """gamma(x) = [a cos(pi x B), a sin(pi x B)] followed by a ReLU MLP
+    (reference: fourier_feature_models.py:10-89)."""
+
+    def __init__(self, num_inputs: int, num_outputs: int, a_values: Optional[torch.Tensor],
+                 b_values: Optional[torch.Tensor], layer_channels: List[int]):
+        _FusedModel.__init__(self)
+        self.params = {
+            "num_inputs": num_inputs,
+            "num_outputs": num_outputs,
+            "a_values": None if a_values is None else a_values.tolist(),
+            "b_values": None if b_values is None else b_values.tolist(),
+            "layer_channels": layer_channels,
+        }
+        self.num_inputs = num_inputs
+        self.num_outputs = num_outputs
+        if b_values is None:
+            self.a_values = None
+            self.b_values = None
+            width = num_inputs
+        else:
+            assert b_values.shape[0] == num_inputs
+            assert a_values.shape[0] == b_values.shape[1]
+            self.a_values = nn.Parameter(a_values, requires_grad=False)
+            self.b_values = nn.Parameter(b_values, requires_grad=False)
+            width = 2 * b_values.shape[1]
+        self.layers = nn.ModuleList()
+        for channels in layer_channels:
+            self.layers.append(nn.Linear(width, channels))
+            width = channels
+        self.layers.append(nn.Linear(width, num_outputs))
+        self.use_view = False
+        self.keep_activations = False
+        self.activations = []
+
+    def _dense_params(self):
+        out = []
+        for layer in self.layers:
+            out += [layer.weight, layer.bias]
+        return out
+
+    def _chain(self, device):
+        if self.num_inputs != 3 or self.num_outputs > 4:
+            raise NotImplementedError("the fused kernels cover the volume-rendering case "
+                                      "(3 inputs, <= 4 outputs)")
+        enc = EncodingSpec(None if self.b_values is None else self.b_values.data,
+                           None if self.a_values is None else self.a_values.data,
+                           math.pi, False, device)
+        specs = []
+        last = len(self.layers) - 1
+        for i, layer in enumerate(self.layers):
+            specs.append(DenseSpec(layer.weight, layer.bias, 0 if i == 0 else layer.in_features,
+                                   0 if i == 0 else None, i != last,
+                                   (0, self.num_outputs) if i == last else None))
+        return [enc], specs
+
+    def forward(self, inputs: torch.Tensor) -> torch.Tensor:
+        """(N,3) positions -> (N,num_outputs) raw outputs."""
+        if self.keep_activations:
+            raise NotImplementedError("keep_activations is a lecture visualisation hook; it is "
+                                      "outside the HIP hot path")
+        self.activations.clear()
+        out = _FusedChainFunction.apply(self, inputs, None, *self._dense_params())
+        return out if self.num_outputs == 4 else out[:, :self.num_outputs]
+
+    def save(self, path: str):
+        """Checkpoint in the reference format: state dict + "type" + "params"."""
+        blob = self.state_dict()
+        blob["type"] = "fourier"
+        blob["params"] = self.params
+        torch.save(blob, path)
+
+
+class MLP(FourierFeatureMLP):
+    """No encoding (fourier_feature_models.py:92-109)."""
+
+    def __init__(self, num_inputs: int, num_outputs: int, num_layers=3, num_channels=256):
+        FourierFeatureMLP.__init__(self, num_inputs, num_outputs, None, None,
+                                   [num_channels] * num_layers)
+
+
+class BasicFourierMLP(FourierFeatureMLP):
+    """B = identity (fourier_feature_models.py:112-131)."""
+
+    def __init__(self, num_inputs: int, num_outputs: int, num_layers=3, num_channels=256):
+        FourierFeatureMLP.__init__(self, num_inputs, num_outputs, torch.ones(num_inputs),
+                                   torch.eye(num_inputs), [num_channels] * num_layers)
+
+
+def axis_frequencies(max_log_scale: float, num_freq: int, num_inputs: int) -> torch.Tensor:
+    """(num_inputs, num_inputs*num_freq) axis-aligned frequency matrix, one block per
+    frequency with columns [x f, y f, z f]; f = 2**linspace(0, max_log_scale, num_freq)."""
+    freqs = 2. ** torch.linspace(0, max_log_scale, num_freq)
+    out = torch.zeros((num_inputs, num_inputs * num_freq))
+    for axis in range(num_inputs):
+        out[axis, axis::num_inputs] = freqs
+    return out
+
+
+class PositionalFourierMLP(FourierFeatureMLP):
+    """Axis-aligned log-spaced frequencies (fourier_feature_models.py:134-166)."""
+
+    def __init__(self, num_inputs: int, num_outputs: int, max_log_scale: float, num_layers=3,
+                 num_channels=256, embedding_size=256):
+        b_values = self._encoding(max_log_scale, embedding_size, num_inputs)
+        FourierFeatureMLP.__init__(self, num_inputs, num_outputs, torch.ones(b_values.shape[1]),
+                                   b_values, [num_channels] * num_layers)
+
+    @staticmethod
+    def _encoding(max_log_scale: float, embedding_size: int, num_inputs: int):
+        return axis_frequencies(max_log_scale, embedding_size // num_inputs, num_inputs)
+
+
+class GaussianFourierMLP(FourierFeatureMLP):
+    """Dense Gaussian B drawn from torch's global RNG (fourier_feature_models.py:169-191)."""
+
+    def __init__(self, num_inputs: int, num_outputs: int, sigma: float, num_layers=3,
+                 num_channels=256, embedding_size=256):
+        b_values = torch.normal(0, sigma, size=(num_inputs, embedding_size))
+        FourierFeatureMLP.__init__(self, num_inputs, num_outputs, torch.ones(b_values.shape[1]),
+                                   b_values, [num_channels] * num_layers)
+
+
+class NeRF(_FusedModel):
+    """Full NeRF: ReLU trunk with skip concatenation, sigma head, linear bottleneck,
+    view-dependent colour branch (reference: nerf_model.py:9-135)."""
+
+    def __init__(self, num_layers: int, num_channels: int, max_log_scale_pos: float,
+                 num_freq_pos: int, max_log_scale_view: float, num_freq_view: int,
+                 skips: Sequence[int], include_inputs: bool):
+        _FusedModel.__init__(self)
+        self.params = {
+            "num_layers": num_layers,
+            "num_channels": num_channels,
+            "max_log_scale_pos": max_log_scale_pos,
+            "num_freq_pos": num_freq_pos,
+            "max_log_scale_view": max_log_scale_view,
+            "num_freq_view": num_freq_view,
+            "skips": list(skips),
+            "include_inputs": include_inputs,
+        }
+        self.pos_encoding = nn.Parameter(self._encoding(max_log_scale_pos, num_freq_pos, 3),
+                                         requires_grad=False)
+        self.view_encoding = nn.Parameter(self._encoding(max_log_scale_view, num_freq_view, 3),
+                                          requires_grad=False)
+        self.skips = set(skips)
+        self.include_inputs = include_inputs
+        self.use_view = True
+        extra = 3 if include_inputs else 0
+        enc_width = 2 * self.pos_encoding.shape[-1] + extra
+        self.layers = nn.ModuleList()
+        width = enc_width
+        for i in range(num_layers):
+            if i in self.skips:
+                width += enc_width
+            self.layers.append(nn.Linear(width, num_channels))
+            width = num_channels
+        self.opacity_out = nn.Linear(width, 1)
+        self.bottleneck = nn.Linear(width, num_channels)
+        self.hidden_view = nn.Linear(num_channels + 2 * self.view_encoding.shape[-1] + extra,
+                                     num_channels // 2)
+        self.color_out = nn.Linear(num_channels // 2, 3)
+
+    @staticmethod
+    def _encoding(max_log_scale: float, num_freq: int, num_inputs: int):
+        return axis_frequencies(max_log_scale, num_freq, num_inputs)
+
+    def _dense_params(self):
+        out = []
+        for layer in list(self.layers) + [self.opacity_out, self.bottleneck, self.hidden_view,
+                                          self.color_out]:
+            out += [layer.weight, layer.bias]
+        return out
+
+    def _chain(self, device):
+        if 0 in self.skips:
+            raise NotImplementedError("a skip connection into layer 0")
+        enc_pos = EncodingSpec(self.pos_encoding.data, None, 1.0, self.include_inputs, device)
+        enc_view = EncodingSpec(self.view_encoding.data, None, 1.0, self.include_inputs, device)
+        channels = self.params["num_channels"]
+        specs = []
+        for i, layer in enumerate(self.layers):
+            if i == 0:
+                specs.append(DenseSpec(layer.weight, layer.bias, 0, 0, True))
+            elif i in self.skips:
+                specs.append(DenseSpec(layer.weight, layer.bias, channels, 0, True))
+            else:
+                specs.append(DenseSpec(layer.weight, layer.bias, channels, None, True))
+        specs.append(DenseSpec(self.opacity_out.weight, self.opacity_out.bias, channels, None,
+                               False, (3, 1)))
+        specs.append(DenseSpec(self.bottleneck.weight, self.bottleneck.bias, channels, None, False))
+        specs.append(DenseSpec(self.hidden_view.weight, self.hidden_view.bias, channels, 1, True))
+        specs.append(DenseSpec(self.color_out.weight, self.color_out.bias, channels // 2, None,
+                               False, (0, 3)))
+        return [enc_pos, enc_view], specs
+
+    def forward(self, position: torch.Tensor, view: torch.Tensor) -> torch.Tensor:
+        """(N,3) positions and (N,3) unit view directions -> (N,4) raw [r,g,b,sigma]."""
+        return _FusedChainFunction.apply(self, position, view, *self._dense_params())
+
+    def save(self, path: str):
+        """Checkpoint in the reference format: state dict + "type" + "params"."""
+        blob = self.state_dict()
+        blob["type"] = "nerf"
+        blob["params"] = self.params
+        torch.save(blob, path)

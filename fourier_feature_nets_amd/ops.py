@@ -1,0 +1,168 @@
+"""Thin tensor-level wrappers over the C ABI: argument checking, pointer plumbing, launch
+on torch's current HIP stream.  Every function requires CUDA(HIP) float32 tensors."""
+
+import ctypes
+import math
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import c_f, c_i, c_i64, c_p
+
+
+def _stream():
+    return c_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t: Optional[torch.Tensor], dtype=torch.float32, name="tensor"):
+    if t is None:
+        return c_p(0)
+    if not t.is_cuda:
+        raise RuntimeError("%s must live on the GPU (got %s); the HIP path has no CPU fallback"
+                           % (name, t.device))
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+    return c_p(t.data_ptr())
+
+
+def _host3(values):
+    arr = (ctypes.c_float * 3)(*[float(v) for v in values])
+    return arr
+
+
+# --------------------------------------------------------------------------------- rays
+def raygen_nearfar(unproj: torch.Tensor, cam_pos: torch.Tensor, width: int, height: int,
+                   box_lo, box_hi):
+    """K1.  unproj (C,4,4), cam_pos (C,3) on the GPU -> starts, directions, near_far, valid."""
+    cams = unproj.shape[0]
+    total = cams * width * height
+    dev = unproj.device
+    starts = torch.empty((total, 3), dtype=torch.float32, device=dev)
+    dirs = torch.empty((total, 3), dtype=torch.float32, device=dev)
+    near_far = torch.empty((2, total), dtype=torch.float32, device=dev)
+    valid = torch.empty((total,), dtype=torch.uint8, device=dev)
+    _lib.call("ffn_raygen_nearfar", _dev(unproj, name="unproj"), _dev(cam_pos, name="cam_pos"),
+              c_i(cams), c_i(width), c_i(height), _host3(box_lo), _host3(box_hi), _dev(starts),
+              _dev(dirs), _dev(near_far), _dev(valid, torch.uint8), _stream())
+    return starts, dirs, near_far, valid
+
+
+def sample_t(near_far: torch.Tensor, ray_index: torch.Tensor, count: int, unit: torch.Tensor,
+             noise: Optional[torch.Tensor], anneal: Optional[float],
+             out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """K2a.  Returns (R, stride) t-values; the first `count` columns are filled."""
+    rays = ray_index.shape[0]
+    if out is None:
+        out = torch.empty((rays, count), dtype=torch.float32, device=near_far.device)
+    _lib.call("ffn_sample_t", _dev(near_far), c_i64(near_far.shape[1]),
+              _dev(ray_index, torch.int64, "ray_index"), c_i(rays), c_i(count), _dev(unit),
+              _dev(noise), c_f(-1.0 if anneal is None else float(anneal)), _dev(out),
+              c_i(out.shape[1]), _stream())
+    return out
+
+
+def materialise_samples(starts, directions, ray_index, t_values, want_views=True):
+    """K2b.  positions (R,S,3) [and view_directions (R,S,3)]."""
+    rays, count = t_values.shape
+    pos = torch.empty((rays, count, 3), dtype=torch.float32, device=t_values.device)
+    views = torch.empty_like(pos) if want_views else None
+    _lib.call("ffn_materialise_samples", _dev(starts), _dev(directions),
+              _dev(ray_index, torch.int64), _dev(t_values), c_i(rays), c_i(count), _dev(pos),
+              _dev(views), _stream())
+    return pos, views
+
+
+def cdf_build(t_probe: torch.Tensor, opacity: torch.Tensor) -> torch.Tensor:
+    """K2c.  (P,n),(P,n) -> (P,n-1)."""
+    rays, n = t_probe.shape
+    cdf = torch.empty((rays, n - 1), dtype=torch.float32, device=t_probe.device)
+    _lib.call("ffn_cdf_build", _dev(t_probe), _dev(opacity), c_i64(rays), c_i(n), _dev(cdf),
+              _stream())
+    return cdf
+
+
+def focus_sample_merge(near_far, cdfs, ray_index, u, unit_focus, t_io, n_focus):
+    """K2d.  In-place on t_io (R,S)."""
+    rays, count = t_io.shape
+    _lib.call("ffn_focus_sample_merge", _dev(near_far), c_i64(near_far.shape[1]), _dev(cdfs),
+              _dev(ray_index, torch.int64), _dev(u), _dev(unit_focus), c_i(rays), c_i(count),
+              c_i(n_focus), _dev(t_io), _stream())
+    return t_io
+
+
+def to_image(colors: torch.Tensor, pixel_index: torch.Tensor, width: int, height: int):
+    """K8.  (n,3) colours + (n,) pixel ids -> (H,W,3) uint8 on the GPU."""
+    img = torch.empty((height, width, 3), dtype=torch.uint8, device=colors.device)
+    _lib.call("ffn_to_image", _dev(colors), _dev(pixel_index, torch.int64),
+              c_i64(colors.shape[0]), c_i(width), c_i(height), _dev(img, torch.uint8), _stream())
+    return img
+
+
+# --------------------------------------------------------------------------------- encode
+def fourier_encode(x: torch.Tensor, b: Optional[torch.Tensor], a: Optional[torch.Tensor],
+                   scale: float, include_input: bool) -> torch.Tensor:
+    """K3.  (N,3) -> (N, 2F[+3]) with the cos block first."""
+    n = x.shape[0]
+    freq = 0 if b is None else b.shape[1]
+    width = 2 * freq + (3 if (include_input or freq == 0) else 0)
+    out = torch.empty((n, width), dtype=torch.float32, device=x.device)
+    _lib.call("ffn_fourier_encode", _dev(x), c_i64(n), _dev(b), _dev(a), c_i(freq),
+              c_f(scale), c_i(1 if include_input else 0), _dev(out), _stream())
+    return out
+
+
+# --------------------------------------------------------------------------------- composite
+def composite_fwd(logits: torch.Tensor, t: torch.Tensor, include_depth: bool,
+                  nan_flag: Optional[torch.Tensor] = None):
+    """K5.  logits (R,S,4), t (R,S) -> color (R,3), alpha (R), depth (R)|None."""
+    rays, count = t.shape
+    dev = t.device
+    color = torch.empty((rays, 3), dtype=torch.float32, device=dev)
+    alpha = torch.empty((rays,), dtype=torch.float32, device=dev)
+    depth = torch.empty((rays,), dtype=torch.float32, device=dev) if include_depth else None
+    _lib.call("ffn_composite_fwd", _dev(logits), _dev(t), c_i(rays), c_i(count), _dev(color),
+              _dev(alpha), _dev(depth), _dev(nan_flag, torch.int32), _stream())
+    return color, alpha, depth
+
+
+def composite_bwd(logits, t, d_color, d_alpha) -> torch.Tensor:
+    """K5b.  d(logits) (R,S,4)."""
+    rays, count = t.shape
+    d_logits = torch.empty((rays, count, 4), dtype=torch.float32, device=t.device)
+    _lib.call("ffn_composite_bwd", _dev(logits), _dev(t), _dev(d_color), _dev(d_alpha),
+              c_i(rays), c_i(count), _dev(d_logits), _stream())
+    return d_logits
+
+
+def mse_loss(color, alpha, gt_colors, gt_alphas, ray_index, color_scale, alpha_scale,
+             want_grad=True):
+    """K6.  Returns (sums (2,), d_color, d_alpha)."""
+    rays = color.shape[0]
+    dev = color.device
+    sums = torch.empty((2,), dtype=torch.float32, device=dev)
+    scratch = torch.empty((2 * ((rays + 255) // 256),), dtype=torch.float32, device=dev)
+    d_color = torch.empty_like(color) if want_grad else None
+    d_alpha = torch.empty_like(alpha) if want_grad else None
+    _lib.call("ffn_mse_loss", _dev(color), _dev(alpha), _dev(gt_colors), _dev(gt_alphas),
+              _dev(ray_index, torch.int64), c_i(rays), c_f(color_scale), c_f(alpha_scale),
+              _dev(sums), _dev(d_color), _dev(d_alpha), _dev(scratch), _stream())
+    return sums, d_color, d_alpha
+
+
+# --------------------------------------------------------------------------------- optimiser
+def clip_adam(params, grads, exp_avg, exp_avg_sq, step: int, lr: float, weight_decay=0.0,
+              clip_value=0.1, max_norm=0.1, beta1=0.9, beta2=0.999, eps=1e-8,
+              scratch=None, norm_out=None):
+    """K7 on flat fp32 buffers; `step` is the 1-based update count."""
+    n = params.numel()
+    if scratch is None:
+        scratch = torch.empty(((n + 1023) // 1024,), dtype=torch.float32, device=params.device)
+    step_size = lr / (1.0 - beta1 ** step)
+    inv_sqrt_bc2 = 1.0 / math.sqrt(1.0 - beta2 ** step)
+    _lib.call("ffn_clip_adam", _dev(params), _dev(grads), _dev(exp_avg), _dev(exp_avg_sq),
+              c_i64(n), c_f(clip_value), c_f(max_norm), c_f(step_size), c_f(inv_sqrt_bc2),
+              c_f(beta1), c_f(beta2), c_f(eps), c_f(weight_decay), _dev(scratch),
+              _dev(norm_out), _stream())

@@ -1,0 +1,299 @@
+/*
+ * ffn_hip.h -- C ABI of libffn_hip.so: the MI355X (gfx950) kernels behind the
+ * fourier_feature_nets volume-rendering hot path.
+ *
+ * The reference (matajoh/fourier_feature_nets) is pure Python on PyTorch and has no
+ * FFI of its own; its "operator interface" for this path is the set of Python methods
+ * cited next to each entry point below (paths relative to the reference root).  Each
+ * entry point replaces the ATen op sequence those lines launch.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a hipError_t value; the message of the
+ *     last failure on the calling thread is available from ffn_last_error_string();
+ *     nothing throws across this boundary
+ *   - the caller owns every buffer and passes raw DEVICE pointers; all arrays are
+ *     contiguous row-major float32 unless the comment says otherwise
+ *   - no hidden allocation, no hidden synchronisation; kernels are enqueued on
+ *     `stream` (a hipStream_t passed as void*; NULL = the default stream)
+ *   - functions are re-entrant and keep no mutable global state
+ *   - one device per call: the device that is current on the calling thread
+ */
+#ifndef FFN_HIP_H
+#define FFN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FFN_ABI_VERSION 1
+
+int ffn_abi_version(void);
+const char* ffn_last_error_string(void);
+
+/* ------------------------------------------------------------------------------------
+ * K1  ray generation + AABB slab test.
+ * Replaces CameraInfo.raycast (camera_info.py:99-109) and RaySampler._near_far
+ * (ray_sampler.py:202-232) for every pixel of every camera.
+ *   unproj      (C,16)  per-camera 4x4 pixel->world matrix (camera_info.py:66-70,
+ *                       computed on the host exactly as the reference does)
+ *   cam_pos     (C,3)   camera positions (extrinsics[:3,3])
+ *   box_lo/hi   (3)     HOST pointers: AABB corners (ray_sampler.py:101-104)
+ *   starts      (C*W*H,3), directions (C*W*H,3), near_far (2,C*W*H)
+ *   valid       (C*W*H) uint8: 1 where near < far (the complement of invalid_rays)
+ * Ray id = cam*W*H + y*W + x, integer pixel coordinates, no half-pixel offset.
+ */
+int ffn_raygen_nearfar(const float* unproj, const float* cam_pos, int num_cameras,
+                       int width, int height, const float* box_lo, const float* box_hi,
+                       float* starts, float* directions, float* near_far, uint8_t* valid,
+                       void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * K2a  t-sampling: gather + anneal + linspace (+ stratified jitter).
+ * Replaces RaySampler.sample up to t_values (ray_sampler.py:364-386) and utils.linspace
+ * (utils.py:179-194).  Bit-exact w.r.t. the reference for identical inputs: every
+ * multiply and add is rounded separately (no FMA contraction).
+ *   near_far    (2,num_rays_total)
+ *   ray_index   (R) int64 ray ids
+ *   unit        (count) torch.linspace(0,1,count) computed on the host
+ *   noise       (R,count) uniform [0,1) block or NULL (not stratified)
+ *   anneal      factor already clamped to [anneal_start,1]; pass a negative value when
+ *               no annealing applies (step is None or step >= num_anneal_steps)
+ *   t_out       (R, t_stride) -- the first `count` entries of each row are written
+ */
+int ffn_sample_t(const float* near_far, int64_t num_rays_total, const int64_t* ray_index,
+                 int num_rays, int count, const float* unit, const float* noise,
+                 float anneal, float* t_out, int t_stride, void* stream);
+
+/* K2b  positions = start + t * dir and view_directions = dir repeated
+ * (ray_sampler.py:394-397).  positions/views are (R,S,3); views may be NULL. */
+int ffn_materialise_samples(const float* starts, const float* directions,
+                            const int64_t* ray_index, const float* t_values, int num_rays,
+                            int num_samples, float* positions, float* views, void* stream);
+
+/* K2c  per-ray CDF from probe opacities (ray_sampler.py:59-67, _determine_cdf).
+ *   t_probe (P,n), opacity (P,n) -> cdf (P,n-1) */
+int ffn_cdf_build(const float* t_probe, const float* opacity, int64_t num_rays, int n,
+                  float* cdf, void* stream);
+
+/* K2d  inverse-transform focus samples + merge with the uniform half + sort
+ * (ray_sampler.py:301-357 and :388-392).
+ *   cdfs (num_rays_total, n_focus-1) indexed by global ray id
+ *   u    (R,n_focus) uniform block (torch.rand, or linspace(0,1,n) repeated)
+ *   t_io (R,S): on entry the first S-n_focus entries of each row hold the uniform
+ *        samples (from ffn_sample_t with t_stride=S); on exit the row holds all S
+ *        samples sorted ascending.  S <= 256. */
+int ffn_focus_sample_merge(const float* near_far, int64_t num_rays_total,
+                           const float* cdfs, const int64_t* ray_index, const float* u,
+                           const float* unit_focus, int num_rays, int num_samples,
+                           int n_focus, float* t_io, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * K3  standalone Fourier feature encoding.
+ * Replaces fourier_feature_models.py:59-68 (scale = pi, optional a_values) and
+ * nerf_model.py:97-102 (scale = 1, include_input appends x).  Output is (N, 2F[+3]),
+ * cos block first.  b is (3,F); a is (F) or NULL.  F == 0 copies x (class MLP).
+ */
+int ffn_fourier_encode(const float* x, int64_t n, const float* b, const float* a,
+                       int num_freq, float scale, int include_input, float* out,
+                       void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * K5  activations + front-to-back alpha compositing, one wavefront per ray.
+ * Replaces Raycaster.render after the model call (ray_caster.py:66-93) and
+ * utils.calculate_blend_weights (utils.py:72-97).
+ *   logits (R,S,4) raw [r,g,b,sigma]; t (R,S)
+ *   color (R,3), alpha (R), depth (R) or NULL
+ *   nan_flag: int32 on the device, OR-ed with 1 if a NaN is seen in sigmoid(rgb) or
+ *             softplus(sigma) (the asserts at ray_caster.py:73-74); may be NULL
+ */
+int ffn_composite_fwd(const float* logits, const float* t, int num_rays, int num_samples,
+                      float* color, float* alpha, float* depth, int32_t* nan_flag,
+                      void* stream);
+
+/* K5b backward of K5: d(loss)/d(logits) from d/d(color) (R,3) and d/d(alpha) (R). */
+int ffn_composite_bwd(const float* logits, const float* t, const float* d_color,
+                      const float* d_alpha, int num_rays, int num_samples,
+                      float* d_logits, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * K6  ground-truth gather + MSE loss + its gradient.
+ * Replaces ImageDataset.render / .loss (image_dataset.py:224-262).
+ *   gt_colors (num_rays_total,3), gt_alphas (num_rays_total) or NULL
+ *   sums      (2) device floats: sum((c-c_gt)^2), sum((a-a_gt)^2) over this call
+ *   d_color = color_scale * 2 (c - c_gt), d_alpha = alpha_scale * 2 (a - a_gt);
+ *   the caller picks color_scale = 1/(3R) and alpha_scale = alpha_weight/R (or the
+ *   global counts under data parallelism).  d_color/d_alpha may be NULL (loss only).
+ *   scratch   (2*ceil(R/256)) floats of workspace
+ */
+int ffn_mse_loss(const float* color, const float* alpha, const float* gt_colors,
+                 const float* gt_alphas, const int64_t* ray_index, int num_rays,
+                 float color_scale, float alpha_scale, float* sums, float* d_color,
+                 float* d_alpha, float* scratch, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * K7  clip_grad_value_ -> clip_grad_norm_ -> Adam(L2 weight decay) on one flat buffer.
+ * Replaces ray_caster.py:327-329 (+ torch.optim.Adam's single-tensor update).
+ *   scratch (ceil(n/1024)) floats; step_size = lr/(1-beta1^t), inv_sqrt_bc2 =
+ *   1/sqrt(1-beta2^t) are computed by the host in double precision.
+ */
+int ffn_clip_adam(float* params, float* grads, float* exp_avg, float* exp_avg_sq,
+                  int64_t n, float clip_value, float max_norm, float step_size,
+                  float inv_sqrt_bc2, float beta1, float beta2, float eps,
+                  float weight_decay, float* scratch, float* grad_norm_out, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * K8  image assembly (ray_sampler.py:191-196): zeros, scatter, (x*255) truncated to u8.
+ *   colors (n,3); pixel_index (n) int64 pixel id inside the frame; image (H*W*3) u8
+ */
+int ffn_to_image(const float* colors, const int64_t* pixel_index, int64_t n, int width,
+                 int height, uint8_t* image, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * K4  fused Fourier-feature MLP (sigma + view-dependent RGB), exact-f32 MFMA.
+ * Replaces FourierFeatureMLP.forward (fourier_feature_models.py:57-78), NeRF.forward
+ * (nerf_model.py:86-124) and their autograd backward.
+ *
+ * The network is described to the kernels as a short chain of dense steps
+ * (ffn_mlp_chain); the same interpreter runs the forward chain and the backward-data
+ * chain.  A wavefront owns 32 consecutive samples; activations never leave the CU
+ * between layers.  Weights are consumed in an MFMA-operand order produced by
+ * ffn_mlp_pack from the natural nn.Linear (out,in) tensors.
+ */
+#define FFN_MAX_STEPS 16
+
+typedef struct ffn_encoding {
+    const float* b;        /* (3,max(F,1)) frequency matrix (device), never NULL      */
+    const float* a;        /* (max(F,1)) amplitudes (device), never NULL              */
+    int32_t num_freq;      /* F; 0 => features are the raw 3 inputs                  */
+    int32_t include_input; /* append x after [cos,sin]                               */
+    float scale;           /* pi (FourierFeatureMLP) or 1 (NeRF)                     */
+    int32_t width;         /* internal feature count padded to a multiple of 16     */
+} ffn_encoding;
+
+/* One dense step.  Its K dimension is [act_groups groups of 8 channels read back from the
+ * wave's activation slab (the previous step's output)] followed by [aux_groups generated
+ * groups]: Fourier features of encoding enc_id in a forward chain (first layer = features
+ * only, hidden layer = activations only, NeRF's skip and view layers = both,
+ * nerf_model.py:112-121), or the d_logits columns [lg_col, lg_col+lg_n) in a backward
+ * chain (the sigma / rgb heads).  act_groups % 4 == 0, aux_groups % 2 == 0.            */
+typedef struct ffn_step {
+    int32_t act_groups;
+    int32_t aux_groups;
+    int32_t enc_id;        /* forward: 0 = position encoding, 1 = view encoding        */
+    int32_t lg_col;        /* backward: first d_logits column feeding this step        */
+    int32_t lg_n;
+    int32_t out_tiles;     /* ceil(out/32): 8, 4, 2 or 1                               */
+    int32_t relu;          /* forward: ReLU on the output                              */
+    int32_t dst;           /* forward: 0 = activation slab, 1 = logits [out_col,+out_n)*/
+    int32_t out_col;
+    int32_t out_n;
+    int32_t save_in_slot;  /* slab that receives the act-part INPUT while it is being
+                              consumed (forward: H for backward; backward: dZ), or -1  */
+    int32_t save_out_slot; /* backward: slab that receives the step's output, or -1    */
+    int32_t mask_slot;     /* backward: slab of the forward activation whose sign gates
+                              the output (ReLU'), or -1                                */
+    int32_t reserved;
+    int64_t w_off;         /* float offset of this step's packed operand weights       */
+    int64_t b_off;         /* forward: float offset of the bias (padded to 32*tiles)   */
+} ffn_step;
+
+typedef struct ffn_mlp_chain {
+    ffn_encoding enc[2];
+    ffn_step step[FFN_MAX_STEPS];
+    int32_t num_steps;
+    int32_t num_slots;                     /* activation slabs                        */
+    int32_t slot_channels[FFN_MAX_STEPS];  /* channels of each slab (multiple of 32)  */
+    int64_t slot_offset[FFN_MAX_STEPS];    /* sum of channels of the slabs before it  */
+} ffn_mlp_chain;
+
+/* Slab ("block") layout, shared by forward, dgrad and wgrad: samples are grouped in blocks
+ * of 32; slab `slot` starts at float offset slot_offset[slot]*num_blocks*32 and holds,
+ * per block, channels*32 floats as float4s indexed [cq][pos], cq = channel/4,
+ * pos = sample_in_block ^ (cq & 15), each float4 = 4 consecutive channels of one sample.
+ * The XOR spreads the weight-gradient kernel's transposed reads over distinct sectors. */
+
+/* Gather a natural (rows, cols) matrix into MFMA A-operand order:
+ *   dst[((g*tiles + o)*64 + lane)*4 + p] = src[row(32*o + (lane&31)) * ld + col(8*g + 4*(lane>>5) + p)]
+ * row_map / col_map (int32, device, may be NULL = identity) translate internal to
+ * natural indices; a negative entry or an index outside [0,rows)x[0,cols) yields 0.
+ * transpose != 0 swaps the roles (operand rows index src columns).                    */
+int ffn_mlp_pack(const float* src, int rows, int cols, int ld, int transpose,
+                 const int32_t* row_map, const int32_t* col_map, int groups, int tiles,
+                 float* dst, void* stream);
+
+/* Forward chain.  positions (N,3), views (N,3) or NULL, logits out (N,4).  saved: when
+ * non-NULL, every step with save_in_slot >= 0 writes its input activations there (block
+ * layout) for the backward pass. */
+int ffn_mlp_forward(const ffn_mlp_chain* chain, const float* packed_w, const float* bias,
+                    const float* positions, const float* views, int64_t n, float* logits,
+                    float* saved, void* stream);
+
+/* Backward-data chain: d_logits (N,4) + saved forward activations -> dZ slabs (same slab
+ * geometry as `saved`).  packed_wt holds the transposed operand packs. */
+int ffn_mlp_backward_data(const ffn_mlp_chain* chain, const float* packed_wt,
+                          const float* d_logits, int64_t n, float* saved, float* dz,
+                          void* stream);
+
+/* Weight gradients.  A job is one 128x128 patch of some dW (kind 0) or the <=4 rows of a
+ * logits head against 128 input channels (kind 1); segments assign contiguous ranges of
+ * 32-sample blocks of a job to persistent waves (seg_start[w] .. seg_start[w+1]); every
+ * segment writes one partial of ffn_mlp_wgrad_partial_floats() floats into slot
+ * `slot` of `partials`. */
+typedef struct ffn_wgrad_job {
+    int32_t kind;      /* 0 = dW patch, 1 = head rows                                  */
+    int32_t m_slot;    /* kind 0: dZ slab providing the 128 output channels            */
+    int32_t m_cq0;     /*         first channel quad inside that slab                  */
+    int32_t m_quads;   /*         valid quads (<= 32)                                  */
+    int32_t n_kind;    /* input panel: 0 = saved activation slab, 1 = encoding         */
+    int32_t n_slot;    /*         slab index, or encoding id                           */
+    int32_t n_cq0;     /*         first channel quad (slab) / internal quad (encoding) */
+    int32_t n_quads;   /*         valid quads (<= 32)                                  */
+    int32_t lg_col;    /* kind 1: d_logits columns [lg_col, lg_col+lg_n)               */
+    int32_t lg_n;
+    int32_t reserved0;
+    int32_t reserved1;
+} ffn_wgrad_job;
+
+typedef struct ffn_wgrad_segment {
+    int32_t job;
+    int32_t slot;
+    int64_t blk_begin;
+    int64_t blk_end;
+} ffn_wgrad_segment;
+
+int ffn_mlp_wgrad(const ffn_mlp_chain* chain, const ffn_wgrad_job* jobs,
+                  const ffn_wgrad_segment* segments, const int32_t* seg_start, int num_waves,
+                  const float* saved, const float* dz, const float* d_logits,
+                  const float* positions, const float* views, int64_t n, float* partials,
+                  void* stream);
+
+/* Fixed-order reduction of the partials of each job into the flat natural-layout
+ * gradient buffer (nn.Linear weight (out,in) row-major, then bias). */
+typedef struct ffn_reduce_job {
+    int32_t kind;
+    int32_t slot_begin, slot_end;  /* contiguous partial slots of this job             */
+    int32_t m_ch0;                 /* kind 0: first output channel of the patch        */
+    int32_t rows;                  /* output rows of the layer                         */
+    int32_t n_quad0;               /* first input quad of the panel                    */
+    int32_t n_quads;
+    int32_t k_base;                /* index of the panel's first quad in col_map space */
+    int32_t ld;                    /* leading dimension (= in_features) of dW          */
+    int32_t has_bias;              /* this job also carries the bias gradient          */
+    int32_t lg_n;
+    int32_t reserved;
+    int64_t w_grad_off;            /* float offset of dW inside `grads`                */
+    int64_t b_grad_off;            /* float offset of db inside `grads`                */
+    const int32_t* col_map;        /* internal K index -> natural column, or -1        */
+} ffn_reduce_job;
+
+int ffn_mlp_wgrad_reduce(const ffn_reduce_job* jobs, int num_jobs, const float* partials,
+                         float* grads, void* stream);
+
+int64_t ffn_mlp_wgrad_partial_floats(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FFN_HIP_H */
