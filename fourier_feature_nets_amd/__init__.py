@@ -5,6 +5,9 @@ of ``include/ffn_hip.h``; this package is the host-side mirror of the reference'
 for that path.  There is no CPU fallback: using a model or sampler without a GPU raises.
 """
 
+from .cameras import CameraInfo, Resolution, orbit
+from .caster import LogEntry, Raycaster, TrainEngine
+from .dataset import ImageDataset, RayDataset
 from .models import (
     BasicFourierMLP,
     FourierFeatureMLP,
@@ -13,5 +16,21 @@ from .models import (
     NeRF,
     PositionalFourierMLP,
 )
+from .sampler import RaySampler, RaySamples
+from .utils import (
+    ETABar,
+    RenderResult,
+    calculate_blend_weights,
+    exponential_lr_decay,
+    linspace,
+    load_model,
+)
+from .voxels import Voxels
 
 __version__ = "0.1.0"
+
+__all__ = ["__version__", "BasicFourierMLP", "CameraInfo", "ETABar", "FourierFeatureMLP",
+           "GaussianFourierMLP", "ImageDataset", "LogEntry", "MLP", "NeRF",
+           "PositionalFourierMLP", "RayDataset", "RaySampler", "RaySamples", "Raycaster",
+           "RenderResult", "Resolution", "TrainEngine", "Voxels", "calculate_blend_weights",
+           "exponential_lr_decay", "linspace", "load_model", "orbit"]

@@ -1,0 +1,348 @@
+"""Differentiable volumetric raycaster + trainer behind the reference's ``Raycaster`` surface
+(ray_caster.py:36-377).
+
+``render`` is an autograd-visible composition of the fused MLP and the composite kernel.
+``fit`` keeps the reference's loop structure (LR schedule, epoch shuffles, crop curriculum,
+validation cadence, log format) but runs each optimisation step through ``TrainEngine``:
+sampling -> fused forward -> composite -> loss -> composite backward -> dgrad/wgrad ->
+(RCCL all-reduce) -> fused clip+Adam, all on one HIP stream over flat fp32 buffers, without
+Python-side autograd and without host synchronisation.
+"""
+
+import copy
+import time
+from typing import List, NamedTuple, Optional, OrderedDict
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .dataset import RayDataset
+from .sampler import RaySampler, RaySamples
+from .utils import RenderResult, learning_rate_at
+
+LogEntry = NamedTuple("LogEntry", [("step", int), ("timestamp", float),
+                                   ("state", OrderedDict[str, torch.Tensor]),
+                                   ("train_psnr", float), ("val_psnr", float)])
+
+
+class _Composite(torch.autograd.Function):
+    """sigmoid / softplus + front-to-back compositing (kernels K5 / K5b)."""
+
+    @staticmethod
+    def forward(ctx, logits, t_values, include_depth, nan_flag):
+        logits = logits.contiguous()
+        t_values = t_values.contiguous()
+        color, alpha, depth = ops.composite_fwd(logits, t_values, include_depth, nan_flag)
+        ctx.save_for_backward(logits, t_values)
+        if depth is None:
+            depth = torch.empty((0,), device=logits.device)
+        ctx.mark_non_differentiable(depth)
+        return color, alpha, depth
+
+    @staticmethod
+    def backward(ctx, d_color, d_alpha, _d_depth):
+        logits, t_values = ctx.saved_tensors
+        d_logits = ops.composite_bwd(logits, t_values, d_color.contiguous(), d_alpha.contiguous())
+        return d_logits, None, None, None
+
+
+class TrainEngine:
+    """One optimisation step as a straight line of kernel launches over flat buffers."""
+
+    def __init__(self, model: nn.Module, weight_decay: float = 0.0, process_group=None):
+        self.model = model
+        params = model._dense_params()
+        device = params[0].device
+        if device.type != "cuda":
+            raise RuntimeError("training runs on the HIP kernels only; move the model to a GPU")
+        total = sum(p.numel() for p in params)
+        flat = torch.empty((total,), dtype=torch.float32, device=device)
+        offset = 0
+        for p in params:                      # nn.Parameters become views of one buffer
+            n = p.numel()
+            flat[offset:offset + n].copy_(p.data.reshape(-1))
+            p.data = flat[offset:offset + n].view(p.shape)
+            offset += n
+        self.flat = flat
+        self.grads = torch.zeros_like(flat)
+        self.exp_avg = torch.zeros_like(flat)
+        self.exp_avg_sq = torch.zeros_like(flat)
+        self.scratch = torch.empty(((total + 1023) // 1024,), dtype=torch.float32, device=device)
+        self.grad_norm = torch.zeros((1,), dtype=torch.float32, device=device)
+        self.nan_flag = torch.zeros((1,), dtype=torch.int32, device=device)
+        self.weight_decay = weight_decay
+        self.count = 0
+        self.device = device
+        self.group = process_group
+        self._saved = {}
+        self.loss_history = None          # set to [] to record every step's loss (device scalars)
+        model.invalidate_packed()
+        assert model.program().num_grad_floats == total
+
+    # ------------------------------------------------------------------ pieces
+    def _saved_buffer(self, prog, n):
+        need = prog.saved_floats(n)
+        buf = self._saved.get("buf")
+        if buf is None or buf.numel() < need:
+            buf = torch.empty((need,), dtype=torch.float32, device=self.device)
+            self._saved["buf"] = buf
+        return buf
+
+    def _samples(self, sampler: RaySampler, rays: torch.Tensor, step: Optional[int]):
+        t = sampler.sample_t(rays, step)
+        pos, views = ops.materialise_samples(sampler.starts, sampler.directions, rays, t,
+                                             want_views=self.model.use_view)
+        return t, pos.view(-1, 3), None if views is None else views.view(-1, 3)
+
+    def shard(self, rays: torch.Tensor) -> torch.Tensor:
+        """This rank's contiguous slice of the (already valid-filtered) global batch."""
+        if self.group is None:
+            return rays
+        import torch.distributed as dist
+        world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
+        per = -(-rays.numel() // world)
+        return rays[rank * per:(rank + 1) * per].contiguous()
+
+    # ------------------------------------------------------------------ train / eval
+    def train_step(self, dataset, batch, step: int, lr: float) -> torch.Tensor:
+        """zero_grad -> loss -> backward -> clip value -> clip norm -> Adam, as
+        ray_caster.py:319-329.  Returns the (global) batch loss as a device scalar."""
+        sampler = dataset.sampler
+        all_rays = dataset.ray_ids(batch)
+        global_count = int(all_rays.numel())
+        rays = self.shard(all_rays)
+        count = int(rays.numel())
+        alphas = dataset._gt_alphas()
+        aw = float(dataset.alpha_weight) if alphas is not None else 0.0
+        prog = self.model.program()
+        if count > 0:
+            t, pos, views = self._samples(sampler, rays, step)
+            saved = self._saved_buffer(prog, pos.shape[0])
+            logits = prog.forward(pos, views, saved)
+            color, alpha, _ = ops.composite_fwd(logits, t, False, self.nan_flag)
+            sums, d_color, d_alpha = ops.mse_loss(color, alpha, dataset.colors, alphas, rays,
+                                                  1.0 / (3 * global_count), aw / global_count)
+            d_logits = ops.composite_bwd(logits, t, d_color, d_alpha)
+            prog.backward(d_logits.view(-1, 4), pos, views, saved, self.grads)
+        else:
+            sums = torch.zeros((2,), dtype=torch.float32, device=self.device)
+            self.grads.zero_()
+        if self.group is not None:
+            import torch.distributed as dist
+            dist.all_reduce(self.grads, group=self.group)      # RCCL over xGMI, one flat buffer
+            dist.all_reduce(sums, group=self.group)
+        self.count += 1
+        ops.clip_adam(self.flat, self.grads, self.exp_avg, self.exp_avg_sq, self.count, lr,
+                      weight_decay=self.weight_decay, scratch=self.scratch,
+                      norm_out=self.grad_norm)
+        self.model.invalidate_packed()
+        loss = sums[0] / (3 * global_count) + aw * (sums[1] / global_count)
+        if self.loss_history is not None:
+            self.loss_history.append(loss)
+        return loss
+
+    def eval_loss(self, dataset, batch, step: Optional[int]) -> torch.Tensor:
+        """Forward-only loss of a batch (the body of ``_validate``)."""
+        sampler = dataset.sampler
+        rays = dataset.ray_ids(batch)
+        count = int(rays.numel())
+        alphas = dataset._gt_alphas()
+        aw = float(dataset.alpha_weight) if alphas is not None else 0.0
+        t, pos, views = self._samples(sampler, rays, step)
+        logits = self.model.program().forward(pos, views, None)
+        color, alpha, _ = ops.composite_fwd(logits, t, False, self.nan_flag)
+        sums, _, _ = ops.mse_loss(color, alpha, dataset.colors, alphas, rays, 1.0, 1.0,
+                                  want_grad=False)
+        return sums[0] / (3 * count) + aw * (sums[1] / count)
+
+    def check_finite(self):
+        """Raises like the asserts at ray_caster.py:73-74 (checked lazily: one sync)."""
+        assert int(self.nan_flag.item()) == 0, "NaN in sigmoid(rgb) / softplus(sigma)"
+
+
+class Raycaster(nn.Module):
+    """Volumetric raycaster around a radiance-field model."""
+
+    def __init__(self, model: nn.Module):
+        nn.Module.__init__(self)
+        self.model = model
+        self._nan_flag = None
+        self.shuffle_source = "numpy"     # epoch permutations from np.random like the reference
+        self.process_group = None         # set to a torch.distributed group for data parallel
+
+    # ------------------------------------------------------------------ rendering
+    def _flag(self, device):
+        if self._nan_flag is None or self._nan_flag.device != device:
+            self._nan_flag = torch.zeros((1,), dtype=torch.int32, device=device)
+        return self._nan_flag
+
+    def check_finite(self):
+        if self._nan_flag is not None:
+            assert int(self._nan_flag.item()) == 0, "NaN in sigmoid(rgb) / softplus(sigma)"
+
+    def render(self, ray_samples: RaySamples, include_depth=False) -> RenderResult:
+        """Per-ray colour / alpha / depth of the samples; differentiable w.r.t. the model
+        (ray_caster.py:48-93)."""
+        num_rays, num_samples = ray_samples.positions.shape[:2]
+        positions = ray_samples.positions.reshape(-1, 3)
+        if self.model.use_view:
+            logits = self.model(positions, ray_samples.view_directions.reshape(-1, 3))
+        else:
+            logits = self.model(positions)
+        logits = logits.reshape(num_rays, num_samples, 4)
+        color, alpha, depth = _Composite.apply(logits, ray_samples.t_values, include_depth,
+                                               self._flag(logits.device))
+        return RenderResult(color, alpha, depth if include_depth else None)
+
+    def _loss(self, step: int, dataset: RayDataset, batch) -> torch.Tensor:
+        device = next(self.model.parameters()).device
+        rays = dataset.get_rays(batch, step).to(device)
+        return dataset.loss(step, rays, self.render(rays, True))
+
+    def batched_render(self, samples: RaySamples, batch_size: int,
+                       include_depth: bool) -> RenderResult:
+        """Renders in batches without gradients; returns numpy arrays
+        (ray_caster.py:103-138)."""
+        self.model.eval()
+        colors, alphas, depths = [], [], []
+        with torch.no_grad():
+            device = next(self.model.parameters()).device
+            total = len(samples.positions)
+            for start in range(0, total, batch_size):
+                end = min(start + batch_size, total)
+                pred = self.render(samples.subset(slice(start, end)).to(device), include_depth)
+                colors.append(pred.color)
+                alphas.append(pred.alpha)
+                if include_depth:
+                    depths.append(pred.depth)
+        self.model.train()
+        out = RenderResult(torch.cat(colors), torch.cat(alphas),
+                           torch.cat(depths) if include_depth else None).numpy()
+        self.check_finite()
+        return out
+
+    def render_image(self, sampler: RaySampler, index: int, batch_size: int,
+                     color_space="RGB") -> np.ndarray:
+        """(H,W,3) uint8 frame of camera ``index % num_cameras`` (ray_caster.py:140-159)."""
+        camera = index % sampler.num_cameras
+        self.model.eval()
+        with torch.no_grad():
+            rays = sampler._valid_for_camera(camera)
+            colors = torch.empty((rays.numel(), 3), dtype=torch.float32, device=sampler.device)
+            for start in range(0, rays.numel(), batch_size):
+                chunk = sampler.sample(rays[start:start + batch_size].contiguous(), None)
+                colors[start:start + batch_size] = self.render(chunk, False).color
+        self.model.train()
+        image = ops.to_image(colors, (rays - camera * sampler.rays_per_camera).contiguous(),
+                             sampler.image_width, sampler.image_height)
+        self.check_finite()
+        return image.cpu().numpy()
+
+    def render_activations(self, *args, **kwargs):
+        raise NotImplementedError("render_activations is a lecture visualisation outside the "
+                                  "HIP hot path")
+
+    def to_scenepic(self, *args, **kwargs):
+        raise NotImplementedError("scenepic export is outside the HIP hot path")
+
+    # ------------------------------------------------------------------ training
+    def _validate(self, engine: TrainEngine, dataset: RayDataset, batch_size: int,
+                  step: int) -> float:
+        """PSNR = -10 log10(mean batch loss) over <= 102400 evenly spaced rays, full batches
+        only (ray_caster.py:220-246)."""
+        num_rays = len(dataset)
+        num_validate = min(num_rays, 1024 * 100)
+        if num_validate < num_rays:
+            index = np.linspace(0, num_rays, num_validate, endpoint=False).astype(np.int32)
+            index = np.asarray(dataset.to_valid(index.tolist()), np.int64)
+        else:
+            index = np.arange(num_rays)
+        index = torch.from_numpy(np.asarray(index, np.int64)).to(engine.device)
+        losses = []
+        self.model.eval()
+        for start in range(0, num_validate, batch_size):
+            if start + batch_size > len(index):
+                break
+            losses.append(engine.eval_loss(dataset, index[start:start + batch_size], step))
+        self.model.train()
+        if not losses:                       # tiny dataset: one short batch instead of a crash
+            losses.append(engine.eval_loss(dataset, index, step))
+        mean = float(torch.stack(losses).mean().item())
+        return float(-10. * np.log10(mean))
+
+    def fit(self, train_dataset: RayDataset, val_dataset: RayDataset, batch_size: int,
+            learning_rate: float, num_steps: int, crop_steps: int, report_interval: int,
+            decay_rate: float, decay_steps: int, weight_decay: float, visualizers: List,
+            disable_aml=False) -> List[LogEntry]:
+        """Trains the model; same arguments, schedule and log lines as ray_caster.py:248-377."""
+        trainval_dataset = train_dataset.sample_cameras(val_dataset.num_cameras,
+                                                        val_dataset.num_samples, False)
+        engine = TrainEngine(self.model, weight_decay, self.process_group)
+        self.engine = engine
+        step = 0
+        start_time = time.time()
+        log = []
+        dataset_mode = train_dataset.mode
+        if crop_steps:
+            for ds in (train_dataset, val_dataset, trainval_dataset):
+                ds.mode = RayDataset.Mode.Center
+        else:
+            val_dataset.mode = dataset_mode
+            trainval_dataset.mode = dataset_mode
+
+        def render_image(samples: RaySamples, include_depth: bool):
+            return self.batched_render(samples, batch_size, include_depth)
+
+        def render_act(sampler: RaySampler, camera: int):
+            return self.render_activations(sampler, camera, batch_size, train_dataset.color_space)
+
+        is_main = self.process_group is None or torch.distributed.get_rank(self.process_group) == 0
+        while step <= num_steps:
+            num_rays = len(train_dataset)
+            if self.shuffle_source == "numpy":
+                order = np.arange(num_rays)
+                np.random.shuffle(order)
+                order = torch.from_numpy(order).to(engine.device)
+            else:
+                order = torch.randperm(num_rays, device=engine.device)
+            for start in range(0, num_rays, batch_size):
+                if step > num_steps:
+                    break
+                lr = learning_rate_at(learning_rate, step, decay_rate, decay_steps)
+                batch = order[start:min(start + batch_size, num_rays)]
+                engine.train_step(train_dataset, batch, step, lr)
+
+                if step < 10 or step % report_interval == 0:
+                    engine.check_finite()
+                    train_psnr = self._validate(engine, trainval_dataset, batch_size, step)
+                    val_psnr = self._validate(engine, val_dataset, batch_size, step)
+                    now = time.time()
+                    if step >= report_interval:
+                        per_step = (now - start_time) / step
+                        eta = time.strftime("%a, %d %b %Y %H:%M:%S +0000",
+                                            time.gmtime(now + (num_steps - step) * per_step))
+                    else:
+                        per_step = 0
+                        eta = "N/A"
+                    if is_main:
+                        print("{:07}".format(step), "{:2f} s/step".format(per_step),
+                              "psnr_train: {:2f}".format(train_psnr),
+                              "val_psnr: {:2f}".format(val_psnr), "lr: {:.2e}".format(lr),
+                              "eta:", eta)
+                    if step % report_interval == 0:
+                        state = copy.deepcopy(self.model.state_dict())
+                        log.append(LogEntry(step, now - start_time, state, train_psnr, val_psnr))
+                    if train_dataset.mode == RayDataset.Mode.Center and step >= crop_steps:
+                        if is_main:
+                            print("Removing center crop...")
+                        for ds in (train_dataset, val_dataset, trainval_dataset):
+                            ds.mode = dataset_mode
+                        step += 1
+                        break
+
+                for visualizer in visualizers:
+                    visualizer.visualize(step, render_image, render_act)
+                step += 1
+        return log

@@ -119,6 +119,36 @@ composite_fwd_kernel(const float4* __restrict__ logits, const float* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------- K5w
+__global__ void __launch_bounds__(256)
+blend_weights_kernel(const float* __restrict__ t, const float* __restrict__ sigma, int R, int S,
+                     float* __restrict__ weights) {
+    const int lane = lane_id();
+    const int wave = (int)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6);
+    const int waves = (int)((gridDim.x * (int64_t)blockDim.x) >> 6);
+    const int rows = (S + 63) >> 6;
+    for (int ray = wave; ray < R; ray += waves) {
+        const float* tr = t + (int64_t)ray * S;
+        const float* sg = sigma + (int64_t)ray * S;
+        float carry = 1.0f;
+        for (int row = 0; row < rows; ++row) {
+            const int s = row * 64 + lane;
+            float alpha = 0.0f, tau = 1.0f;
+            if (s < S) {
+                const float delta = (s == S - 1) ? 1e10f : tr[s + 1] - tr[s];
+                alpha = 1.0f - expf(-(sg[s] * delta));
+                const float u = (1.0f - alpha) + 1e-10f;
+                tau = u < 1.0f ? u : 1.0f;
+            }
+            const float incl = wave_scan_mul(tau, lane);
+            float excl = __shfl_up(incl, 1, 64);
+            if (lane == 0) excl = 1.0f;
+            if (s < S) weights[(int64_t)ray * S + s] = alpha * (carry * excl);
+            carry *= __shfl(incl, 63, 64);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------- K5b
 // Recomputes the forward terms (cheaper than storing 12 B/sample) and walks the rows in
 // reverse to form Q_s = sum_{j>s} g_j w_j, the quantity cumprod's backward needs.
@@ -248,6 +278,15 @@ extern "C" int ffn_composite_fwd(const float* logits, const float* t, int num_ra
                        (hipStream_t)stream, (const float4*)logits, t, num_rays, num_samples, color,
                        alpha, depth, nan_flag);
     return check_launch("ffn_composite_fwd");
+}
+
+extern "C" int ffn_blend_weights(const float* t, const float* sigma, int num_rays,
+                                 int num_samples, float* weights, void* stream) {
+    if (num_rays == 0) return 0;
+    if (num_rays < 0 || num_samples < 1) return fail_arg("ffn_blend_weights: shape");
+    hipLaunchKernelGGL(blend_weights_kernel, dim3(ray_grid(num_rays)), dim3(256), 0,
+                       (hipStream_t)stream, t, sigma, num_rays, num_samples, weights);
+    return check_launch("ffn_blend_weights");
 }
 
 extern "C" int ffn_composite_bwd(const float* logits, const float* t, const float* d_color,

@@ -10,7 +10,8 @@ namespace ffn {
 // One thread per (camera, pixel).  33 B written per ray, nothing but 76 B/camera read.
 __global__ void __launch_bounds__(256)
 raygen_nearfar_kernel(const float* __restrict__ unproj, const float* __restrict__ cam_pos,
-                      int num_cameras, int width, int height, float3 lo, float3 hi,
+                      const float* __restrict__ points, int num_cameras, int width, int height,
+                      float3 lo, float3 hi,
                       float* __restrict__ starts, float* __restrict__ dirs,
                       float* __restrict__ near_far, uint8_t* __restrict__ valid) {
     const int64_t per_cam = (int64_t)width * height;
@@ -19,8 +20,9 @@ raygen_nearfar_kernel(const float* __restrict__ unproj, const float* __restrict_
          ray += (int64_t)gridDim.x * blockDim.x) {
         const int cam = (int)(ray / per_cam);
         const int pix = (int)(ray - cam * per_cam);
-        const float px = (float)(pix % width);
-        const float py = (float)(pix / width);
+        // explicit (P,2) pixel coordinates (CameraInfo.raycast) or the integer grid
+        const float px = points != nullptr ? points[2 * pix + 0] : (float)(pix % width);
+        const float py = points != nullptr ? points[2 * pix + 1] : (float)(pix / width);
         const float* u = unproj + cam * 16;
         const float cx = cam_pos[cam * 3 + 0], cy = cam_pos[cam * 3 + 1], cz = cam_pos[cam * 3 + 2];
         // world = U @ [x, y, 1, 1]; k-ordered fused chain like a 4-deep SGEMM micro-kernel
@@ -133,8 +135,9 @@ static inline int grid_for(int64_t n, int block = 256, int cap = 256 * 8) {
 
 using namespace ffn;
 
-extern "C" int ffn_raygen_nearfar(const float* unproj, const float* cam_pos, int num_cameras,
-                                  int width, int height, const float* box_lo,
+extern "C" int ffn_raygen_nearfar(const float* unproj, const float* cam_pos,
+                                  const float* points, int num_cameras, int width, int height,
+                                  const float* box_lo,
                                   const float* box_hi, float* starts, float* directions,
                                   float* near_far, uint8_t* valid, void* stream) {
     if (num_cameras <= 0 || width <= 0 || height <= 0) return fail_arg("ffn_raygen_nearfar: empty");
@@ -142,7 +145,7 @@ extern "C" int ffn_raygen_nearfar(const float* unproj, const float* cam_pos, int
     const float3 lo = make_float3(box_lo[0], box_lo[1], box_lo[2]);
     const float3 hi = make_float3(box_hi[0], box_hi[1], box_hi[2]);
     hipLaunchKernelGGL(raygen_nearfar_kernel, dim3(grid_for(total)), dim3(256), 0,
-                       (hipStream_t)stream, unproj, cam_pos, num_cameras, width, height, lo, hi,
+                       (hipStream_t)stream, unproj, cam_pos, points, num_cameras, width, height, lo, hi,
                        starts, directions, near_far, valid);
     return check_launch("ffn_raygen_nearfar");
 }

@@ -1,0 +1,344 @@
+"""Image-backed ray dataset behind the reference's ``RayDataset`` / ``ImageDataset`` surface
+(ray_dataset.py:17-242, image_dataset.py:20-482), with everything the training loop touches
+kept on the GPU: ground-truth colours / alphas per ray, the index maps of the sampling modes
+and the validity filter.  ``get_rays`` never round-trips through Python lists.
+"""
+
+import os
+from abc import ABC
+from enum import Enum
+from typing import List, Optional, Set, Union
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .cameras import CameraInfo, Resolution
+from .sampler import RaySampler, RaySamples
+from .utils import ETABar, RenderResult
+
+
+class _MseLoss(torch.autograd.Function):
+    """colour-MSE + alpha_weight * alpha-MSE against the ground truth of the given rays
+    (kernel K6: gather, masking of transparent pixels, loss sums and gradient in one pass)."""
+
+    @staticmethod
+    def forward(ctx, color, alpha, gt_colors, gt_alphas, rays, alpha_weight):
+        count = color.shape[0]
+        use_alpha = gt_alphas is not None and alpha_weight > 0
+        sums, d_color, d_alpha = ops.mse_loss(
+            color.contiguous(), alpha.contiguous(), gt_colors, gt_alphas, rays,
+            1.0 / (3 * count), (alpha_weight / count) if use_alpha else 0.0)
+        ctx.save_for_backward(d_color, d_alpha)
+        loss = sums[0] / (3 * count)
+        if use_alpha:
+            loss = loss + alpha_weight * (sums[1] / count)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad):
+        d_color, d_alpha = ctx.saved_tensors
+        return grad * d_color, grad * d_alpha, None, None, None, None
+
+
+class RayDataset(ABC):
+    """Interface shared by ray datasets; only the sampling ``Mode`` and two helpers live here."""
+
+    class Mode(Enum):
+        Full = 0      # every valid ray
+        Sparse = 1    # a coarse regular grid per image
+        Center = 2    # the central half-size crop
+        Dilate = 3    # a dilated neighbourhood of the alpha mask
+        Patch = 4     # reserved by the reference, unused
+
+    def to_image(self, camera: int, colors: np.ndarray) -> np.ndarray:
+        """Per-ray colours (in dataset order for this camera) -> (H,W,3) uint8."""
+        colors = np.asarray(colors, np.float32)
+        if colors.ndim == 1:
+            colors = np.repeat(colors[:, None], 3, 1)
+        res = self.cameras[camera].resolution
+        pixel = torch.as_tensor(np.asarray(self.index_for_camera(camera), np.int64))
+        dev = self.sampler.device
+        image = ops.to_image(torch.from_numpy(colors).to(dev).contiguous(),
+                             pixel.to(dev).contiguous(), res.width, res.height)
+        return image.cpu().numpy()
+
+    def sample_cameras(self, num_cameras: int, num_samples: int, stratified: bool) -> "RayDataset":
+        """Farthest-point subset of the cameras (ray_dataset.py:185-216)."""
+        if self.num_cameras < num_cameras:
+            chosen = list(range(self.num_cameras))
+        else:
+            pos = np.concatenate([cam.position for cam in self.sampler.cameras])
+            chosen = [0]
+            while len(chosen) < num_cameras:
+                dist = np.square(pos[:, None, :] - pos[None, chosen, :]).sum(-1).min(-1)
+                dist = np.array(dist, np.float32)
+                dist[chosen] = -1
+                rest = [i for i in range(len(pos)) if i not in chosen]
+                chosen.append(rest[int(np.argmax(dist[rest]))])
+            chosen = sorted(chosen)
+        return self.subset(chosen, num_samples, stratified, self.label)
+
+
+def _ellipse(size: int) -> np.ndarray:
+    """Elliptical structuring element following OpenCV's published construction."""
+    r = size // 2
+    c = size // 2
+    out = np.zeros((size, size), np.uint8)
+    inv_r2 = 1.0 / (r * r) if r else 0.0
+    for i in range(size):
+        dy = i - r
+        if abs(dy) <= r:
+            dx = int(round(c * np.sqrt((r * r - dy * dy) * inv_r2)))
+            out[i, max(c - dx, 0):min(c + dx + 1, size)] = 1
+    return out
+
+
+class ImageDataset(RayDataset):
+    """Rays + ground truth built from a stack of RGBA images and their cameras."""
+
+    def __init__(self, label: str, images: np.ndarray, bounds: np.ndarray,
+                 cameras: List[CameraInfo], num_samples: int, include_alpha=True,
+                 stratified=False, opacity_model: nn.Module = None, batch_size=4096,
+                 color_space="RGB", sparse_size=50, anneal_start=0.2, num_anneal_steps=0,
+                 alpha_weight=0.1, device=None):
+        assert len(images.shape) == 4
+        assert len(images) == len(cameras)
+        assert images.dtype == np.uint8
+        if color_space != "RGB":
+            raise NotImplementedError("only the RGB colour space is supported (YCrCb needs OpenCV)")
+        self._color_space = color_space
+        self._mode = RayDataset.Mode.Full
+        self.image_height, self.image_width = images.shape[1:3]
+        self._images = images
+        self._label = label
+        self.include_alpha = include_alpha
+        self._subsample_index = None
+        self._subsample_mask = None
+        self.sampler = RaySampler(bounds, cameras, num_samples, stratified, opacity_model,
+                                  batch_size, anneal_start, num_anneal_steps, device=device)
+        dev = self.sampler.device
+        width, height = self.image_width, self.image_height
+        per_cam = width * height
+        cam_offsets = torch.arange(len(images), dtype=torch.int64, device=dev) * per_cam
+
+        # central half-size crop: x in [W//4, W - W//4), y likewise (image_dataset.py:77-90)
+        x0, y0 = width // 4, height // 4
+        xs = torch.arange(x0, width - x0, dtype=torch.int64, device=dev)
+        ys = torch.arange(y0, height - y0, dtype=torch.int64, device=dev)
+        crop = (ys[:, None] * width + xs[None, :]).reshape(-1)
+        self.crop_rays_per_camera = int(crop.numel())
+        self.crop_index = (cam_offsets[:, None] + crop[None, :]).reshape(-1)
+
+        sparse = torch.as_tensor(self._subsample_rays(sparse_size), dtype=torch.int64, device=dev)
+        self.sparse_size = sparse_size
+        self.sparse_resolution = (sparse_size * width // height, sparse_size)
+        self.sparse_rays_per_camera = int(sparse.numel())
+        self.sparse_index = (cam_offsets[:, None] + sparse[None, :]).reshape(-1)
+
+        # u8 -> float32 / 255 on the host with numpy, bit-identical to the reference's
+        # ground truth (a GPU division by a constant may differ in the last ulp)
+        self.colors = torch.from_numpy(
+            (images[..., :3].astype(np.float32) / 255).reshape(-1, 3)).to(dev).contiguous()
+        self.dilate_ranges = []
+        self.dilate_index = torch.zeros((0,), dtype=torch.int64, device=dev)
+        has_alpha = images.shape[-1] == 4
+        if has_alpha:
+            alpha = torch.from_numpy(images[..., 3].astype(np.float32) / 255).to(dev)
+            radius = 8 * min(width, height) // 100
+            element = torch.from_numpy(_ellipse(2 * radius + 1)).float().to(dev)
+            mask = (alpha > 0).float().unsqueeze(1)
+            grown = torch.nn.functional.conv2d(mask, element[None, None], padding=radius) > 0
+            found, total = [], 0
+            for cam in range(len(images)):
+                ids = torch.nonzero(grown[cam, 0].reshape(-1)).flatten() + cam * per_cam
+                self.dilate_ranges.append((total, total + int(ids.numel())))
+                total += int(ids.numel())
+                found.append(ids)
+            self.dilate_index = torch.cat(found)
+        if has_alpha and include_alpha:
+            self.alphas = alpha.reshape(-1).contiguous()
+            self.alpha_weight = alpha_weight
+        else:
+            self.alphas = None
+            self.alpha_weight = 0
+
+    # ------------------------------------------------------------------ properties
+    @property
+    def color_space(self) -> str:
+        return self._color_space
+
+    @property
+    def mode(self) -> RayDataset.Mode:
+        return self._mode
+
+    @mode.setter
+    def mode(self, value: RayDataset.Mode):
+        if value == RayDataset.Mode.Dilate and len(self.dilate_index) == 0:
+            raise ValueError("Unable to use dilate mode: missing alpha channel")
+        self._mode = value
+
+    @property
+    def subsample_index(self) -> Optional[Set[int]]:
+        return self._subsample_index
+
+    @subsample_index.setter
+    def subsample_index(self, index: Optional[Set[int]]):
+        self._subsample_index = index
+        self._subsample_mask = None
+        if index:
+            mask = torch.zeros((self.sampler.rays_per_camera,), dtype=torch.bool,
+                               device=self.sampler.device)
+            mask[torch.as_tensor(sorted(index), dtype=torch.int64, device=mask.device)] = True
+            self._subsample_mask = mask
+
+    @property
+    def images(self) -> np.ndarray:
+        return self._images
+
+    @property
+    def label(self) -> str:
+        return self._label
+
+    @property
+    def num_cameras(self) -> int:
+        return self.sampler.num_cameras
+
+    @property
+    def num_samples(self) -> int:
+        return self.sampler.num_samples
+
+    @property
+    def cameras(self) -> List[CameraInfo]:
+        return self.sampler.cameras
+
+    # ------------------------------------------------------------------ indexing
+    def _mode_index(self) -> Optional[torch.Tensor]:
+        if self._mode == RayDataset.Mode.Center:
+            return self.crop_index
+        if self._mode == RayDataset.Mode.Sparse:
+            return self.sparse_index
+        if self._mode == RayDataset.Mode.Dilate:
+            return self.dilate_index
+        if self._mode == RayDataset.Mode.Full:
+            return None
+        raise NotImplementedError("Unsupported sampling mode")
+
+    def __len__(self) -> int:
+        index = self._mode_index()
+        return len(self.sampler) if index is None else int(index.numel())
+
+    def _camera_span(self, camera: int):
+        if self._mode == RayDataset.Mode.Center:
+            return camera * self.crop_rays_per_camera, (camera + 1) * self.crop_rays_per_camera
+        if self._mode == RayDataset.Mode.Sparse:
+            return camera * self.sparse_rays_per_camera, (camera + 1) * self.sparse_rays_per_camera
+        if self._mode == RayDataset.Mode.Dilate:
+            return self.dilate_ranges[camera]
+        return camera * self.sampler.rays_per_camera, (camera + 1) * self.sampler.rays_per_camera
+
+    def ray_ids(self, idx) -> torch.Tensor:
+        """Dataset-local indices -> global ids of the valid rays among them (device tensor)."""
+        sampler = self.sampler
+        local = sampler._index_tensor(idx)
+        index = self._mode_index()
+        rays = local if index is None else index[local]
+        if self._subsample_mask is not None:
+            rays = rays[self._subsample_mask[rays % sampler.rays_per_camera]]
+        return sampler.valid_index(rays)
+
+    def to_valid(self, idx: List[int]) -> List[int]:
+        return self.sampler.to_valid(idx)
+
+    def index_for_camera(self, camera: int) -> List[int]:
+        """Pixel ids (inside the image) of this camera's rays in the current mode."""
+        start, end = self._camera_span(camera)
+        local = torch.arange(start, end, dtype=torch.int64, device=self.sampler.device)
+        index = self._mode_index()
+        rays = local if index is None else index[local]
+        rays = self.sampler.valid_index(rays) - camera * self.sampler.rays_per_camera
+        return rays.cpu().tolist()
+
+    def get_rays(self, idx: Union[List[int], torch.Tensor, np.ndarray, int],
+                 step: int = None) -> RaySamples:
+        """Samples of the selected rays (image_dataset.py:364-386)."""
+        if isinstance(idx, (int, np.integer)):
+            idx = [int(idx)]
+        return self.sampler.sample(self.ray_ids(idx), step)
+
+    def rays_for_camera(self, camera: int) -> RaySamples:
+        start, end = self._camera_span(camera)
+        return self.get_rays(torch.arange(start, end, dtype=torch.int64,
+                                          device=self.sampler.device), None)
+
+    # ------------------------------------------------------------------ ground truth
+    def _gt_alphas(self) -> Optional[torch.Tensor]:
+        if self.alphas is None or self._mode == RayDataset.Mode.Dilate:
+            return None
+        return self.alphas
+
+    def render(self, samples: RaySamples) -> RenderResult:
+        """Ground-truth colour (zeroed where alpha == 0) and alpha of the rays
+        (image_dataset.py:244-262)."""
+        rays = samples.rays.to(self.colors.device)
+        color = self.colors[rays]
+        alphas = self._gt_alphas()
+        if alphas is None:
+            return RenderResult(color, None, None)
+        alpha = alphas[rays]
+        return RenderResult(torch.where(alpha.unsqueeze(1) > 0, color, torch.zeros_like(color)),
+                            alpha, None)
+
+    def loss(self, _: int, rays: RaySamples, render: RenderResult) -> torch.Tensor:
+        """mean((c - c_gt)^2) + alpha_weight * mean((a - a_gt)^2) (image_dataset.py:224-242)."""
+        return _MseLoss.apply(render.color, render.alpha, self.colors, self._gt_alphas(),
+                              rays.rays.contiguous(), float(self.alpha_weight))
+
+    # ------------------------------------------------------------------ construction helpers
+    def subset(self, cameras: List[int], num_samples: int, stratified: bool,
+               label: str) -> "ImageDataset":
+        return ImageDataset(label, self.images[cameras], self.sampler.bounds,
+                            [self.sampler.cameras[i] for i in cameras], num_samples,
+                            self.include_alpha, stratified, self.sampler.opacity_model,
+                            self.sampler.batch_size, self.color_space, self.sparse_size,
+                            self.sampler.anneal_start, self.sampler.num_anneal_steps,
+                            self.alpha_weight if self.alpha_weight else 0.1,
+                            device=self.sampler.device)
+
+    @staticmethod
+    def load(path: str, split: str, num_samples: int, include_alpha: bool, stratified: bool,
+             opacity_model: nn.Module = None, batch_size=4096, color_space="RGB", sparse_size=50,
+             anneal_start=0.2, num_anneal_steps=0, device=None) -> Optional["ImageDataset"]:
+        """Loads one split of an NPZ with images (C,H,W,3|4) u8, intrinsics (C,3,3),
+        extrinsics (C,4,4) camera-to-world, bounds (4,4) and split_counts (3,)
+        (image_dataset.py:388-471).  Returns None when the file is missing."""
+        if not os.path.exists(path):
+            alt = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "data", path))
+            if not os.path.exists(alt):
+                print("Unable to find dataset", path)
+                return None
+            path = alt
+        data = np.load(path)
+        total, height, width = data["images"].shape[:3]
+        counts = data["split_counts"]
+        train_end = int(counts[0])
+        val_end = train_end + int(counts[1])
+        spans = {"train": (0, train_end), "val": (train_end, val_end), "test": (val_end, total)}
+        if split not in spans:
+            print("Unrecognized split:", split)
+            return None
+        idx = list(range(*spans[split]))
+        cameras = [CameraInfo.create("{}{:03}".format(split, i), Resolution(width, height), k, e)
+                   for i, (k, e) in enumerate(zip(data["intrinsics"][idx], data["extrinsics"][idx]))]
+        return ImageDataset(split, data["images"][idx], data["bounds"], cameras, num_samples,
+                            include_alpha, stratified, opacity_model, batch_size, color_space,
+                            sparse_size, anneal_start, num_anneal_steps, device=device)
+
+    def _subsample_rays(self, resolution: int) -> List[int]:
+        """Pixel ids of a resolution-high regular grid (image_dataset.py:473-482)."""
+        nx = resolution * self.image_width // self.image_height
+        xs = (np.linspace(0, self.image_width - 1, nx) + 0.5).astype(np.int32)
+        ys = (np.linspace(0, self.image_height - 1, resolution) + 0.5).astype(np.int32)
+        xs, ys = np.meshgrid(xs, ys)
+        return (ys.reshape(-1) * self.image_width + xs.reshape(-1)).tolist()

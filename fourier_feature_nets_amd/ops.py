@@ -35,8 +35,9 @@ def _host3(values):
 
 # --------------------------------------------------------------------------------- rays
 def raygen_nearfar(unproj: torch.Tensor, cam_pos: torch.Tensor, width: int, height: int,
-                   box_lo, box_hi):
-    """K1.  unproj (C,4,4), cam_pos (C,3) on the GPU -> starts, directions, near_far, valid."""
+                   box_lo, box_hi, points: Optional[torch.Tensor] = None):
+    """K1.  unproj (C,4,4), cam_pos (C,3) on the GPU -> starts, directions, near_far, valid.
+    ``points`` (W*H,2) float32 overrides the integer pixel grid."""
     cams = unproj.shape[0]
     total = cams * width * height
     dev = unproj.device
@@ -45,7 +46,7 @@ def raygen_nearfar(unproj: torch.Tensor, cam_pos: torch.Tensor, width: int, heig
     near_far = torch.empty((2, total), dtype=torch.float32, device=dev)
     valid = torch.empty((total,), dtype=torch.uint8, device=dev)
     _lib.call("ffn_raygen_nearfar", _dev(unproj, name="unproj"), _dev(cam_pos, name="cam_pos"),
-              c_i(cams), c_i(width), c_i(height), _host3(box_lo), _host3(box_hi), _dev(starts),
+              _dev(points, name="points"), c_i(cams), c_i(width), c_i(height), _host3(box_lo), _host3(box_hi), _dev(starts),
               _dev(dirs), _dev(near_far), _dev(valid, torch.uint8), _stream())
     return starts, dirs, near_far, valid
 
@@ -126,6 +127,15 @@ def composite_fwd(logits: torch.Tensor, t: torch.Tensor, include_depth: bool,
     _lib.call("ffn_composite_fwd", _dev(logits), _dev(t), c_i(rays), c_i(count), _dev(color),
               _dev(alpha), _dev(depth), _dev(nan_flag, torch.int32), _stream())
     return color, alpha, depth
+
+
+def blend_weights(t: torch.Tensor, sigma: torch.Tensor) -> torch.Tensor:
+    """K5w.  utils.calculate_blend_weights: (R,S),(R,S) -> (R,S)."""
+    rays, count = t.shape
+    out = torch.empty_like(t)
+    _lib.call("ffn_blend_weights", _dev(t), _dev(sigma), c_i(rays), c_i(count), _dev(out),
+              _stream())
+    return out
 
 
 def composite_bwd(logits, t, d_color, d_alpha) -> torch.Tensor:

@@ -39,13 +39,16 @@ const char* ffn_last_error_string(void);
  *   unproj      (C,16)  per-camera 4x4 pixel->world matrix (camera_info.py:66-70,
  *                       computed on the host exactly as the reference does)
  *   cam_pos     (C,3)   camera positions (extrinsics[:3,3])
+ *   points      (W*H,2) explicit pixel coordinates shared by all cameras, or NULL for the
+ *                       integer grid x = id % W, y = id / W (ray_sampler.py:133-136)
  *   box_lo/hi   (3)     HOST pointers: AABB corners (ray_sampler.py:101-104)
  *   starts      (C*W*H,3), directions (C*W*H,3), near_far (2,C*W*H)
  *   valid       (C*W*H) uint8: 1 where near < far (the complement of invalid_rays)
  * Ray id = cam*W*H + y*W + x, integer pixel coordinates, no half-pixel offset.
  */
-int ffn_raygen_nearfar(const float* unproj, const float* cam_pos, int num_cameras,
-                       int width, int height, const float* box_lo, const float* box_hi,
+int ffn_raygen_nearfar(const float* unproj, const float* cam_pos, const float* points,
+                       int num_cameras, int width, int height, const float* box_lo,
+                       const float* box_hi,
                        float* starts, float* directions, float* near_far, uint8_t* valid,
                        void* stream);
 
@@ -111,6 +114,11 @@ int ffn_fourier_encode(const float* x, int64_t n, const float* b, const float* a
 int ffn_composite_fwd(const float* logits, const float* t, int num_rays, int num_samples,
                       float* color, float* alpha, float* depth, int32_t* nan_flag,
                       void* stream);
+
+/* K5w  utils.calculate_blend_weights (utils.py:72-97) on its own: t (R,S), sigma (R,S)
+ * already activated -> weights (R,S). */
+int ffn_blend_weights(const float* t, const float* sigma, int num_rays, int num_samples,
+                      float* weights, void* stream);
 
 /* K5b backward of K5: d(loss)/d(logits) from d/d(color) (R,3) and d/d(alpha) (R). */
 int ffn_composite_bwd(const float* logits, const float* t, const float* d_color,
