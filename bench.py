@@ -164,13 +164,13 @@ def main():
     n_samples = args.rays * args.samples
 
     # per-kernel timing with events on the launch stream
-    timers = {"fwd": [], "dgrad": [], "wgrad": []}
+    timers = {"fwd": [], "dgrad": [], "wgrad": [], "wgrad_heads": []}
     from fourier_feature_nets_amd import _lib as lib_mod
     orig_call = lib_mod.call
 
     def timed_call(name, *a):
         key = {"ffn_mlp_forward": "fwd", "ffn_mlp_backward_data": "dgrad",
-               "ffn_mlp_wgrad": "wgrad"}.get(name)
+               "ffn_mlp_wgrad_units": "wgrad", "ffn_mlp_wgrad": "wgrad_heads"}.get(name)
         if key is None or not timed_call.on:
             return orig_call(name, *a)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -220,7 +220,9 @@ def main():
                       [l.weight for l in model.layers]]
         fwd_flops = 2 * sum(o * k for o, k in layer_dims)
         dgrad_flops = 2 * sum(o * k for o, k in layer_dims[1:])
-        flops = {"fwd": fwd_flops, "dgrad": dgrad_flops, "wgrad": fwd_flops}
+        head_flops = 2 * layer_dims[-1][0] * layer_dims[-1][1]
+        flops = {"fwd": fwd_flops, "dgrad": dgrad_flops, "wgrad": fwd_flops - head_flops,
+                 "wgrad_heads": head_flops}
         kernels = {}
         for key, pairs in timers.items():
             ms = [a.elapsed_time(b) for a, b in pairs]
@@ -232,7 +234,7 @@ def main():
                             "flop_per_sample": flops[key]}
         dominant = max(kernels, key=lambda k: kernels[k]["avg_ms"])
         names = {"fwd": "mlp_forward_kernel<train>", "dgrad": "mlp_backward_data_kernel",
-                 "wgrad": "wgrad_kernel"}
+                 "wgrad": "wgrad_unit_kernel", "wgrad_heads": "wgrad_kernel(heads)"}
         result = {
             "metric": "rays/sec (train)",
             "value": global_batch * args.steps / elapsed,

@@ -219,6 +219,184 @@ wgrad_kernel(const ffn_mlp_chain ch, const ffn_wgrad_job* __restrict__ jobs,
     }
 }
 
+// ---------------------------------------------------------------------------------- units
+// LDS-staged variant for full 256x256 products.  A 256-thread workgroup owns one unit
+// (dZ slab window of <=256 channels  x  input window of <=256 channels) over a range of
+// sample blocks.  Per block the two 32 KiB operand images are brought into LDS exactly as
+// they sit in HBM (global_load_lds, 1 KiB per wave-instruction, double buffered), or -- for
+// an encoding input -- generated into LDS by the workgroup, one frequency pair per thread
+// per MFMA step.  Each wave then computes its 128x128 quadrant from LDS with two
+// conflict-free ds_read_b128 per 16 MFMAs.  HBM/L2 traffic = the unique operand bytes.
+constexpr int kUnitBufBytes = 64 * 1024;   // A image 32 KiB + B image 32 KiB
+
+__device__ __forceinline__ void stage_slab(const f32x4* __restrict__ block_base, int quads,
+                                           char* lds_part, int tid, int wave) {
+    // chunk k = 8 quads = 4 KiB = one 16-byte piece per thread
+    for (int k = 0; k < (quads >> 3); ++k) {
+        const char* g = reinterpret_cast<const char*>(block_base) + k * 4096 + tid * 16;
+        char* l = lds_part + k * 4096 + wave * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+    }
+}
+
+template <bool ENC>
+__device__ __forceinline__ void unit_segment(const ffn_mlp_chain& ch, const ffn_wgrad_unit& unit,
+                                             const ffn_wgrad_segment& seg, char* smem,
+                                             const float* __restrict__ saved,
+                                             const float* __restrict__ dz,
+                                             const float* __restrict__ xyz, int64_t n,
+                                             int64_t num_blocks, float* __restrict__ partials) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int hh = lane >> 5;
+    const int li = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mp = wave >> 1, np = wave & 1;
+    const int m_valid = unit.m_quads - 32 * mp;   // quads of this wave's M panel (may be <= 0)
+    const int n_valid = unit.n_quads - 32 * np;
+    const bool a_ok = li < m_valid, b_ok = li < n_valid;
+    const f32x4* a_slab = reinterpret_cast<const f32x4*>(dz + ch.slot_offset[unit.m_slot] * num_blocks * 32) + unit.m_cq0 * 32;
+    const int64_t a_stride = ch.slot_channels[unit.m_slot] * 8;
+    const f32x4* b_slab = nullptr;
+    int64_t b_stride = 0;
+    EncRegsW enc = load_enc_w(ch.enc[ENC ? unit.n_slot : 0]);
+    if (!ENC) {
+        b_slab = reinterpret_cast<const f32x4*>(saved + ch.slot_offset[unit.n_slot] * num_blocks * 32) + unit.n_cq0 * 32;
+        b_stride = ch.slot_channels[unit.n_slot] * 8;
+    }
+    // feature generation: thread -> sample tid&31, quads (tid>>5) + 8j, j = 0..7
+    const int f_s = tid & 31;
+    const int f_q = tid >> 5;
+
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[p][q][r] = 0.0f;
+    f32x4 bsum = zero4();
+
+    auto feature_store = [&](char* buf, int j, int half, float x0, float x1, float x2) {
+        const int cq = f_q + 8 * j;                 // quad inside the window
+        if (cq < unit.n_quads) {
+            const int k = 2 * (unit.n_cq0 + cq) + half;
+            const int kk = k < enc.Fi ? k : enc.Fi - 1;
+            const float s0 = enc.scale * x0, s1 = enc.scale * x1, s2 = enc.scale * x2;
+            float ang = s0 * enc.b[kk];
+            ang = __builtin_fmaf(s1, enc.b[enc.Fi + kk], ang);
+            ang = __builtin_fmaf(s2, enc.b[2 * enc.Fi + kk], ang);
+            float sn, cs;
+            fast_sincos(ang, sn, cs);
+            const float amp = enc.a[kk];
+            const int c = 2 * (k - enc.F);
+            const float raw_even = (enc.raw && c == 0) ? x0 : ((enc.raw && c == 2) ? x2 : 0.0f);
+            const float raw_odd = (enc.raw && c == 0) ? x1 : 0.0f;
+            const bool trig = k < enc.F;
+            float2 v;
+            v.x = trig ? amp * cs : raw_even;
+            v.y = trig ? amp * sn : raw_odd;
+            char* dst = buf + 32 * 1024 + (cq * 32 + (f_s ^ (cq & 15))) * 16 + half * 8;
+            *reinterpret_cast<float2*>(dst) = v;
+        }
+    };
+    auto load_xyz = [&](int64_t blk, float& x0, float& x1, float& x2) {
+        int64_t sample = blk * 32 + f_s;
+        sample = sample < n ? sample : n - 1;
+        x0 = xyz[sample * 3 + 0]; x1 = xyz[sample * 3 + 1]; x2 = xyz[sample * 3 + 2];
+    };
+
+    // ---- prologue: stage the first block into buffer 0
+    {
+        char* buf = smem;
+        stage_slab(a_slab + seg.blk_begin * a_stride, unit.m_quads, buf, tid, wave);
+        if (ENC) {
+            float x0, x1, x2;
+            load_xyz(seg.blk_begin, x0, x1, x2);
+            for (int u = 0; u < 16; ++u) feature_store(buf, u >> 1, u & 1, x0, x1, x2);
+        } else {
+            stage_slab(b_slab + seg.blk_begin * b_stride, unit.n_quads, buf + 32 * 1024, tid, wave);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    for (int64_t blk = seg.blk_begin; blk < seg.blk_end; ++blk) {
+        const int cur = (int)((blk - seg.blk_begin) & 1);
+        char* buf = smem + cur * kUnitBufBytes;
+        char* nxt = smem + (cur ^ 1) * kUnitBufBytes;
+        const bool more = blk + 1 < seg.blk_end;
+        float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+        if (more) {
+            stage_slab(a_slab + (blk + 1) * a_stride, unit.m_quads, nxt, tid, wave);
+            if (ENC) load_xyz(blk + 1, x0, x1, x2);
+            else stage_slab(b_slab + (blk + 1) * b_stride, unit.n_quads, nxt + 32 * 1024, tid, wave);
+        }
+        const f32x4* la = reinterpret_cast<const f32x4*>(buf) + (32 * mp + (a_ok ? li : 0)) * 32;
+        const f32x4* lb = reinterpret_cast<const f32x4*>(buf + 32 * 1024) + (32 * np + (b_ok ? li : 0)) * 32;
+        const int sw = li & 15;
+        f32x4 a = la[hh ^ sw];
+        f32x4 b = lb[hh ^ sw];
+#pragma unroll 2
+        for (int u = 0; u < 16; ++u) {
+            const int un = u + 1 < 16 ? u + 1 : u;
+            const f32x4 a_n = la[(2 * un + hh) ^ sw];
+            const f32x4 b_n = lb[(2 * un + hh) ^ sw];
+            if (ENC && more) feature_store(nxt, u >> 1, u & 1, x0, x1, x2);
+            {   // idle quadrants (narrow windows) multiply zeros rather than branch
+                const f32x4 av = a_ok ? a : zero4();
+                const f32x4 bv = b_ok ? b : zero4();
+                bsum += av;
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        acc[p][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p], bv[q], acc[p][q], 0, 0, 0);
+            }
+            a = a_n;
+            b = b_n;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    {   // (idle quadrants store zeros into their own, never-read slot)
+        float* out = partials + (int64_t)(seg.slot + wave) * kPartialFloats;
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    out[((p * 4 + q) * 16 + r) * 64 + lane] = acc[p][q][r];
+        reinterpret_cast<f32x4*>(out + 16 * 16 * 64)[lane] = bsum;
+    }
+}
+
+__global__ void __launch_bounds__(256, 1)
+wgrad_unit_kernel(const ffn_mlp_chain ch, const ffn_wgrad_unit* __restrict__ units,
+                  const ffn_wgrad_segment* __restrict__ segments,
+                  const int32_t* __restrict__ seg_start, const float* __restrict__ saved,
+                  const float* __restrict__ dz, const float* __restrict__ positions,
+                  const float* __restrict__ views, int64_t n, float* __restrict__ partials) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int64_t num_blocks = (n + 31) / 32;
+    const int seg_lo = seg_start[blockIdx.x], seg_hi = seg_start[blockIdx.x + 1];
+    for (int si = seg_lo; si < seg_hi; ++si) {
+        const ffn_wgrad_segment seg = segments[si];
+        if (seg.blk_end <= seg.blk_begin) continue;
+        const ffn_wgrad_unit unit = units[seg.job];
+        if (unit.n_kind == 1) {
+            const float* xyz = unit.n_slot == 1 ? views : positions;
+            unit_segment<true>(ch, unit, seg, smem, saved, dz, xyz, n, num_blocks, partials);
+        } else {
+            unit_segment<false>(ch, unit, seg, smem, saved, dz, positions, n, num_blocks, partials);
+        }
+        __syncthreads();
+    }
+}
+
 // Sums a job's partials in slot order and scatters into the flat natural-layout gradient.
 __global__ void __launch_bounds__(256)
 wgrad_reduce_kernel(const ffn_reduce_job* __restrict__ rjobs, const float* __restrict__ partials,
@@ -228,7 +406,7 @@ wgrad_reduce_kernel(const ffn_reduce_job* __restrict__ rjobs, const float* __res
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < elems + 256; e += gridDim.x * blockDim.x) {
         float sum = 0.0f;
         if (e < elems) {
-            for (int s = job.slot_begin; s < job.slot_end; ++s)
+            for (int s = job.slot_begin; s < job.slot_end; s += job.slot_stride)
                 sum += partials[(int64_t)s * kPartialFloats + e];
             const int lane = e & 63;
             const int r = (e >> 6) & 15;
@@ -256,7 +434,7 @@ wgrad_reduce_kernel(const ffn_reduce_job* __restrict__ rjobs, const float* __res
             if (job.kind == 0) {
                 const int i = b >> 2, p = b & 3;  // i in 0..63 covers both halves; use i < 32
                 if (i >= 32) continue;
-                for (int s = job.slot_begin; s < job.slot_end; ++s) {
+                for (int s = job.slot_begin; s < job.slot_end; s += job.slot_stride) {
                     const float* strip = partials + (int64_t)s * kPartialFloats + 16 * 16 * 64;
                     sum += strip[i * 4 + p] + strip[(32 + i) * 4 + p];
                 }
@@ -264,7 +442,7 @@ wgrad_reduce_kernel(const ffn_reduce_job* __restrict__ rjobs, const float* __res
                 if (row < job.rows) grads[job.b_grad_off + row] = sum;
             } else {
                 if (b >= job.lg_n) continue;
-                for (int s = job.slot_begin; s < job.slot_end; ++s) {
+                for (int s = job.slot_begin; s < job.slot_end; s += job.slot_stride) {
                     const float* strip = partials + (int64_t)s * kPartialFloats + 16 * 16 * 64;
                     sum += strip[b] + strip[32 + b];
                 }
@@ -287,6 +465,20 @@ extern "C" int ffn_mlp_wgrad(const ffn_mlp_chain* chain, const ffn_wgrad_job* jo
     hipLaunchKernelGGL(wgrad_kernel, dim3(num_waves / 4), dim3(256), 0, (hipStream_t)stream, *chain,
                        jobs, segments, seg_start, saved, dz, d_logits, positions, views, n, partials);
     return check_launch("ffn_mlp_wgrad");
+}
+
+extern "C" int ffn_mlp_wgrad_units(const ffn_mlp_chain* chain, const ffn_wgrad_unit* units,
+                                   const ffn_wgrad_segment* segments, const int32_t* seg_start,
+                                   int num_groups, const float* saved, const float* dz,
+                                   const float* positions, const float* views, int64_t n,
+                                   float* partials, void* stream) {
+    if (n <= 0 || num_groups <= 0) return fail_arg("ffn_mlp_wgrad_units: shape");
+    const size_t lds = 2 * kUnitBufBytes;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_unit_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(wgrad_unit_kernel, dim3(num_groups), dim3(256), lds, (hipStream_t)stream,
+                       *chain, units, segments, seg_start, saved, dz, positions, views, n, partials);
+    return check_launch("ffn_mlp_wgrad_units");
 }
 
 extern "C" int ffn_mlp_wgrad_reduce(const ffn_reduce_job* jobs, int num_jobs,

@@ -20,6 +20,7 @@ from .ops import _dev, _stream
 
 MAX_STEPS = 16
 WGRAD_WAVES = 1024          # one persistent wave per SIMD: 256 CUs x 4
+WGRAD_GROUPS = 256          # one persistent workgroup per CU for the LDS-staged units
 COST_FULL = 256             # MFMAs per 32-sample block of a 128x128 patch
 COST_HEAD = 64
 
@@ -55,6 +56,12 @@ class FfnWgradJob(ctypes.Structure):
                 ("reserved0", ctypes.c_int32), ("reserved1", ctypes.c_int32)]
 
 
+class FfnWgradUnit(ctypes.Structure):
+    _fields_ = [("m_slot", ctypes.c_int32), ("m_cq0", ctypes.c_int32), ("m_quads", ctypes.c_int32),
+                ("n_kind", ctypes.c_int32), ("n_slot", ctypes.c_int32), ("n_cq0", ctypes.c_int32),
+                ("n_quads", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
 class FfnWgradSegment(ctypes.Structure):
     _fields_ = [("job", ctypes.c_int32), ("slot", ctypes.c_int32),
                 ("blk_begin", ctypes.c_int64), ("blk_end", ctypes.c_int64)]
@@ -65,7 +72,7 @@ class FfnReduceJob(ctypes.Structure):
                 ("slot_end", ctypes.c_int32), ("m_ch0", ctypes.c_int32), ("rows", ctypes.c_int32),
                 ("n_quad0", ctypes.c_int32), ("n_quads", ctypes.c_int32),
                 ("k_base", ctypes.c_int32), ("ld", ctypes.c_int32), ("has_bias", ctypes.c_int32),
-                ("lg_n", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("lg_n", ctypes.c_int32), ("slot_stride", ctypes.c_int32),
                 ("w_grad_off", ctypes.c_int64), ("b_grad_off", ctypes.c_int64),
                 ("col_map", ctypes.c_void_p)]
 
@@ -141,12 +148,15 @@ class Workspace:
         blocks = (n + 31) // 32
         slab = prog.saved_channels * 32 * blocks
         self.dz = torch.empty((slab,), dtype=torch.float32, device=dev)
-        segs, starts, reduce_jobs, slots = prog._plan_wgrad(blocks)
-        self.segments = _struct_array_to_device(segs, dev)
-        self.seg_start = torch.tensor(starts, dtype=torch.int32, device=dev)
-        self.reduce_jobs = _struct_array_to_device(reduce_jobs, dev)
-        self.num_reduce_jobs = len(reduce_jobs)
-        self.partials = torch.empty((slots * prog.partial_floats,), dtype=torch.float32, device=dev)
+        plan = prog._plan_wgrad(blocks)
+        self.unit_segments = _struct_array_to_device(plan["unit_segments"], dev)
+        self.unit_seg_start = torch.tensor(plan["unit_starts"], dtype=torch.int32, device=dev)
+        self.segments = _struct_array_to_device(plan["head_segments"], dev)
+        self.seg_start = torch.tensor(plan["head_starts"], dtype=torch.int32, device=dev)
+        self.reduce_jobs = _struct_array_to_device(plan["reduce_jobs"], dev)
+        self.num_reduce_jobs = len(plan["reduce_jobs"])
+        self.partials = torch.empty((plan["slots"] * prog.partial_floats,), dtype=torch.float32,
+                                    device=dev)
 
 
 class MlpProgram:
@@ -309,79 +319,118 @@ class MlpProgram:
         self.packed_bwd = torch.zeros((max(wt_off, 1),), dtype=torch.float32, device=self.device)
 
     def _build_wgrad_jobs(self):
+        """Weight-gradient work list: LDS-staged 256x256 units for the hidden layers, per-wave
+        head jobs (<=4 output rows) for the logits heads."""
+        self.wgrad_units: List[FfnWgradUnit] = []
+        self.unit_meta = []     # per unit: reducer metadata
         self.wgrad_jobs: List[FfnWgradJob] = []
-        self.job_meta = []      # per job: dict for the reducer
+        self.job_meta = []
         for i, spec in enumerate(self.layers):
             enc = None if spec.enc_id is None else self.encodings[spec.enc_id]
-            panels = []         # (n_kind, n_slot, first quad, quads, k_base)
+            windows = []        # (n_kind, n_slot, first quad, quads, k_base, first-of-layer)
             if spec.act_in > 0:
                 slot = self.slot_of[self.producer_of[i]]
                 quads = spec.act_in // 4
-                for q0 in range(0, quads, 32):
-                    panels.append((0, slot, q0, min(32, quads - q0), 0))
+                for q0 in range(0, quads, 64):
+                    windows.append((0, slot, q0, min(64, quads - q0), 0))
             if enc is not None:
                 quads = enc.width // 4
-                for q0 in range(0, quads, 32):
-                    panels.append((1, spec.enc_id, q0, min(32, quads - q0), spec.act_in))
+                for q0 in range(0, quads, 64):
+                    windows.append((1, spec.enc_id, q0, min(64, quads - q0), spec.act_in))
             if spec.to_logits is None:
                 m_slot = self.slot_of[i]
                 out_quads = spec.out // 4
-                for m0 in range(0, out_quads, 32):
-                    for pi, (nk, ns, q0, nq, kb) in enumerate(panels):
-                        job = FfnWgradJob(0, m_slot, m0, min(32, out_quads - m0), nk, ns, q0, nq,
-                                          0, 0, 0, 0)
-                        self.wgrad_jobs.append(job)
-                        self.job_meta.append(dict(layer=i, kind=0, m_ch0=4 * m0, n_quad0=q0,
-                                                  n_quads=nq, k_base=kb, has_bias=int(pi == 0),
-                                                  lg_n=0, cost=COST_FULL))
+                for m0 in range(0, out_quads, 64):
+                    for wi, (nk, ns, q0, nq, kb) in enumerate(windows):
+                        self.wgrad_units.append(FfnWgradUnit(m_slot, m0, min(64, out_quads - m0),
+                                                             nk, ns, q0, nq, 0))
+                        self.unit_meta.append(dict(layer=i, m0=m0, m_quads=min(64, out_quads - m0),
+                                                   n_quad0=q0, n_quads=nq, k_base=kb,
+                                                   first=(wi == 0)))
             else:
                 col, cnt = spec.to_logits
-                for pi, (nk, ns, q0, nq, kb) in enumerate(panels):
-                    job = FfnWgradJob(1, 0, 0, 0, nk, ns, q0, nq, col, cnt, 0, 0)
-                    self.wgrad_jobs.append(job)
-                    self.job_meta.append(dict(layer=i, kind=1, m_ch0=0, n_quad0=q0, n_quads=nq,
-                                              k_base=kb, has_bias=int(pi == 0), lg_n=cnt,
-                                              cost=COST_HEAD))
+                for wi, (nk, ns, q0, nq, kb) in enumerate(windows):
+                    for p0 in range(0, nq, 32):
+                        self.wgrad_jobs.append(FfnWgradJob(1, 0, 0, 0, nk, ns, q0 + p0,
+                                                           min(32, nq - p0), col, cnt, 0, 0))
+                        self.job_meta.append(dict(layer=i, n_quad0=q0 + p0,
+                                                  n_quads=min(32, nq - p0), k_base=kb,
+                                                  has_bias=int(wi == 0 and p0 == 0), lg_n=cnt))
+        self.wgrad_units_dev = _struct_array_to_device(self.wgrad_units, self.device)
         self.wgrad_jobs_dev = _struct_array_to_device(self.wgrad_jobs, self.device)
 
-    def _plan_wgrad(self, blocks: int):
-        """Cost-balanced split of (job, block-range) work over the persistent waves."""
-        costs = [m["cost"] for m in self.job_meta]
+    @staticmethod
+    def _split(costs: List[int], blocks: int, workers: int):
+        """Contiguous, cost-balanced split of the job-major (job, block) sequence.
+        Returns (segments as (job, blk_begin, blk_end), starts per worker)."""
         total = sum(c * blocks for c in costs)
-        waves = WGRAD_WAVES
-        target = -(-total // waves)
+        target = -(-total // workers) if total else 0
         segs, starts = [], [0]
-        job_slots = [[] for _ in self.job_meta]
         job, blk = 0, 0
-        slot = 0
-        for w in range(waves):
+        for w in range(workers):
             budget = target
-            last = w == waves - 1
+            last = w == workers - 1
             while job < len(costs) and (budget > 0 or last):
                 left = blocks - blk
                 take = left if last else min(left, budget // costs[job])
                 if take <= 0:
                     break
-                segs.append(FfnWgradSegment(job, slot, blk, blk + take))
-                job_slots[job].append(slot)
-                slot += 1
+                segs.append((job, blk, blk + take))
                 budget -= take * costs[job]
                 blk += take
                 if blk == blocks:
                     job, blk = job + 1, 0
             starts.append(len(segs))
         assert job == len(costs), "work left unassigned"
+        return segs, starts
+
+    def _plan_wgrad(self, blocks: int):
+        """Segments for both weight-gradient kernels + the reducer's job table."""
+        slot = 0
         reduce_jobs = []
+        # ---- units: one workgroup-segment = 4 consecutive partial slots (one per quadrant)
+        raw, unit_starts = self._split([1] * len(self.wgrad_units), blocks, WGRAD_GROUPS)
+        unit_segments = []
+        unit_slots = [[] for _ in self.wgrad_units]
+        for (u, b0, b1) in raw:
+            unit_segments.append(FfnWgradSegment(u, slot, b0, b1))
+            unit_slots[u].append(slot)
+            slot += 4
+        for u, meta in enumerate(self.unit_meta):
+            spec = self.layers[meta["layer"]]
+            sl = unit_slots[u]
+            assert sl == list(range(sl[0], sl[-1] + 4, 4))
+            for mp in range(2):
+                for np_ in range(2):
+                    if meta["m_quads"] - 32 * mp <= 0 or meta["n_quads"] - 32 * np_ <= 0:
+                        continue
+                    q = 2 * mp + np_
+                    reduce_jobs.append(FfnReduceJob(
+                        0, sl[0] + q, sl[-1] + q + 1, 4 * (meta["m0"] + 32 * mp), spec.out,
+                        meta["n_quad0"] + 32 * np_, min(32, meta["n_quads"] - 32 * np_),
+                        meta["k_base"], spec.ld, int(meta["first"] and np_ == 0), 0, 4,
+                        self.grad_w_off[meta["layer"]], self.grad_b_off[meta["layer"]],
+                        self.col_maps[meta["layer"]].data_ptr()))
+        # ---- logits heads: per-wave jobs
+        raw, head_starts = self._split([COST_HEAD] * len(self.wgrad_jobs), blocks, WGRAD_WAVES)
+        head_segments = []
+        job_slots = [[] for _ in self.wgrad_jobs]
+        for (j, b0, b1) in raw:
+            head_segments.append(FfnWgradSegment(j, slot, b0, b1))
+            job_slots[j].append(slot)
+            slot += 1
         for j, meta in enumerate(self.job_meta):
             spec = self.layers[meta["layer"]]
             sl = job_slots[j]
             assert sl == list(range(sl[0], sl[-1] + 1))
             reduce_jobs.append(FfnReduceJob(
-                meta["kind"], sl[0], sl[-1] + 1, meta["m_ch0"], spec.out, meta["n_quad0"],
-                meta["n_quads"], meta["k_base"], spec.ld, meta["has_bias"], meta["lg_n"], 0,
+                1, sl[0], sl[-1] + 1, 0, spec.out, meta["n_quad0"], meta["n_quads"],
+                meta["k_base"], spec.ld, meta["has_bias"], meta["lg_n"], 1,
                 self.grad_w_off[meta["layer"]], self.grad_b_off[meta["layer"]],
                 self.col_maps[meta["layer"]].data_ptr()))
-        return segs, starts, reduce_jobs, slot
+        return dict(unit_segments=unit_segments, unit_starts=unit_starts,
+                    head_segments=head_segments, head_starts=head_starts,
+                    reduce_jobs=reduce_jobs, slots=slot)
 
     # ------------------------------------------------------------------ packing
     def pack(self):
@@ -436,10 +485,18 @@ class MlpProgram:
         if self.bwd.num_steps > 0:
             _lib.call("ffn_mlp_backward_data", ctypes.byref(self.bwd), _dev(self.packed_bwd),
                       _dev(d_logits), c_i64(n), _dev(saved), _dev(ws.dz), _stream())
-        _lib.call("ffn_mlp_wgrad", ctypes.byref(self.fwd), _dev(self.wgrad_jobs_dev, torch.uint8),
-                  _dev(ws.segments, torch.uint8), _dev(ws.seg_start, torch.int32),
-                  c_i(WGRAD_WAVES), _dev(saved), _dev(ws.dz), _dev(d_logits), _dev(positions),
-                  _dev(views), c_i64(n), _dev(ws.partials), _stream())
+        if self.wgrad_units:
+            _lib.call("ffn_mlp_wgrad_units", ctypes.byref(self.fwd),
+                      _dev(self.wgrad_units_dev, torch.uint8), _dev(ws.unit_segments, torch.uint8),
+                      _dev(ws.unit_seg_start, torch.int32), c_i(WGRAD_GROUPS), _dev(saved),
+                      _dev(ws.dz), _dev(positions), _dev(views), c_i64(n), _dev(ws.partials),
+                      _stream())
+        if self.wgrad_jobs:
+            _lib.call("ffn_mlp_wgrad", ctypes.byref(self.fwd),
+                      _dev(self.wgrad_jobs_dev, torch.uint8), _dev(ws.segments, torch.uint8),
+                      _dev(ws.seg_start, torch.int32), c_i(WGRAD_WAVES), _dev(saved), _dev(ws.dz),
+                      _dev(d_logits), _dev(positions), _dev(views), c_i64(n), _dev(ws.partials),
+                      _stream())
         _lib.call("ffn_mlp_wgrad_reduce", _dev(ws.reduce_jobs, torch.uint8),
                   c_i(ws.num_reduce_jobs), _dev(ws.partials), _dev(grads), _stream())
         return grads

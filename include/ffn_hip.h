@@ -277,11 +277,32 @@ int ffn_mlp_wgrad(const ffn_mlp_chain* chain, const ffn_wgrad_job* jobs,
                   const float* positions, const float* views, int64_t n, float* partials,
                   void* stream);
 
+/* LDS-staged variant for full products: a unit is a (<=256 output channels) x (<=256 input
+ * channels) block of some dW; workgroup g (256 threads) processes the segments
+ * seg_start[g] .. seg_start[g+1] (segment.job indexes `units`), its four waves own the four
+ * 128x128 quadrants and write partial slots segment.slot + {0,1,2,3}. */
+typedef struct ffn_wgrad_unit {
+    int32_t m_slot;    /* dZ slab                                                      */
+    int32_t m_cq0;     /* first channel quad of the output window inside the slab      */
+    int32_t m_quads;   /* valid quads (<= 64, multiple of 8)                           */
+    int32_t n_kind;    /* input window: 0 = saved activation slab, 1 = encoding        */
+    int32_t n_slot;    /* slab index, or encoding id                                   */
+    int32_t n_cq0;     /* first channel quad / internal quad of the window             */
+    int32_t n_quads;   /* valid quads (<= 64, multiple of 8 for slabs)                 */
+    int32_t reserved;
+} ffn_wgrad_unit;
+
+int ffn_mlp_wgrad_units(const ffn_mlp_chain* chain, const ffn_wgrad_unit* units,
+                        const ffn_wgrad_segment* segments, const int32_t* seg_start,
+                        int num_groups, const float* saved, const float* dz,
+                        const float* positions, const float* views, int64_t n,
+                        float* partials, void* stream);
+
 /* Fixed-order reduction of the partials of each job into the flat natural-layout
  * gradient buffer (nn.Linear weight (out,in) row-major, then bias). */
 typedef struct ffn_reduce_job {
     int32_t kind;
-    int32_t slot_begin, slot_end;  /* contiguous partial slots of this job             */
+    int32_t slot_begin, slot_end;  /* partial slots slot_begin, +stride, ... < slot_end      */
     int32_t m_ch0;                 /* kind 0: first output channel of the patch        */
     int32_t rows;                  /* output rows of the layer                         */
     int32_t n_quad0;               /* first input quad of the panel                    */
@@ -290,7 +311,7 @@ typedef struct ffn_reduce_job {
     int32_t ld;                    /* leading dimension (= in_features) of dW          */
     int32_t has_bias;              /* this job also carries the bias gradient          */
     int32_t lg_n;
-    int32_t reserved;
+    int32_t slot_stride;           /* distance between consecutive slots of this job   */
     int64_t w_grad_off;            /* float offset of dW inside `grads`                */
     int64_t b_grad_off;            /* float offset of db inside `grads`                */
     const int32_t* col_map;        /* internal K index -> natural column, or -1        */
