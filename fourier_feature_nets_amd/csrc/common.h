@@ -36,6 +36,23 @@ __device__ __forceinline__ float np_min(float a, float b) {
     return (a != a || b != b) ? __builtin_nanf("") : (a < b ? a : b);
 }
 
+// Encoding tables live in LDS while a kernel runs: per encoding [b row 0 | b row 1 | b row 2 |
+// a], each max(F,1) floats, at a fixed 1024-float pitch.  Feature arithmetic then waits on
+// lgkmcnt only and never drains the weight / operand prefetches that sit on vmcnt.
+constexpr int kEncTablePitch = 1024;            // floats per encoding (F <= 256)
+constexpr int kEncTableBytes = 2 * kEncTablePitch * 4;
+
+__device__ __forceinline__ void stage_encoding_tables(const ffn_encoding* enc, float* table,
+                                                      int tid, int nthreads) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int fi = enc[e].num_freq > 0 ? enc[e].num_freq : 1;
+        float* dst = table + e * kEncTablePitch;
+        for (int i = tid; i < 3 * fi; i += nthreads) dst[i] = enc[e].b[i];
+        for (int i = tid; i < fi; i += nthreads) dst[3 * fi + i] = enc[e].a[i];
+    }
+}
+
 // Branch-free sin/cos: 3-constant Cody-Waite reduction by pi/2 (fused multiply-adds) and
 // degree-7/8 minimax polynomials on [-pi/4, pi/4].  Max abs error 8.8e-8 for |x| <= 5000
 // (checked against a 200-bit reference), i.e. the class of a 1-ulp libm; the encodings on

@@ -24,6 +24,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kSamplesPerWave = 32;
 constexpr int kWavesPerBlock = 4;
 constexpr int kActBytesPerWave = 32 * 1024;  // 256 channels x 32 samples x 4 B
+constexpr int kBiasLdsFloats = 4096;         // LDS copy of all (padded) biases
 
 enum Mode { kInfer = 0, kTrainFwd = 1, kBackward = 2 };
 
@@ -68,9 +69,10 @@ struct EncRegs {
     float scale;
 };
 
-__device__ __forceinline__ EncRegs load_enc(const ffn_encoding& e) {
+__device__ __forceinline__ EncRegs load_enc(const ffn_encoding& e, const float* table) {
     EncRegs r;
-    r.b = e.b; r.a = e.a; r.F = e.num_freq; r.Fi = e.num_freq > 0 ? e.num_freq : 1;
+    r.F = e.num_freq; r.Fi = e.num_freq > 0 ? e.num_freq : 1;
+    r.b = table; r.a = table + 3 * r.Fi;          // LDS copies (stage_encoding_tables)
     r.raw = (e.include_input != 0 || e.num_freq == 0) ? 1 : 0;
     r.scale = e.scale;
     return r;
@@ -140,6 +142,9 @@ struct WaveCtx {
     float v0, v1, v2;        // view direction of this lane's sample
     f32x4 dl;                // backward: d(loss)/d(logits) of this lane's sample
     f32x4* act;              // this wave's LDS slab, indexed [group*64 + lane]
+    const float* enc_table;  // LDS copies of the encoding tables
+    const float* bias_lds;   // LDS copy of every step's (padded) bias
+    uint4* masks;            // ReLU sign masks: [slot][block][lane] x 128 bit
     int64_t block;           // global 32-sample block id
     int64_t num_blocks;
     float logit[4];
@@ -155,10 +160,10 @@ __device__ __forceinline__ f32x4* slab_block(const ffn_mlp_chain& ch, float* bas
 }
 
 template <int OT, int MODE>
-__device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step& L, WaveCtx& w,
+__device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step& L,
+                                         const ffn_step* next, WaveCtx& w,
                                          const float* __restrict__ packed_w,
-                                         const float* __restrict__ bias,
-                                         float* __restrict__ slab_in,    // bwd: forward activations
+                                         f32x4 (&pre)[16],               // groups 0,1 weights, prefetched
                                          float* __restrict__ slab_out) { // fwd: saved; bwd: dZ
     f32x16 acc[OT];
 #pragma unroll
@@ -168,26 +173,49 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
 
     const f32x4* wp = reinterpret_cast<const f32x4*>(packed_w + L.w_off) + w.lane;
     const int GA = L.act_groups;   // multiple of 4
-    const int GX = L.aux_groups;   // even; encoding features (fwd) or d_logits columns (bwd)
-    f32x4 a0[OT], a1[OT];
-    f32x4 x0, x1;
-    load_weights<OT>(a0, wp, 0);
+    const int GX = L.aux_groups;   // multiple of 4; encoding features (fwd) or d_logits (bwd)
+    const int G = GA + GX;
+    // weights are double buffered two K groups deep: while pair A feeds the MFMAs, pair B
+    // (two groups = 4096 MFMA cycles ahead) is in flight from L2
+    f32x4 wa0[OT], wa1[OT], wb0[OT], wb1[OT];
+    f32x4 x0, x1, x2, x3;
+#pragma unroll
+    for (int o = 0; o < OT; ++o) { wa0[o] = pre[o]; wa1[o] = pre[8 + o]; }
+    // backward: the ReLU sign mask of the layer being differentiated, fetched a layer ahead
+    uint4 mbits = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+    if (MODE == kBackward && L.mask_slot >= 0)
+        mbits = w.masks[((int64_t)L.mask_slot * w.num_blocks + w.block) * 64 + w.lane];
 
     // ---- segment 1: K groups read back from the activation slab ------------------
     if (GA > 0) {
         f32x4* save = nullptr;
         if (MODE != kInfer && L.save_in_slot >= 0) save = slab_block(ch, slab_out, L.save_in_slot, w);
         x0 = w.act[w.lane];
-        for (int g = 0; g < GA; g += 2) {
-            load_weights<OT>(a1, wp, g + 1);
-            x1 = w.act[(g + 1) * 64 + w.lane];
-            if (MODE != kInfer && save != nullptr) save[saved_index(2 * g + w.h, w.s)] = x0;
-            mma_group<OT>(acc, a0, x0);
-            const int gn = g + 2 < GA + GX ? g + 2 : g;
-            load_weights<OT>(a0, wp, gn);
-            if (g + 2 < GA) x0 = w.act[(g + 2) * 64 + w.lane];
-            if (MODE != kInfer && save != nullptr) save[saved_index(2 * (g + 1) + w.h, w.s)] = x1;
-            mma_group<OT>(acc, a1, x1);
+        x1 = w.act[64 + w.lane];
+        for (int g = 0; g < GA; g += 4) {
+            load_weights<OT>(wb0, wp, g + 2);
+            load_weights<OT>(wb1, wp, g + 3);
+            x2 = w.act[(g + 2) * 64 + w.lane];
+            x3 = w.act[(g + 3) * 64 + w.lane];
+            if (MODE != kInfer && save != nullptr) {
+                save[saved_index(2 * g + w.h, w.s)] = x0;
+                save[saved_index(2 * (g + 1) + w.h, w.s)] = x1;
+            }
+            mma_group<OT>(acc, wa0, x0);
+            mma_group<OT>(acc, wa1, x1);
+            const int gn = g + 4 < G ? g + 4 : g;     // redundant reload on the very last trip
+            load_weights<OT>(wa0, wp, gn);
+            load_weights<OT>(wa1, wp, gn + 1);
+            if (g + 4 < GA) {
+                x0 = w.act[(g + 4) * 64 + w.lane];
+                x1 = w.act[(g + 5) * 64 + w.lane];
+            }
+            if (MODE != kInfer && save != nullptr) {
+                save[saved_index(2 * (g + 2) + w.h, w.s)] = x2;
+                save[saved_index(2 * (g + 3) + w.h, w.s)] = x3;
+            }
+            mma_group<OT>(acc, wb0, x2);
+            mma_group<OT>(acc, wb1, x3);
         }
     }
 
@@ -204,33 +232,51 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
                 for (int c = 0; c < 4; ++c) v = (c == L.lg_col + p && p < L.lg_n) ? d[c] : v;
                 sel[p] = w.h == 0 ? v : 0.0f;
             }
-            mma_group<OT>(acc, a0, sel);   // group GA (a0 was prefetched); group GA+1 is all zero
+            mma_group<OT>(acc, wa0, sel);   // group GA; the padding groups are all zero
         } else {
-            const EncRegs enc = load_enc(ch.enc[L.enc_id]);
+            const EncRegs enc = load_enc(ch.enc[L.enc_id], w.enc_table + L.enc_id * kEncTablePitch);
             const float p0 = L.enc_id == 0 ? w.x0 : w.v0;
             const float p1 = L.enc_id == 0 ? w.x1 : w.v1;
             const float p2 = L.enc_id == 0 ? w.x2 : w.v2;
             x0 = feature_group(enc, 0, w.h, p0, p1, p2);
-            for (int e = 0; e < GX; e += 2) {
-                load_weights<OT>(a1, wp, GA + e + 1);
-                x1 = feature_group(enc, e + 1, w.h, p0, p1, p2);
-                mma_group<OT>(acc, a0, x0);
-                interleave_hint<OT>(3);
-                const int en = e + 2 < GX ? e + 2 : e;
-                load_weights<OT>(a0, wp, GA + en);
+            x1 = feature_group(enc, 1, w.h, p0, p1, p2);
+            for (int e = 0; e < GX; e += 4) {
+                load_weights<OT>(wb0, wp, GA + e + 2);
+                load_weights<OT>(wb1, wp, GA + e + 3);
+                x2 = feature_group(enc, e + 2, w.h, p0, p1, p2);
+                x3 = feature_group(enc, e + 3, w.h, p0, p1, p2);
+                mma_group<OT>(acc, wa0, x0);
+                mma_group<OT>(acc, wa1, x1);
+                interleave_hint<2 * OT>(3);
+                const int en = e + 4 < GX ? e + 4 : e;
+                load_weights<OT>(wa0, wp, GA + en);
+                load_weights<OT>(wa1, wp, GA + en + 1);
                 x0 = feature_group(enc, en, w.h, p0, p1, p2);
-                mma_group<OT>(acc, a1, x1);
-                interleave_hint<OT>(3);
+                x1 = feature_group(enc, en + 1, w.h, p0, p1, p2);
+                mma_group<OT>(acc, wb0, x2);
+                mma_group<OT>(acc, wb1, x3);
+                interleave_hint<2 * OT>(3);
             }
         }
     }
 
+    // ---- next step's first weight group rides under this step's epilogue -----------
+    if (next != nullptr) {
+        const f32x4* wn = reinterpret_cast<const f32x4*>(packed_w + next->w_off) + w.lane;
+        const int ot_next = next->out_tiles;
+#pragma unroll
+        for (int o = 0; o < 8; ++o)
+            if (o < ot_next) {
+                pre[o] = wn[o * 64];
+                pre[8 + o] = wn[(int64_t)(ot_next + o) * 64];
+            }
+    }
+
     // ---- epilogue: bias / activation / mask, hand-off -------------------------------
-    const float* bv = (MODE == kBackward) ? nullptr : bias + L.b_off + 4 * w.h;
-    const f32x4* mask = nullptr;
-    if (MODE == kBackward && L.mask_slot >= 0) mask = slab_block(ch, slab_in, L.mask_slot, w);
+    const float* bv = w.bias_lds + L.b_off + 4 * w.h;
     f32x4* save_out = nullptr;
     if (MODE == kBackward && L.save_out_slot >= 0) save_out = slab_block(ch, slab_out, L.save_out_slot, w);
+    unsigned sign_bits[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int o = 0; o < OT; ++o) {
 #pragma unroll
@@ -238,12 +284,11 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
             const int group = 4 * o + q;
             f32x4 y;
             if (MODE == kBackward) {
+                const unsigned word = o < 2 ? mbits.x : (o < 4 ? mbits.y : (o < 6 ? mbits.z : mbits.w));
 #pragma unroll
-                for (int p = 0; p < 4; ++p) y[p] = acc[o][4 * q + p];
-                if (mask != nullptr) {
-                    const f32x4 hv = mask[saved_index(2 * group + w.h, w.s)];
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) y[p] = hv[p] > 0.0f ? y[p] : 0.0f;
+                for (int p = 0; p < 4; ++p) {
+                    const int bit = 16 * (o & 1) + 4 * q + p;
+                    y[p] = ((word >> bit) & 1u) ? acc[o][4 * q + p] : 0.0f;
                 }
                 w.act[group * 64 + w.lane] = y;
                 if (save_out != nullptr) save_out[saved_index(2 * group + w.h, w.s)] = y;
@@ -252,6 +297,7 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
                     float t = acc[o][4 * q + p] + b4[p];
+                    if (MODE == kTrainFwd) sign_bits[o >> 1] |= (t > 0.0f ? 1u : 0u) << (16 * (o & 1) + 4 * q + p);
                     if (L.relu) t = t > 0.0f ? t : 0.0f;
                     y[p] = t;
                 }
@@ -271,26 +317,50 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
             }
         }
     }
+    if (MODE == kTrainFwd && L.relu && L.mask_slot >= 0)
+        w.masks[((int64_t)L.mask_slot * w.num_blocks + w.block) * 64 + w.lane] =
+            make_uint4(sign_bits[0], sign_bits[1], sign_bits[2], sign_bits[3]);
 }
 
 template <int MODE>
-__device__ __forceinline__ void dispatch_step(const ffn_mlp_chain& ch, const ffn_step& L,
-                                              WaveCtx& w, const float* packed_w, const float* bias,
-                                              float* slab_in, float* slab_out) {
-    switch (L.out_tiles) {
-        case 8: run_step<8, MODE>(ch, L, w, packed_w, bias, slab_in, slab_out); break;
-        case 4: run_step<4, MODE>(ch, L, w, packed_w, bias, slab_in, slab_out); break;
-        case 2: run_step<2, MODE>(ch, L, w, packed_w, bias, slab_in, slab_out); break;
-        default: run_step<1, MODE>(ch, L, w, packed_w, bias, slab_in, slab_out); break;
+__device__ __forceinline__ void run_chain(const ffn_mlp_chain& ch, WaveCtx& w,
+                                          const float* __restrict__ packed_w,
+                                          float* __restrict__ slab_out) {
+    f32x4 pre[16];
+    {
+        const ffn_step& first = ch.step[0];
+        const f32x4* wp = reinterpret_cast<const f32x4*>(packed_w + first.w_off) + w.lane;
+#pragma unroll
+        for (int o = 0; o < 8; ++o)
+            if (o < first.out_tiles) {
+                pre[o] = wp[o * 64];
+                pre[8 + o] = wp[(int64_t)(first.out_tiles + o) * 64];
+            }
+    }
+    for (int li = 0; li < ch.num_steps; ++li) {
+        const ffn_step& L = ch.step[li];
+        const ffn_step* next = li + 1 < ch.num_steps ? &ch.step[li + 1] : nullptr;
+        switch (L.out_tiles) {
+            case 8: run_step<8, MODE>(ch, L, next, w, packed_w, pre, slab_out); break;
+            case 4: run_step<4, MODE>(ch, L, next, w, packed_w, pre, slab_out); break;
+            case 2: run_step<2, MODE>(ch, L, next, w, packed_w, pre, slab_out); break;
+            default: run_step<1, MODE>(ch, L, next, w, packed_w, pre, slab_out); break;
+        }
     }
 }
 
-__device__ __forceinline__ bool wave_setup(WaveCtx& w, char* smem, int64_t n) {
+// Persistent launch: one workgroup per CU; its four waves walk the 32-sample blocks
+// independently (block = first, first + stride, ...) -- no workgroup turnover, no tail of
+// SIMDs idling until the slowest sibling wave retires.
+__device__ __forceinline__ bool wave_setup(WaveCtx& w, char* smem, int64_t n, int64_t& stride) {
     w.lane = threadIdx.x & 63;
     w.h = w.lane >> 5;
     w.s = w.lane & 31;
     const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    stride = (int64_t)gridDim.x * kWavesPerBlock;
     w.act = reinterpret_cast<f32x4*>(smem + wave_in_block * kActBytesPerWave);
+    w.enc_table = reinterpret_cast<const float*>(smem + kWavesPerBlock * kActBytesPerWave);
+    w.bias_lds = reinterpret_cast<const float*>(smem + kWavesPerBlock * kActBytesPerWave + kEncTableBytes);
     w.num_blocks = (n + kSamplesPerWave - 1) / kSamplesPerWave;
     w.block = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block;
     return w.block < w.num_blocks;  // no barriers anywhere, an idle wave may simply leave
@@ -301,25 +371,35 @@ __global__ void __launch_bounds__(256, 1)
 mlp_forward_kernel(const ffn_mlp_chain ch, const float* __restrict__ packed_w,
                    const float* __restrict__ bias, const float* __restrict__ positions,
                    const float* __restrict__ views, int64_t n, float* __restrict__ logits,
-                   float* __restrict__ saved) {
+                   float* __restrict__ saved, uint32_t* __restrict__ masks) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    WaveCtx w;
-    if (!wave_setup(w, smem, n)) return;
-    const int64_t sample = w.block * kSamplesPerWave + w.s;
-    const int64_t src = sample < n ? sample : n - 1;  // tail lanes recompute the last sample
-    w.x0 = positions[src * 3 + 0]; w.x1 = positions[src * 3 + 1]; w.x2 = positions[src * 3 + 2];
-    if (views != nullptr) {
-        w.v0 = views[src * 3 + 0]; w.v1 = views[src * 3 + 1]; w.v2 = views[src * 3 + 2];
-    } else {
-        w.v0 = w.v1 = w.v2 = 0.0f;
+    stage_encoding_tables(ch.enc, reinterpret_cast<float*>(smem + kWavesPerBlock * kActBytesPerWave),
+                          threadIdx.x, 256);
+    {
+        float* bl = reinterpret_cast<float*>(smem + kWavesPerBlock * kActBytesPerWave + kEncTableBytes);
+        for (int i = threadIdx.x; i < ch.bias_floats; i += 256) bl[i] = bias[i];
     }
-    w.logit[0] = w.logit[1] = w.logit[2] = w.logit[3] = 0.0f;
-    for (int li = 0; li < ch.num_steps; ++li)
-        dispatch_step<MODE>(ch, ch.step[li], w, packed_w, bias, nullptr, saved);
-    if (w.h == 0 && sample < n) {
-        f32x4 out;
-        out[0] = w.logit[0]; out[1] = w.logit[1]; out[2] = w.logit[2]; out[3] = w.logit[3];
-        reinterpret_cast<f32x4*>(logits)[sample] = out;
+    __syncthreads();                                  // the only barrier of the kernel
+    WaveCtx w;
+    int64_t stride;
+    if (!wave_setup(w, smem, n, stride)) return;
+    w.masks = reinterpret_cast<uint4*>(masks);
+    for (; w.block < w.num_blocks; w.block += stride) {
+        const int64_t sample = w.block * kSamplesPerWave + w.s;
+        const int64_t src = sample < n ? sample : n - 1;  // tail lanes recompute the last sample
+        w.x0 = positions[src * 3 + 0]; w.x1 = positions[src * 3 + 1]; w.x2 = positions[src * 3 + 2];
+        if (views != nullptr) {
+            w.v0 = views[src * 3 + 0]; w.v1 = views[src * 3 + 1]; w.v2 = views[src * 3 + 2];
+        } else {
+            w.v0 = w.v1 = w.v2 = 0.0f;
+        }
+        w.logit[0] = w.logit[1] = w.logit[2] = w.logit[3] = 0.0f;
+        run_chain<MODE>(ch, w, packed_w, saved);
+        if (w.h == 0 && sample < n) {
+            f32x4 out;
+            out[0] = w.logit[0]; out[1] = w.logit[1]; out[2] = w.logit[2]; out[3] = w.logit[3];
+            reinterpret_cast<f32x4*>(logits)[sample] = out;
+        }
     }
 }
 
@@ -327,17 +407,20 @@ mlp_forward_kernel(const ffn_mlp_chain ch, const float* __restrict__ packed_w,
 // dZ of every hidden layer (block layout) for the weight-gradient kernel.
 __global__ void __launch_bounds__(256, 1)
 mlp_backward_data_kernel(const ffn_mlp_chain ch, const float* __restrict__ packed_wt,
-                         const float* __restrict__ d_logits, int64_t n, float* __restrict__ saved,
-                         float* __restrict__ dz) {
+                         const float* __restrict__ d_logits, int64_t n,
+                         uint32_t* __restrict__ masks, float* __restrict__ dz) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     WaveCtx w;
-    if (!wave_setup(w, smem, n)) return;
-    const int64_t sample = w.block * kSamplesPerWave + w.s;
-    f32x4 zero; zero[0] = zero[1] = zero[2] = zero[3] = 0.0f;
-    w.dl = sample < n ? reinterpret_cast<const f32x4*>(d_logits)[sample] : zero;
+    int64_t stride;
+    if (!wave_setup(w, smem, n, stride)) return;
+    w.masks = reinterpret_cast<uint4*>(masks);
     w.x0 = w.x1 = w.x2 = w.v0 = w.v1 = w.v2 = 0.0f;
-    for (int li = 0; li < ch.num_steps; ++li)
-        dispatch_step<kBackward>(ch, ch.step[li], w, packed_wt, nullptr, saved, dz);
+    for (; w.block < w.num_blocks; w.block += stride) {
+        const int64_t sample = w.block * kSamplesPerWave + w.s;
+        f32x4 zero; zero[0] = zero[1] = zero[2] = zero[3] = 0.0f;
+        w.dl = sample < n ? reinterpret_cast<const f32x4*>(d_logits)[sample] : zero;
+        run_chain<kBackward>(ch, w, packed_wt, dz);
+    }
 }
 
 }  // namespace ffn
@@ -358,14 +441,16 @@ extern "C" int ffn_mlp_pack(const float* src, int rows, int cols, int ld, int tr
 
 static int validate_chain(const ffn_mlp_chain* ch, bool backward) {
     if (ch == nullptr || ch->num_steps < 1 || ch->num_steps > FFN_MAX_STEPS) return 1;
+    if (ch->bias_floats < 0 || ch->bias_floats > kBiasLdsFloats) return 1;
     for (int i = 0; i < ch->num_steps; ++i) {
         const ffn_step& L = ch->step[i];
         const int ot = L.out_tiles;
         if (!(ot == 1 || ot == 2 || ot == 4 || ot == 8)) return 1;
         if (L.act_groups < 0 || L.aux_groups < 0 || L.act_groups > 32) return 1;
-        if ((L.act_groups & 3) || (L.aux_groups & 1) || L.act_groups + L.aux_groups == 0) return 1;
+        if ((L.act_groups & 3) || (L.aux_groups & 3) || L.act_groups + L.aux_groups == 0) return 1;
         if (!backward && L.aux_groups > 0 && (L.enc_id < 0 || L.enc_id > 1)) return 1;
-        if (backward && L.aux_groups != 0 && L.aux_groups != 2) return 1;
+        if (!backward && (ch->enc[0].num_freq > 256 || ch->enc[1].num_freq > 256)) return 1;
+        if (backward && L.aux_groups != 0 && L.aux_groups != 4) return 1;
         if (backward && L.aux_groups && (L.lg_n < 1 || L.lg_col < 0 || L.lg_col + L.lg_n > 4)) return 1;
         if (!backward && L.dst == 1 &&
             (L.out_n < 1 || L.out_n > 4 || L.out_col < 0 || L.out_col + L.out_n > 4))
@@ -374,7 +459,21 @@ static int validate_chain(const ffn_mlp_chain* ch, bool backward) {
     return 0;
 }
 
-static const size_t kLdsBytes = (size_t)kWavesPerBlock * kActBytesPerWave;
+static const size_t kLdsBytes = (size_t)kWavesPerBlock * kActBytesPerWave + kEncTableBytes + kBiasLdsFloats * 4;
+
+// one resident workgroup per CU (its ~150 KiB of LDS admit no second one)
+static int64_t persistent_grid(int64_t blocks32) {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    const int64_t wgs = (blocks32 + kWavesPerBlock - 1) / kWavesPerBlock;
+    return wgs < cus ? wgs : cus;
+}
 
 template <typename K>
 static void allow_big_lds(K kernel) {
@@ -384,34 +483,36 @@ static void allow_big_lds(K kernel) {
 
 extern "C" int ffn_mlp_forward(const ffn_mlp_chain* chain, const float* packed_w,
                                const float* bias, const float* positions, const float* views,
-                               int64_t n, float* logits, float* saved, void* stream) {
+                               int64_t n, float* logits, float* saved, uint32_t* masks,
+                               void* stream) {
     if (n == 0) return 0;
     if (n < 0 || validate_chain(chain, false)) return fail_arg("ffn_mlp_forward: bad chain or size");
+    if ((saved == nullptr) != (masks == nullptr)) return fail_arg("ffn_mlp_forward: saved and masks go together");
     const int64_t blocks32 = (n + kSamplesPerWave - 1) / kSamplesPerWave;
-    const int64_t grid = (blocks32 + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int64_t grid = persistent_grid(blocks32);
     if (saved != nullptr) {
         allow_big_lds(&mlp_forward_kernel<kTrainFwd>);
         hipLaunchKernelGGL(mlp_forward_kernel<kTrainFwd>, dim3((unsigned)grid), dim3(256), kLdsBytes,
                            (hipStream_t)stream, *chain, packed_w, bias, positions, views, n, logits,
-                           saved);
+                           saved, masks);
     } else {
         allow_big_lds(&mlp_forward_kernel<kInfer>);
         hipLaunchKernelGGL(mlp_forward_kernel<kInfer>, dim3((unsigned)grid), dim3(256), kLdsBytes,
                            (hipStream_t)stream, *chain, packed_w, bias, positions, views, n, logits,
-                           saved);
+                           saved, masks);
     }
     return check_launch("ffn_mlp_forward");
 }
 
 extern "C" int ffn_mlp_backward_data(const ffn_mlp_chain* chain, const float* packed_wt,
-                                     const float* d_logits, int64_t n, float* saved, float* dz,
-                                     void* stream) {
+                                     const float* d_logits, int64_t n, uint32_t* masks,
+                                     float* dz, void* stream) {
     if (n == 0) return 0;
     if (n < 0 || validate_chain(chain, true)) return fail_arg("ffn_mlp_backward_data: bad chain or size");
     const int64_t blocks32 = (n + kSamplesPerWave - 1) / kSamplesPerWave;
-    const int64_t grid = (blocks32 + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int64_t grid = persistent_grid(blocks32);
     allow_big_lds(&mlp_backward_data_kernel);
     hipLaunchKernelGGL(mlp_backward_data_kernel, dim3((unsigned)grid), dim3(256), kLdsBytes,
-                       (hipStream_t)stream, *chain, packed_wt, d_logits, n, saved, dz);
+                       (hipStream_t)stream, *chain, packed_wt, d_logits, n, masks, dz);
     return check_launch("ffn_mlp_backward_data");
 }

@@ -23,9 +23,11 @@ struct EncRegsW {
     const float* b; const float* a; int F; int Fi; int raw; float scale;
 };
 
-__device__ __forceinline__ EncRegsW load_enc_w(const ffn_encoding& e) {
+__device__ __forceinline__ EncRegsW load_enc_w(const ffn_encoding& e, const float* table = nullptr) {
     EncRegsW r;
-    r.b = e.b; r.a = e.a; r.F = e.num_freq; r.Fi = e.num_freq > 0 ? e.num_freq : 1;
+    r.F = e.num_freq; r.Fi = e.num_freq > 0 ? e.num_freq : 1;
+    r.b = table != nullptr ? table : e.b;              // LDS copy when the kernel staged one
+    r.a = table != nullptr ? table + 3 * r.Fi : e.a;
     r.raw = (e.include_input != 0 || e.num_freq == 0) ? 1 : 0;
     r.scale = e.scale;
     return r;
@@ -260,7 +262,9 @@ __device__ __forceinline__ void unit_segment(const ffn_mlp_chain& ch, const ffn_
     const int64_t a_stride = ch.slot_channels[unit.m_slot] * 8;
     const f32x4* b_slab = nullptr;
     int64_t b_stride = 0;
-    EncRegsW enc = load_enc_w(ch.enc[ENC ? unit.n_slot : 0]);
+    const int enc_id = ENC ? unit.n_slot : 0;
+    EncRegsW enc = load_enc_w(ch.enc[enc_id], reinterpret_cast<const float*>(smem + 2 * kUnitBufBytes) +
+                                                  enc_id * kEncTablePitch);
     if (!ENC) {
         b_slab = reinterpret_cast<const f32x4*>(saved + ch.slot_offset[unit.n_slot] * num_blocks * 32) + unit.n_cq0 * 32;
         b_stride = ch.slot_channels[unit.n_slot] * 8;
@@ -381,6 +385,8 @@ wgrad_unit_kernel(const ffn_mlp_chain ch, const ffn_wgrad_unit* __restrict__ uni
                   const float* __restrict__ dz, const float* __restrict__ positions,
                   const float* __restrict__ views, int64_t n, float* __restrict__ partials) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    stage_encoding_tables(ch.enc, reinterpret_cast<float*>(smem + 2 * kUnitBufBytes), threadIdx.x, 256);
+    __syncthreads();
     const int64_t num_blocks = (n + 31) / 32;
     const int seg_lo = seg_start[blockIdx.x], seg_hi = seg_start[blockIdx.x + 1];
     for (int si = seg_lo; si < seg_hi; ++si) {
@@ -473,7 +479,7 @@ extern "C" int ffn_mlp_wgrad_units(const ffn_mlp_chain* chain, const ffn_wgrad_u
                                    const float* positions, const float* views, int64_t n,
                                    float* partials, void* stream) {
     if (n <= 0 || num_groups <= 0) return fail_arg("ffn_mlp_wgrad_units: shape");
-    const size_t lds = 2 * kUnitBufBytes;
+    const size_t lds = 2 * kUnitBufBytes + kEncTableBytes;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_unit_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(wgrad_unit_kernel, dim3(num_groups), dim3(256), lds, (hipStream_t)stream,

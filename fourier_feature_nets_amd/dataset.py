@@ -141,28 +141,52 @@ class ImageDataset(RayDataset):
         # ground truth (a GPU division by a constant may differ in the last ulp)
         self.colors = torch.from_numpy(
             (images[..., :3].astype(np.float32) / 255).reshape(-1, 3)).to(dev).contiguous()
-        self.dilate_ranges = []
-        self.dilate_index = torch.zeros((0,), dtype=torch.int64, device=dev)
         has_alpha = images.shape[-1] == 4
+        self._has_alpha = has_alpha
+        self._dilate = None        # (index, ranges), built on first use of Mode.Dilate
+        alpha = None
         if has_alpha:
             alpha = torch.from_numpy(images[..., 3].astype(np.float32) / 255).to(dev)
-            radius = 8 * min(width, height) // 100
-            element = torch.from_numpy(_ellipse(2 * radius + 1)).float().to(dev)
-            mask = (alpha > 0).float().unsqueeze(1)
-            grown = torch.nn.functional.conv2d(mask, element[None, None], padding=radius) > 0
-            found, total = [], 0
-            for cam in range(len(images)):
-                ids = torch.nonzero(grown[cam, 0].reshape(-1)).flatten() + cam * per_cam
-                self.dilate_ranges.append((total, total + int(ids.numel())))
-                total += int(ids.numel())
-                found.append(ids)
-            self.dilate_index = torch.cat(found)
         if has_alpha and include_alpha:
             self.alphas = alpha.reshape(-1).contiguous()
             self.alpha_weight = alpha_weight
         else:
             self.alphas = None
             self.alpha_weight = 0
+
+    # ------------------------------------------------------------------ dilate mode (lazy)
+    def _build_dilate(self):
+        """Ray ids inside an elliptical dilation (radius 8% of the short side) of each
+        image's alpha mask (image_dataset.py:92-135).  Set-up only, so it runs as a stock
+        conv2d; "parity unpinned": OpenCV's ellipse rasterisation is restated from its docs."""
+        if self._dilate is not None:
+            return self._dilate
+        dev = self.sampler.device
+        width, height = self.image_width, self.image_height
+        per_cam = width * height
+        ranges, found, total = [], [], 0
+        if self._has_alpha:
+            radius = 8 * min(width, height) // 100
+            element = torch.from_numpy(_ellipse(2 * radius + 1)).float().to(dev)
+            for cam in range(len(self._images)):
+                mask = torch.from_numpy((self._images[cam, ..., 3] > 0).astype(np.float32)).to(dev)
+                grown = torch.nn.functional.conv2d(mask[None, None], element[None, None],
+                                                   padding=radius) > 0
+                ids = torch.nonzero(grown.reshape(-1)).flatten() + cam * per_cam
+                ranges.append((total, total + int(ids.numel())))
+                total += int(ids.numel())
+                found.append(ids)
+        index = torch.cat(found) if found else torch.zeros((0,), dtype=torch.int64, device=dev)
+        self._dilate = (index, ranges)
+        return self._dilate
+
+    @property
+    def dilate_index(self) -> torch.Tensor:
+        return self._build_dilate()[0]
+
+    @property
+    def dilate_ranges(self):
+        return self._build_dilate()[1]
 
     # ------------------------------------------------------------------ properties
     @property
@@ -175,7 +199,7 @@ class ImageDataset(RayDataset):
 
     @mode.setter
     def mode(self, value: RayDataset.Mode):
-        if value == RayDataset.Mode.Dilate and len(self.dilate_index) == 0:
+        if value == RayDataset.Mode.Dilate and not self._has_alpha:
             raise ValueError("Unable to use dilate mode: missing alpha channel")
         self._mode = value
 

@@ -44,6 +44,7 @@ class FfnStep(ctypes.Structure):
 class FfnMlpChain(ctypes.Structure):
     _fields_ = [("enc", FfnEncoding * 2), ("step", FfnStep * MAX_STEPS),
                 ("num_steps", ctypes.c_int32), ("num_slots", ctypes.c_int32),
+                ("bias_floats", ctypes.c_int32), ("reserved", ctypes.c_int32),
                 ("slot_channels", ctypes.c_int32 * MAX_STEPS),
                 ("slot_offset", ctypes.c_int64 * MAX_STEPS)]
 
@@ -100,9 +101,11 @@ class EncodingSpec:
         self.a = a.contiguous()
         self.scale = float(scale)
         self.include_input = bool(include_input) or self.num_freq == 0
+        if self.num_freq > 256:
+            raise NotImplementedError("encodings with more than 256 frequencies")
         natural = 2 * self.num_freq + (3 if self.include_input else 0)
         self.natural_width = natural
-        self.width = ((natural + 15) // 16) * 16
+        self.width = ((natural + 31) // 32) * 32
 
     def natural_index(self, internal: int) -> int:
         """Natural column ([cos F][sin F][x 3]) of internal channel 2k+trig / 2F+d, or -1."""
@@ -237,6 +240,8 @@ class MlpProgram:
                     raise NotImplementedError("hidden widths must be multiples of 32")
                 slot = len(self.slot_of)
                 self.slot_of[i] = slot
+                if spec.relu:
+                    L.mask_slot = slot           # sign bits of this layer's output
                 fwd.slot_channels[slot] = spec.out
                 fwd.slot_offset[slot] = slot_off
                 slot_off += spec.out
@@ -260,6 +265,9 @@ class MlpProgram:
             g_off += spec.out
         fwd.num_steps = len(self.layers)
         fwd.num_slots = len(self.slot_of)
+        fwd.bias_floats = b_off
+        if b_off > 4096:
+            raise NotImplementedError("more than 4096 (padded) bias values")
         self.fwd = fwd
         self.saved_channels = slot_off
         self.num_grad_floats = g_off
@@ -291,7 +299,7 @@ class MlpProgram:
             st = FfnStep()
             st.out_tiles = _tiles(self.layers[j].out)
             st.act_groups = 0 if not hidden else self.layers[hidden[0]].out // 8
-            st.aux_groups = 2 if heads else 0
+            st.aux_groups = 4 if heads else 0
             st.relu = 0
             st.mask_slot = self.slot_of[j] if self.layers[j].relu else -1
             st.save_in_slot = self.slot_of[hidden[0]] if hidden else -1
@@ -304,8 +312,8 @@ class MlpProgram:
             if heads:
                 c = heads[0]
                 st.lg_col, st.lg_n = self.layers[c].to_logits
-                self.bwd_packs.append((c, 2, st.out_tiles, wt_off))
-                wt_off += 2 * st.out_tiles * 256
+                self.bwd_packs.append((c, 4, st.out_tiles, wt_off))
+                wt_off += 4 * st.out_tiles * 256
             steps.append(st)
         if steps:
             # the last step's output (dZ of the first producer) has no consumer step
@@ -463,17 +471,27 @@ class MlpProgram:
         return ws
 
     def saved_floats(self, n: int) -> int:
-        return self.saved_channels * 32 * ((n + 31) // 32)
+        """Size (in floats) of the per-call training buffer: activation slabs followed by
+        the ReLU sign masks (256 words per 32-sample block and slab)."""
+        blocks = (n + 31) // 32
+        return self.saved_channels * 32 * blocks + self.fwd.num_slots * 256 * blocks
+
+    def _split_saved(self, saved: torch.Tensor, n: int):
+        blocks = (n + 31) // 32
+        acts = self.saved_channels * 32 * blocks
+        return saved[:acts], saved[acts:acts + self.fwd.num_slots * 256 * blocks]
 
     def forward(self, positions: torch.Tensor, views: Optional[torch.Tensor],
                 saved: Optional[torch.Tensor] = None) -> torch.Tensor:
         """positions (N,3) [views (N,3)] -> raw logits (N,4).  ``saved`` (a flat float
-        buffer of ``saved_floats(N)`` elements) receives the activations for backward."""
+        buffer of ``saved_floats(N)`` elements) receives what the backward pass needs."""
         n = positions.shape[0]
         logits = torch.empty((n, 4), dtype=torch.float32, device=self.device)
+        acts, masks = (None, None) if saved is None else self._split_saved(saved, n)
         _lib.call("ffn_mlp_forward", ctypes.byref(self.fwd), _dev(self.packed_fwd),
                   _dev(self.bias_buf), _dev(positions, name="positions"),
-                  _dev(views, name="views"), c_i64(n), _dev(logits), _dev(saved), _stream())
+                  _dev(views, name="views"), c_i64(n), _dev(logits), _dev(acts), _dev(masks),
+                  _stream())
         return logits
 
     def backward(self, d_logits: torch.Tensor, positions: torch.Tensor,
@@ -482,9 +500,10 @@ class MlpProgram:
         activations ``saved`` by the matching forward call."""
         n = positions.shape[0]
         ws = self.workspace(n)
+        saved, masks = self._split_saved(saved, n)
         if self.bwd.num_steps > 0:
             _lib.call("ffn_mlp_backward_data", ctypes.byref(self.bwd), _dev(self.packed_bwd),
-                      _dev(d_logits), c_i64(n), _dev(saved), _dev(ws.dz), _stream())
+                      _dev(d_logits), c_i64(n), _dev(masks), _dev(ws.dz), _stream())
         if self.wgrad_units:
             _lib.call("ffn_mlp_wgrad_units", ctypes.byref(self.fwd),
                       _dev(self.wgrad_units_dev, torch.uint8), _dev(ws.unit_segments, torch.uint8),

@@ -177,7 +177,7 @@ typedef struct ffn_encoding {
     int32_t num_freq;      /* F; 0 => features are the raw 3 inputs                  */
     int32_t include_input; /* append x after [cos,sin]                               */
     float scale;           /* pi (FourierFeatureMLP) or 1 (NeRF)                     */
-    int32_t width;         /* internal feature count padded to a multiple of 16     */
+    int32_t width;         /* internal feature count padded to a multiple of 32     */
 } ffn_encoding;
 
 /* One dense step.  Its K dimension is [act_groups groups of 8 channels read back from the
@@ -185,7 +185,8 @@ typedef struct ffn_encoding {
  * groups]: Fourier features of encoding enc_id in a forward chain (first layer = features
  * only, hidden layer = activations only, NeRF's skip and view layers = both,
  * nerf_model.py:112-121), or the d_logits columns [lg_col, lg_col+lg_n) in a backward
- * chain (the sigma / rgb heads).  act_groups % 4 == 0, aux_groups % 2 == 0.            */
+ * chain (the sigma / rgb heads; 4 groups, only the first is non-zero).  Both counts are
+ * multiples of 4.                                                                      */
 typedef struct ffn_step {
     int32_t act_groups;
     int32_t aux_groups;
@@ -200,8 +201,9 @@ typedef struct ffn_step {
     int32_t save_in_slot;  /* slab that receives the act-part INPUT while it is being
                               consumed (forward: H for backward; backward: dZ), or -1  */
     int32_t save_out_slot; /* backward: slab that receives the step's output, or -1    */
-    int32_t mask_slot;     /* backward: slab of the forward activation whose sign gates
-                              the output (ReLU'), or -1                                */
+    int32_t mask_slot;     /* ReLU sign-mask slot: a forward step writes the sign bits of
+                              its output there, the backward step that differentiates that
+                              layer reads them; -1 = no ReLU                           */
     int32_t reserved;
     int64_t w_off;         /* float offset of this step's packed operand weights       */
     int64_t b_off;         /* forward: float offset of the bias (padded to 32*tiles)   */
@@ -212,6 +214,8 @@ typedef struct ffn_mlp_chain {
     ffn_step step[FFN_MAX_STEPS];
     int32_t num_steps;
     int32_t num_slots;                     /* activation slabs                        */
+    int32_t bias_floats;                   /* total padded bias floats (<= 4096)      */
+    int32_t reserved;
     int32_t slot_channels[FFN_MAX_STEPS];  /* channels of each slab (multiple of 32)  */
     int64_t slot_offset[FFN_MAX_STEPS];    /* sum of channels of the slabs before it  */
 } ffn_mlp_chain;
@@ -231,17 +235,20 @@ int ffn_mlp_pack(const float* src, int rows, int cols, int ld, int transpose,
                  const int32_t* row_map, const int32_t* col_map, int groups, int tiles,
                  float* dst, void* stream);
 
-/* Forward chain.  positions (N,3), views (N,3) or NULL, logits out (N,4).  saved: when
- * non-NULL, every step with save_in_slot >= 0 writes its input activations there (block
- * layout) for the backward pass. */
+/* Forward chain.  positions (N,3), views (N,3) or NULL, logits out (N,4).  Training: when
+ * `saved` and `masks` are non-NULL, every step with save_in_slot >= 0 writes its input
+ * activations into `saved` (block layout, for the weight gradients) and every ReLU step
+ * writes the sign bits of its output into `masks` (num_slots * num_blocks * 256 uint32:
+ * [slot][block][lane][4], bit 16*(tile&1)+r of word tile/2 = accumulator register r of
+ * that lane) for the backward-data chain. */
 int ffn_mlp_forward(const ffn_mlp_chain* chain, const float* packed_w, const float* bias,
                     const float* positions, const float* views, int64_t n, float* logits,
-                    float* saved, void* stream);
+                    float* saved, uint32_t* masks, void* stream);
 
-/* Backward-data chain: d_logits (N,4) + saved forward activations -> dZ slabs (same slab
- * geometry as `saved`).  packed_wt holds the transposed operand packs. */
+/* Backward-data chain: d_logits (N,4) + ReLU sign masks -> dZ slabs (same slab geometry as
+ * `saved`).  packed_wt holds the transposed operand packs. */
 int ffn_mlp_backward_data(const ffn_mlp_chain* chain, const float* packed_wt,
-                          const float* d_logits, int64_t n, float* saved, float* dz,
+                          const float* d_logits, int64_t n, uint32_t* masks, float* dz,
                           void* stream);
 
 /* Weight gradients.  A job is one 128x128 patch of some dW (kind 0) or the <=4 rows of a

@@ -516,4 +516,4 @@ class OracleTrainer:
         with torch.no_grad():
             for p, g, m, v in zip(params, grads, self.m, self.v):
                 adam_update(p, g, m, v, self.count, lr, self.weight_decay)
-        return float(loss)
+        return float(loss.detach())

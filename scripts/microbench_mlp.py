@@ -21,15 +21,21 @@ def main():
     ap.add_argument("--samples", type=int, default=64)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--channels", type=int, default=256)
+    ap.add_argument("--model", default="positional", choices=["positional", "raw"])
+    ap.add_argument("--hidden", type=int, default=3)
     args = ap.parse_args()
     from oracle import ffn_oracle as orc
     from fourier_feature_nets_amd.mlp_engine import DenseSpec, EncodingSpec, MlpProgram
     dev = torch.device("cuda:0")
     torch.manual_seed(20080524)
     C = args.channels
-    b = orc.positional_b_values(5.5, 256, 3).to(dev)
-    a = torch.ones(b.shape[1], device=dev)
-    dims = [(C, 2 * b.shape[1]), (C, C), (C, C), (4, C)]
+    if args.model == "positional":
+        b = orc.positional_b_values(5.5, 256, 3).to(dev)
+        a = torch.ones(b.shape[1], device=dev)
+        first = 2 * b.shape[1]
+    else:
+        b, a, first = None, None, 3
+    dims = [(C, first)] + [(C, C)] * (args.hidden - 1) + [(4, C)]
     layers = []
     for i, (o, k) in enumerate(dims):
         lin = torch.nn.Linear(k, o)
@@ -37,7 +43,7 @@ def main():
         layers.append(DenseSpec(lin.weight.detach().to(dev), lin.bias.detach().to(dev),
                                 0 if i == 0 else k, 0 if i == 0 else None, not last,
                                 (0, 4) if last else None))
-    prog = MlpProgram([EncodingSpec(b, a, math.pi, False)], layers, dev)
+    prog = MlpProgram([EncodingSpec(b, a, math.pi, False, dev)], layers, dev)
     prog.pack()
     n = args.rays * args.samples
     x = (torch.rand(n, 3, device=dev) * 2 - 1)

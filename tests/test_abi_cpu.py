@@ -22,7 +22,7 @@ def test_library_is_built_and_exports_every_declared_symbol():
 
 
 def test_plan_struct_sizes_match_header():
-    """ctypes mirrors of the plan structs have the C layout (checked against a tiny C probe
+    """ctypes mirrors of the ABI structs have the C layout (checked against a tiny C probe
     compiled with gcc from the real header)."""
     import subprocess
     import tempfile
@@ -32,9 +32,12 @@ def test_plan_struct_sizes_match_header():
     #include <stddef.h>
     #include "ffn_hip.h"
     int main(void) {
-      printf("%zu %zu %zu %zu %zu %zu\n", sizeof(ffn_encoding), sizeof(ffn_layer),
-             sizeof(ffn_mlp_plan), offsetof(ffn_mlp_plan, layer), offsetof(ffn_mlp_plan, num_layers),
-             offsetof(ffn_mlp_plan, slot_offset));
+      printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(ffn_encoding),
+             sizeof(ffn_step), sizeof(ffn_mlp_chain), offsetof(ffn_mlp_chain, step),
+             offsetof(ffn_mlp_chain, num_steps), offsetof(ffn_mlp_chain, bias_floats),
+             offsetof(ffn_mlp_chain, slot_offset), offsetof(ffn_step, w_off),
+             sizeof(ffn_wgrad_job), sizeof(ffn_wgrad_unit), sizeof(ffn_wgrad_segment),
+             sizeof(ffn_reduce_job));
       return 0; }'''
     with tempfile.TemporaryDirectory() as tmp:
         c_path = os.path.join(tmp, "probe.c")
@@ -44,10 +47,12 @@ def test_plan_struct_sizes_match_header():
         inc = os.path.dirname(_lib.HEADER_PATH)
         subprocess.run(["gcc", "-I", inc, c_path, "-o", exe], check=True)
         out = subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()
-    got = [ctypes.sizeof(me.FfnEncoding), ctypes.sizeof(me.FfnLayer), ctypes.sizeof(me.FfnMlpPlan),
-           me.FfnMlpPlan.layer.offset, me.FfnMlpPlan.num_layers.offset,
-           me.FfnMlpPlan.slot_offset.offset]
-    assert [int(v) for v in out] == got
+    got = [ctypes.sizeof(me.FfnEncoding), ctypes.sizeof(me.FfnStep), ctypes.sizeof(me.FfnMlpChain),
+           me.FfnMlpChain.step.offset, me.FfnMlpChain.num_steps.offset,
+           me.FfnMlpChain.bias_floats.offset, me.FfnMlpChain.slot_offset.offset,
+           me.FfnStep.w_off.offset, ctypes.sizeof(me.FfnWgradJob), ctypes.sizeof(me.FfnWgradUnit),
+           ctypes.sizeof(me.FfnWgradSegment), ctypes.sizeof(me.FfnReduceJob)]
+    assert [int(v) for v in out] == got, (out, got)
 
 
 def test_ops_refuse_cpu_tensors():

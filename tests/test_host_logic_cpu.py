@@ -1,0 +1,232 @@
+"""Host-side logic that needs no GPU: chain / job planning for the fused MLP kernels, the
+encoding column maps, camera rigs, and the data-parallel arithmetic (2 gloo ranks on CPU, with
+the oracle standing in for the kernels)."""
+
+import math
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+import fourier_feature_nets_amd as ffn
+from fourier_feature_nets_amd.mlp_engine import EncodingSpec, MlpProgram
+from oracle import ffn_oracle as orc
+
+
+def _plan(model):
+    enc, specs = model._chain(torch.device("cpu"))
+    return MlpProgram(enc, specs, torch.device("cpu"), planning_only=True)
+
+
+def test_models_keep_the_reference_state_dict_layout():
+    nerf = ffn.NeRF(8, 256, 9, 10, 3, 4, [4], True)
+    shapes = {k: tuple(v.shape) for k, v in nerf.state_dict().items()}
+    assert list(shapes)[:2] == ["pos_encoding", "view_encoding"]
+    assert shapes["layers.0.weight"] == (256, 63) and shapes["layers.4.weight"] == (256, 319)
+    assert shapes["hidden_view.weight"] == (128, 283) and shapes["color_out.weight"] == (3, 128)
+    assert sum(p.numel() for p in nerf.parameters() if p.requires_grad) == 595844
+    tiny = ffn.PositionalFourierMLP(3, 4, 5.5)
+    assert tuple(tiny.b_values.shape) == (3, 255)
+    assert sum(p.numel() for p in tiny.parameters() if p.requires_grad) == 263428
+    assert tiny.use_view is False and nerf.use_view is True
+    # frequency tables are bit-identical to the oracle's restatement of the reference
+    assert torch.equal(tiny.b_values.data, orc.positional_b_values(5.5, 256, 3))
+    assert torch.equal(nerf.pos_encoding.data, orc.axis_frequency_matrix(9, 10))
+
+
+def test_encoding_internal_order_covers_every_natural_column_once():
+    for freq, inc in [(255, False), (30, True), (12, True), (0, False), (256, False), (3, False)]:
+        b = None if freq == 0 else torch.zeros(3, freq)
+        enc = EncodingSpec(b, None, math.pi, inc, torch.device("cpu"))
+        nat = [enc.natural_index(c) for c in range(enc.width)]
+        real = [n for n in nat if n >= 0]
+        assert sorted(real) == list(range(enc.natural_width))
+        assert enc.width % 32 == 0 and enc.width >= enc.natural_width
+        # cos at even internal channels, sin at odd ones
+        for k in range(freq):
+            assert nat[2 * k] == k and nat[2 * k + 1] == freq + k
+
+
+@pytest.mark.parametrize("make", [
+    lambda: ffn.PositionalFourierMLP(3, 4, 5.5),
+    lambda: ffn.NeRF(8, 256, 9, 10, 3, 4, [4], True),
+    lambda: ffn.MLP(3, 4, num_channels=64),
+    lambda: ffn.NeRF(4, 64, 5, 6, 2, 3, [2], False),
+])
+def test_chain_and_wgrad_plans(make):
+    model = make()
+    prog = _plan(model)
+    n_dense = len(prog.layers)
+    assert prog.fwd.num_steps == n_dense
+    assert prog.num_grad_floats == sum(p.numel() for p in model._dense_params())
+    # forward steps: K groups multiples of 4, every hidden output has exactly one slab
+    for i in range(n_dense):
+        st = prog.fwd.step[i]
+        assert st.act_groups % 4 == 0 and st.aux_groups % 4 == 0
+        assert st.out_tiles in (1, 2, 4, 8)
+    assert prog.fwd.num_slots == len([s for s in prog.layers if s.to_logits is None])
+    saved_by = [prog.fwd.step[i].save_in_slot for i in range(n_dense)]
+    used = [s for s in saved_by if s >= 0]
+    assert len(used) == len(set(used))           # each activation is saved by one consumer
+    # backward chain ends by storing dZ of the first layer
+    last = prog.bwd.step[prog.bwd.num_steps - 1]
+    assert last.save_out_slot == 0
+    # every (row, col) of every weight gradient is produced by exactly one reduce job
+    for blocks in (1, 7, 4096):
+        plan = prog._plan_wgrad(blocks)
+        cover = {}
+        for seg in plan["unit_segments"]:
+            cover.setdefault(("u", seg.job), []).append((seg.blk_begin, seg.blk_end))
+        for seg in plan["head_segments"]:
+            cover.setdefault(("h", seg.job), []).append((seg.blk_begin, seg.blk_end))
+        assert len(cover) == len(prog.wgrad_units) + len(prog.wgrad_jobs)
+        for spans in cover.values():
+            spans.sort()
+            assert spans[0][0] == 0 and spans[-1][1] == blocks
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        for li, spec in enumerate(prog.layers):
+            hits = np.zeros((spec.out, spec.ld), np.int32)
+            cmap = prog.col_maps[li].numpy()
+            for rj in plan["reduce_jobs"]:
+                if rj.w_grad_off != prog.grad_w_off[li]:
+                    continue
+                for jj in range(rj.n_quads):
+                    for q in range(4):
+                        col = cmap[rj.k_base + 4 * (rj.n_quad0 + jj) + q]
+                        if col < 0:
+                            continue
+                        if rj.kind == 0:
+                            rows = range(rj.m_ch0, min(rj.m_ch0 + 128, spec.out))
+                        else:
+                            rows = range(rj.lg_n)
+                        for row in rows:
+                            hits[row, col] += 1
+            assert hits.min() == 1 and hits.max() == 1, (li, hits.min(), hits.max())
+        slots = set()
+        for rj in plan["reduce_jobs"]:
+            mine = set(range(rj.slot_begin, rj.slot_end, rj.slot_stride))
+            assert not (mine & slots)
+            slots |= mine
+        assert max(slots) < plan["slots"]
+
+
+def test_unsupported_shapes_raise_not_fall_back():
+    with pytest.raises(NotImplementedError):
+        _plan(ffn.GaussianFourierMLP(3, 4, 10.0, num_channels=512))
+    with pytest.raises(NotImplementedError):
+        _plan(ffn.MLP(3, 4, num_channels=96))
+    model = ffn.MLP(3, 4, num_channels=32)
+    with pytest.raises(RuntimeError, match="GPU"):
+        model(torch.zeros(2, 3))
+    with pytest.raises(RuntimeError, match="GPU"):
+        ffn.RaySampler(np.eye(4, dtype=np.float32) * 2, [], 8, device="cpu")
+
+
+def test_orbit_cameras_look_at_the_origin():
+    cams = ffn.orbit(np.array([0, 1, 0.]), np.array([0, 0, 1.]), 12, 40, ffn.Resolution(64, 48), 4)
+    assert len(cams) == 12
+    for cam in cams:
+        pose = cam.extrinsics
+        eye = pose[:3, 3]
+        assert abs(np.linalg.norm(eye) - 4) < 1e-5
+        np.testing.assert_allclose(pose[:3, 2], -eye / np.linalg.norm(eye), atol=1e-6)
+        np.testing.assert_allclose(pose[:3, :3] @ pose[:3, :3].T, np.eye(3), atol=1e-6)
+        assert cam.intrinsics[0, 2] == 32 and cam.intrinsics[1, 2] == 24
+    # altitude ramps up then down; azimuth makes two turns
+    heights = [c.extrinsics[1, 3] for c in cams]
+    assert heights[5] > heights[0] and heights[5] > heights[11]
+    assert abs(cams[0].fov_y_degrees - 2 * np.degrees(np.arctan(32 / cams[0].intrinsics[1, 1]))) < 1e-4
+
+
+def test_lr_schedule_and_result_tuples():
+    from fourier_feature_nets_amd.utils import learning_rate_at
+
+    class Opt:
+        param_groups = [{"lr": 0.0}, {"lr": 0.0}]
+
+    ffn.exponential_lr_decay(Opt, 5e-4, 25000, 0.1, 25000)
+    assert Opt.param_groups[0]["lr"] == Opt.param_groups[1]["lr"] == orc.lr_decay(5e-4, 25000, 0.1, 25000)
+    assert learning_rate_at(5e-4, 0, 0.1, 25000) == 5e-4
+    res = ffn.RenderResult(torch.zeros(2, 3), torch.zeros(2), None)
+    assert res.numpy().depth is None and res.to(torch.float64).color.dtype == torch.float64
+    samples = ffn.RaySamples(torch.zeros(4, 2, 3), None, torch.zeros(4, 2), torch.arange(4))
+    assert samples.subset([1, 2]).rays.tolist() == [1, 2]
+    assert samples.subset(slice(0, 3)).positions.shape == (3, 2, 3)
+    assert samples.numpy().view_directions is None
+
+
+# --------------------------------------------------------------------------------- data parallel
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _dp_worker(rank, world, port, out):
+    """Each rank: its contiguous shard of the valid-filtered global batch, gradients scaled
+    by the GLOBAL ray count, one all-reduce(sum) of the flat gradient buffer, clip AFTER the
+    reduction, identical Adam step everywhere -- exactly TrainEngine's recipe."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    torch.set_num_threads(1)
+    b = orc.positional_b_values(3.0, 12, 3)
+    dims = [(32, 2 * b.shape[1]), (32, 32), (4, 32)]
+    ws = [torch.randn(o, k) / math.sqrt(k) for o, k in dims]
+    bs = [torch.randn(o) * 0.1 for o, _ in dims]
+    R, S = 37, 8                                       # ragged on purpose: 19 + 18 rays
+    pos = torch.rand(R, S, 3) * 2 - 1
+    t = torch.sort(torch.rand(R, S) * 3 + 1, -1)[0]
+    gt_c, gt_a = torch.rand(R, 3), (torch.rand(R) > 0.5).float()
+
+    class Group:                                       # TrainEngine.shard only needs these
+        pass
+
+    engine = ffn.TrainEngine.__new__(ffn.TrainEngine)
+    engine.group = dist.group.WORLD
+    mine = engine.shard(torch.arange(R))
+    model = orc.OracleFourierMLP(torch.ones(b.shape[1]), b, ws, bs)
+    logits = model(pos[mine].reshape(-1, 3)).reshape(len(mine), S, 4)
+    color, alpha, _ = orc.render(logits, t[mine], False)
+    # sums scaled by the global counts, as ffn_mse_loss is called under DP
+    loss = ((gt_c[mine] - color).square().sum() / (3 * R)
+            + 0.1 * (gt_a[mine] - alpha).square().sum() / R)
+    loss.backward()
+    flat = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    dist.all_reduce(flat)
+    total = torch.tensor([float(loss)])
+    dist.all_reduce(total)
+    grads = []
+    offset = 0
+    for p in model.parameters():
+        grads.append(flat[offset:offset + p.numel()].view_as(p).clone())
+        offset += p.numel()
+    orc.clip_gradients(grads)
+    with torch.no_grad():
+        for p, g in zip(model.parameters(), grads):
+            orc.adam_update(p, g, torch.zeros_like(p), torch.zeros_like(p), 1, 5e-4)
+    if rank == 0:
+        torch.save({"loss": float(total), "count": len(mine),
+                    "params": [p.detach().clone() for p in model.parameters()],
+                    "inputs": (ws, bs, b, pos, t, gt_c, gt_a)}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_step_equals_single_process_step(tmp_path):
+    out = str(tmp_path / "dp.pt")
+    mp.spawn(_dp_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    blob = torch.load(out)
+    ws, bs, b, pos, t, gt_c, gt_a = blob["inputs"]
+    assert blob["count"] == 19
+    model = orc.OracleFourierMLP(torch.ones(b.shape[1]), b, ws, bs)
+    trainer = orc.OracleTrainer(model, 5e-4)
+    loss = trainer.step(pos, None, t, gt_c, gt_a, 5e-4)
+    assert abs(loss - blob["loss"]) < 1e-6
+    for mine, theirs in zip(model.parameters(), blob["params"]):
+        np.testing.assert_allclose(mine.detach().numpy(), theirs.numpy(), rtol=1e-5, atol=1e-7)
