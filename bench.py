@@ -233,6 +233,16 @@ def main():
                             "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
                             "flop_per_sample": flops[key]}
         dominant = max(kernels, key=lambda k: kernels[k]["avg_ms"])
+        # HBM bytes per launch from the PMC passes committed under profiles/ (same workload)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+        symbol = {"fwd": "ffn::mlp_forward_kernel<1>", "dgrad": "ffn::mlp_backward_data_kernel",
+                  "wgrad": "ffn::wgrad_unit_kernel", "wgrad_heads": "ffn::wgrad_kernel"}
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                tdata = json.load(f)
+            if tdata["config"] == {"rays": args.rays, "samples": args.samples}:
+                traffic = tdata["kernels"].get(symbol[dominant], {}).get("hbm_bytes")
         names = {"fwd": "mlp_forward_kernel<train>", "dgrad": "mlp_backward_data_kernel",
                  "wgrad": "wgrad_unit_kernel", "wgrad_heads": "wgrad_kernel(heads)"}
         result = {
@@ -257,7 +267,8 @@ def main():
             "roofline": {"bound": "mfma", "kernel": names[dominant],
                          "achieved": kernels[dominant]["achieved"],
                          "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": kernels[dominant]["frac"], "traffic": None},
+                         "frac": kernels[dominant]["frac"], "traffic": traffic,
+                         "algorithmic_flop_per_launch": kernels[dominant]["flop_per_sample"] * n_samples},
             "kernels": {names[k]: v for k, v in kernels.items()},
         }
         if not args.no_cpu_baseline and world == 1:

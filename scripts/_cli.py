@@ -1,0 +1,118 @@
+"""Shared pieces of the driver scripts: table-driven argument parsers with the reference
+drivers' flag names and defaults, log writing, and a small PNG-dumping training hook."""
+
+import argparse
+import json
+import os
+
+import numpy as np
+
+# (flag, kwargs) -- names/defaults follow train_nerf.py:14-71, train_tiny_nerf.py:14-66 and
+# orbit_video.py:16-40 of the reference so that command lines carry over unchanged
+TRAIN_COMMON = [
+    ("data_path", dict(help="dataset NPZ")),
+    ("results_dir", dict(help="output directory")),
+    ("--mode", dict(choices=["rgba", "rgb", "dilate"], default="rgba")),
+    ("--opacity-model", dict(help="checkpoint of a coarse opacity model (focus sampling)")),
+    ("--num-samples", dict(type=int, default=128)),
+    ("--batch-size", dict(type=int, default=1024)),
+    ("--learning-rate", dict(type=float, default=5e-4)),
+    ("--num-channels", dict(type=int, default=256)),
+    ("--num-steps", dict(type=int, default=50000)),
+    ("--report-interval", dict(type=int, default=1000)),
+    ("--image-interval", dict(type=int, default=2000)),
+    ("--crop-steps", dict(type=int, default=1000)),
+    ("--seed", dict(type=int, default=20080524)),
+    ("--decay-rate", dict(type=float, default=0.1)),
+    ("--weight-decay", dict(type=float, default=0)),
+    ("--make-video", dict(action="store_true")),
+    ("--color-space", dict(choices=["YCrCb", "RGB"], default="RGB")),
+    ("--num-frames", dict(type=int, default=200)),
+    ("--device", dict(default="cuda")),
+    ("--anneal-start", dict(type=float, default=0.2)),
+    ("--num-anneal-steps", dict(type=int, default=2000)),
+]
+NERF_ONLY = [
+    ("--resolution", dict(type=int, default=400)),
+    ("--num-cameras", dict(type=int, default=100)),
+    ("--num-layers", dict(type=int, default=8)),
+    ("--pos-freq", dict(type=int, default=10)),
+    ("--pos-max-log-scale", dict(type=float, default=9)),
+    ("--view-freq", dict(type=int, default=4)),
+    ("--view-max-log-scale", dict(type=float, default=3)),
+    ("--omit-inputs", dict(action="store_true")),
+    ("--decay-steps", dict(type=int, default=250000)),
+]
+TINY_ONLY = [
+    ("--embedding-size", dict(type=int, default=256)),
+    ("--pos-max-log-scale", dict(type=float, default=5.5)),
+    ("--gauss-sigma", dict(type=float, default=6.05)),
+    ("--make-activations", dict(action="store_true")),
+    ("--decay-steps", dict(type=int, default=25000)),
+]
+ORBIT = [
+    ("model_path", dict(help="trained checkpoint")),
+    ("resolution", dict(type=int, help="frame size in pixels")),
+    ("output_dir", dict(help="directory for the PNG frames")),
+    ("--opacity-model", dict(help="optional checkpoint of an opacity model")),
+    ("--distance", dict(type=float, default=4)),
+    ("--fov-y-degrees", dict(type=float, default=40)),
+    ("--num-frames", dict(type=int, default=200)),
+    ("--up-dir", dict(default="y+", choices=["x+", "x-", "y+", "y-", "z+", "z-"])),
+    ("--forward-dir", dict(default="z-", choices=["x+", "x-", "y+", "y-", "z+", "z-"])),
+    ("--num-samples", dict(type=int, default=128)),
+    ("--alpha-thresh", dict(type=float, default=0.3)),
+    ("--batch_size", dict(type=int, default=4096)),
+    ("--device", dict(default="cuda")),
+]
+
+
+def build_parser(title, *tables, positional_extra=()):
+    parser = argparse.ArgumentParser(title, formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    flat = []
+    for table in tables:
+        flat.extend(table)
+    pos = [row for row in flat if not row[0].startswith("-")]
+    opt = [row for row in flat if row[0].startswith("-")]
+    for name, kw in pos[:1] + list(positional_extra) + pos[1:] + opt:
+        parser.add_argument(name, **kw)
+    return parser
+
+
+def axis_vector(code):
+    vec = np.zeros(3, np.float32)
+    vec["xyz".index(code[0])] = 1 if code[1] == "+" else -1
+    return vec
+
+
+def write_log(path, args, log):
+    """log.txt in the reference layout: the args as JSON, a blank line, a tab-separated
+    header and one row per report."""
+    with open(path, "w") as f:
+        json.dump(vars(args), f)
+        f.write("\n\n")
+        f.write("\t".join(["step", "timestamp", "psnr_train", "psnr_val"]) + "\n")
+        for e in log:
+            f.write("\t".join(str(v) for v in (e.step, e.timestamp, e.train_psnr, e.val_psnr)) + "\n")
+
+
+def save_png(path, image):
+    from PIL import Image
+    Image.fromarray(image).save(path)
+
+
+class FrameDump:
+    """Training hook with the visualizer call signature (step, render_image, render_act):
+    every `interval` steps renders camera 0 of a dataset and writes a PNG."""
+
+    def __init__(self, results_dir, dataset, interval, raycaster, batch_size):
+        self.dir = os.path.join(results_dir, dataset.label)
+        os.makedirs(self.dir, exist_ok=True)
+        self.dataset, self.interval = dataset, interval
+        self.raycaster, self.batch_size = raycaster, batch_size
+
+    def visualize(self, step, render_image, render_act):
+        if step % self.interval:
+            return
+        image = self.raycaster.render_image(self.dataset.sampler, 0, max(self.batch_size, 4096))
+        save_png(os.path.join(self.dir, "{:06}.png".format(step)), image)

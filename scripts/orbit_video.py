@@ -1,0 +1,48 @@
+"""Renders an orbit of PNG frames from a trained checkpoint on the MI355X path (counterpart of
+the reference's orbit_video.py).  With several GPUs (torch.distributed.run) frame f goes to
+rank f mod world: replicas only, no collective."""
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import fourier_feature_nets_amd as ffn  # noqa: E402
+from scripts import _cli  # noqa: E402
+
+
+def main():
+    args = _cli.build_parser("Orbit video (MI355X)", _cli.ORBIT).parse_args()
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    device = args.device
+    if world > 1 and device == "cuda":
+        device = "cuda:%d" % int(os.environ.get("LOCAL_RANK", "0"))
+    cameras = ffn.orbit(_cli.axis_vector(args.up_dir), _cli.axis_vector(args.forward_dir),
+                        args.num_frames, args.fov_y_degrees,
+                        ffn.Resolution(args.resolution, args.resolution), args.distance)
+    bounds = np.diag([2, 2, 2, 1]).astype(np.float32)
+    model = ffn.load_model(args.model_path)
+    if model is None:
+        return 1
+    model = model.to(device)
+    opacity = model
+    if args.opacity_model:
+        opacity = ffn.load_model(args.opacity_model).to(device)
+    mine = list(range(rank, args.num_frames, world))
+    caster = ffn.Raycaster(model)
+    sampler = ffn.RaySampler(bounds, [cameras[f] for f in mine], args.num_samples, False, opacity,
+                             args.batch_size, device=device)
+    os.makedirs(args.output_dir, exist_ok=True)
+    bar = ffn.ETABar("Rendering", max=len(mine))
+    for local, frame in enumerate(mine):
+        bar.next()
+        image = caster.render_image(sampler, local, args.batch_size)
+        _cli.save_png(os.path.join(args.output_dir, "frame_{:05d}.png".format(frame)), image)
+    bar.finish()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

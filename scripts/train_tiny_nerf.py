@@ -1,0 +1,59 @@
+"""Trains a position-only radiance field on the MI355X path (counterpart of the reference's
+train_tiny_nerf.py: same flags, same outputs `tiny_nerf.pt` + `log.txt`)."""
+
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import fourier_feature_nets_amd as ffn  # noqa: E402
+from scripts import _cli  # noqa: E402
+
+
+def main():
+    kinds = ("nerf_model", dict(choices=["mlp", "basic", "positional", "gaussian"]))
+    args = _cli.build_parser("Tiny NeRF training (MI355X)", _cli.TRAIN_COMMON, _cli.TINY_ONLY,
+                             positional_extra=[kinds]).parse_args()
+    torch.manual_seed(args.seed)
+    width = dict(num_channels=args.num_channels)
+    makers = {
+        "mlp": lambda: ffn.MLP(3, 4, **width),
+        "basic": lambda: ffn.BasicFourierMLP(3, 4, **width),
+        "positional": lambda: ffn.PositionalFourierMLP(3, 4, max_log_scale=args.pos_max_log_scale,
+                                                       embedding_size=args.embedding_size, **width),
+        "gaussian": lambda: ffn.GaussianFourierMLP(3, 4, sigma=args.gauss_sigma,
+                                                   embedding_size=args.embedding_size, **width),
+    }
+    model = makers[args.nerf_model]()
+    opacity = None
+    if args.opacity_model:
+        opacity = ffn.load_model(args.opacity_model)
+        if opacity is None:
+            return 1
+        opacity = opacity.to(args.device)
+    with_alpha = args.mode == "rgba"
+    train = ffn.ImageDataset.load(args.data_path, "train", args.num_samples, with_alpha, True,
+                                  opacity, args.batch_size, args.color_space,
+                                  anneal_start=args.anneal_start,
+                                  num_anneal_steps=args.num_anneal_steps, device=args.device)
+    val = ffn.ImageDataset.load(args.data_path, "val", args.num_samples, with_alpha, False,
+                                opacity, args.batch_size, args.color_space, device=args.device)
+    if train is None or val is None:
+        return 1
+    if args.mode == "dilate":
+        train.mode = ffn.RayDataset.Mode.Dilate
+    os.makedirs(args.results_dir, exist_ok=True)
+    caster = ffn.Raycaster(model.to(args.device))
+    hooks = [_cli.FrameDump(args.results_dir, ds, args.image_interval, caster, args.batch_size)
+             for ds in (train, val)]
+    log = caster.fit(train, val, args.batch_size, args.learning_rate, args.num_steps,
+                     args.crop_steps, args.report_interval, args.decay_rate, args.decay_steps,
+                     args.weight_decay, hooks)
+    model.save(os.path.join(args.results_dir, "tiny_nerf.pt"))
+    _cli.write_log(os.path.join(args.results_dir, "log.txt"), args, log)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

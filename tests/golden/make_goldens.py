@@ -460,6 +460,26 @@ def main():
     for key, val_t in init_state.items():
         out["fit_init/" + key] = val_t
     np.savez(os.path.join(OUT, "training.npz"), **out)
+
+    # ---------------- CLI defaults of the three target scripts (a16) ----------
+    import importlib.util
+    import json
+    cli = {}
+    for script, argv in [("train_nerf", ["d.npz", "out"]),
+                         ("train_tiny_nerf", ["d.npz", "positional", "out"]),
+                         ("orbit_video", ["m.pt", "400", "out"])]:
+        spec = importlib.util.spec_from_file_location("ref_" + script,
+                                                      os.path.join(REFERENCE, script + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        old = sys.argv
+        sys.argv = [script + ".py"] + argv
+        try:
+            cli[script] = vars(mod._parse_args())
+        finally:
+            sys.argv = old
+    with open(os.path.join(OUT, "cli_defaults.json"), "w") as f:
+        json.dump(cli, f, indent=1, sort_keys=True)
     print("goldens written to", OUT)
 
 

@@ -230,3 +230,23 @@ def test_data_parallel_step_equals_single_process_step(tmp_path):
     assert abs(loss - blob["loss"]) < 1e-6
     for mine, theirs in zip(model.parameters(), blob["params"]):
         np.testing.assert_allclose(mine.detach().numpy(), theirs.numpy(), rtol=1e-5, atol=1e-7)
+
+
+def test_driver_scripts_keep_the_reference_flags_and_defaults():
+    """argparse surface of scripts/{train_nerf,train_tiny_nerf,orbit_video}.py == the
+    reference scripts' (captured into tests/golden/cli_defaults.json by make_goldens.py)."""
+    import json
+    from scripts import _cli
+    with open(os.path.join(os.path.dirname(__file__), "golden", "cli_defaults.json")) as f:
+        ref = json.load(f)
+    kinds = ("nerf_model", dict(choices=["mlp", "basic", "positional", "gaussian"]))
+    mine = {
+        "train_nerf": vars(_cli.build_parser("t", _cli.TRAIN_COMMON, _cli.NERF_ONLY)
+                           .parse_args(["d.npz", "out"])),
+        "train_tiny_nerf": vars(_cli.build_parser("t", _cli.TRAIN_COMMON, _cli.TINY_ONLY,
+                                                  positional_extra=[kinds])
+                                .parse_args(["d.npz", "positional", "out"])),
+        "orbit_video": vars(_cli.build_parser("t", _cli.ORBIT).parse_args(["m.pt", "400", "out"])),
+    }
+    for name in ref:
+        assert mine[name] == ref[name], name
