@@ -78,34 +78,51 @@ __device__ __forceinline__ EncRegs load_enc(const ffn_encoding& e, const float* 
     return r;
 }
 
-__device__ __forceinline__ void feature_pair(const EncRegs& enc, int k, float s0, float s1,
-                                             float s2, float x0, float x1, float x2, float& even,
-                                             float& odd) {
-    const int kk = k < enc.Fi ? k : enc.Fi - 1;
-    float ang = s0 * enc.b[kk];
-    ang = __builtin_fmaf(s1, enc.b[enc.Fi + kk], ang);
-    ang = __builtin_fmaf(s2, enc.b[2 * enc.Fi + kk], ang);
-    float sn, cs;
-    fast_sincos(ang, sn, cs);
-    const float amp = enc.a[kk];
-    const int c = 2 * (k - enc.F);  // offset past the trig block
-    const float raw_even = (enc.raw && c == 0) ? x0 : ((enc.raw && c == 2) ? x2 : 0.0f);
-    const float raw_odd = (enc.raw && c == 0) ? x1 : 0.0f;
-    const bool trig = k < enc.F;
-    even = trig ? amp * cs : raw_even;
-    odd = trig ? amp * sn : raw_odd;
+// Table entries of the two frequencies (4g+2h, 4g+2h+1) a lane needs for K group g, fetched
+// from LDS one loop trip ahead of their use so that no ds_read latency sits in the MFMA stream.
+struct FeatTab {
+    float b0[2], b1[2], b2[2], amp[2];
+};
+
+__device__ __forceinline__ FeatTab feature_tables(const EncRegs& enc, int g, int h) {
+    FeatTab t;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int k = 4 * g + 2 * h + j;
+        const int kk = k < enc.Fi ? k : enc.Fi - 1;
+        t.b0[j] = enc.b[kk];
+        t.b1[j] = enc.b[enc.Fi + kk];
+        t.b2[j] = enc.b[2 * enc.Fi + kk];
+        t.amp[j] = enc.a[kk];
+    }
+    return t;
+}
+
+__device__ __forceinline__ f32x4 feature_compute(const EncRegs& enc, const FeatTab& t, int g, int h,
+                                                 float x0, float x1, float x2) {
+    f32x4 v;
+    const float s0 = enc.scale * x0, s1 = enc.scale * x1, s2 = enc.scale * x2;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int k = 4 * g + 2 * h + j;
+        float ang = s0 * t.b0[j];
+        ang = __builtin_fmaf(s1, t.b1[j], ang);
+        ang = __builtin_fmaf(s2, t.b2[j], ang);
+        float sn, cs;
+        fast_sincos(ang, sn, cs);
+        const int c = 2 * (k - enc.F);  // offset past the trig block
+        const float raw_even = (enc.raw && c == 0) ? x0 : ((enc.raw && c == 2) ? x2 : 0.0f);
+        const float raw_odd = (enc.raw && c == 0) ? x1 : 0.0f;
+        const bool trig = k < enc.F;
+        v[2 * j] = trig ? t.amp[j] * cs : raw_even;
+        v[2 * j + 1] = trig ? t.amp[j] * sn : raw_odd;
+    }
+    return v;
 }
 
 __device__ __forceinline__ f32x4 feature_group(const EncRegs& enc, int g, int h, float x0,
                                                float x1, float x2) {
-    f32x4 v;
-    const int k0 = 4 * g + 2 * h;
-    const float s0 = enc.scale * x0, s1 = enc.scale * x1, s2 = enc.scale * x2;
-    float e0, o0, e1, o1;
-    feature_pair(enc, k0, s0, s1, s2, x0, x1, x2, e0, o0);
-    feature_pair(enc, k0 + 1, s0, s1, s2, x0, x1, x2, e1, o1);
-    v[0] = e0; v[1] = o0; v[2] = e1; v[3] = o1;
-    return v;
+    return feature_compute(enc, feature_tables(enc, g, h), g, h, x0, x1, x2);
 }
 
 // ---------------------------------------------------------------------------------- MFMA block
@@ -118,22 +135,33 @@ __device__ __forceinline__ void mma_group(f32x16 (&acc)[OT], const f32x4 (&a)[OT
             acc[o] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[o][p], x[p], acc[o], 0, 0, 0);
 }
 
-// Ask the scheduler for "1 MFMA, then `valu` VALU ops" OT*4 times: spreads the feature
-// arithmetic of the next K group through this group's MFMA issue slots.
+// Scheduling pipelines (sched_group_barrier masks: 0x002 VALU, 0x008 MFMA, 0x020 VMEM read,
+// 0x100 DS read).  A single in-order wave per SIMD has nothing to hide an s_waitcnt behind, so
+// every load (weights from L2, operands / tables from LDS) must ISSUE at the head of a
+// half-trip and be consumed a full MFMA block later; left alone, the scheduler sinks the
+// ds_reads next to their users and each lgkmcnt wait stalls the matrix pipe ~100 cycles.
 template <int OT>
-__device__ __forceinline__ void interleave_hint(int valu_per_mfma) {
+__device__ __forceinline__ void pipeline_plain() {
+    __builtin_amdgcn_sched_group_barrier(0x020, 2 * OT, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 8 * OT, 0);
+}
+template <int OT>
+__device__ __forceinline__ void pipeline_features() {
+    __builtin_amdgcn_sched_group_barrier(0x020, 2 * OT, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
 #pragma unroll
-    for (int i = 0; i < OT * 4; ++i) {
+    for (int i = 0; i < OT * 8; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
     }
-    (void)valu_per_mfma;
 }
 
+// `wg` points at this lane's float4 of tile 0 of the wanted K group; tiles are 64 float4 apart
 template <int OT>
-__device__ __forceinline__ void load_weights(f32x4 (&a)[OT], const f32x4* __restrict__ wp, int g) {
+__device__ __forceinline__ void load_group(f32x4 (&a)[OT], const f32x4* __restrict__ wg) {
 #pragma unroll
-    for (int o = 0; o < OT; ++o) a[o] = wp[(int64_t)(g * OT + o) * 64];
+    for (int o = 0; o < OT; ++o) a[o] = wg[o * 64];
 }
 
 struct WaveCtx {
@@ -165,22 +193,40 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
                                          const float* __restrict__ packed_w,
                                          f32x4 (&pre)[16],               // groups 0,1 weights, prefetched
                                          float* __restrict__ slab_out) { // fwd: saved; bwd: dZ
+    // accumulators start at the bias (forward) or zero (backward): the 32 LDS reads go out
+    // back to back here instead of sitting, each with its own wait, in the epilogue
     f32x16 acc[OT];
+    if (MODE == kBackward) {
 #pragma unroll
-    for (int o = 0; o < OT; ++o)
+        for (int o = 0; o < OT; ++o)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[o][r] = 0.0f;
+            for (int r = 0; r < 16; ++r) acc[o][r] = 0.0f;
+    } else {
+        const float* bv = w.bias_lds + L.b_off + 4 * w.h;
+#pragma unroll
+        for (int o = 0; o < OT; ++o)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(bv + 32 * o + 8 * q);
+#pragma unroll
+                for (int p = 0; p < 4; ++p) acc[o][4 * q + p] = b4[p];
+            }
+    }
 
     const f32x4* wp = reinterpret_cast<const f32x4*>(packed_w + L.w_off) + w.lane;
     const int GA = L.act_groups;   // multiple of 4
     const int GX = L.aux_groups;   // multiple of 4; encoding features (fwd) or d_logits (bwd)
     const int G = GA + GX;
+    constexpr int kGroupStride = OT * 64;   // float4 between consecutive K groups
     // weights are double buffered two K groups deep: while pair A feeds the MFMAs, pair B
-    // (two groups = 4096 MFMA cycles ahead) is in flight from L2
+    // (two groups = 4096 MFMA cycles ahead) is in flight from L2.  `wnext` walks the packed
+    // panel group by group: one 64-bit add per pair of groups, constant offsets otherwise.
     f32x4 wa0[OT], wa1[OT], wb0[OT], wb1[OT];
     f32x4 x0, x1, x2, x3;
 #pragma unroll
     for (int o = 0; o < OT; ++o) { wa0[o] = pre[o]; wa1[o] = pre[8 + o]; }
+    const f32x4* wnext = wp + 2 * kGroupStride;          // group 2
+    const f32x4* wlast = wp + (int64_t)(G - 2) * kGroupStride;
     // backward: the ReLU sign mask of the layer being differentiated, fetched a layer ahead
     uint4 mbits = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
     if (MODE == kBackward && L.mask_slot >= 0)
@@ -190,25 +236,27 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
     if (GA > 0) {
         f32x4* save = nullptr;
         if (MODE != kInfer && L.save_in_slot >= 0) save = slab_block(ch, slab_out, L.save_in_slot, w);
-        x0 = w.act[w.lane];
-        x1 = w.act[64 + w.lane];
+        const f32x4* xa = w.act + w.lane;
+        x0 = xa[0];
+        x1 = xa[64];
         for (int g = 0; g < GA; g += 4) {
-            load_weights<OT>(wb0, wp, g + 2);
-            load_weights<OT>(wb1, wp, g + 3);
-            x2 = w.act[(g + 2) * 64 + w.lane];
-            x3 = w.act[(g + 3) * 64 + w.lane];
+            load_group<OT>(wb0, wnext);
+            load_group<OT>(wb1, wnext + kGroupStride);
+            x2 = xa[128];
+            x3 = xa[192];
             if (MODE != kInfer && save != nullptr) {
                 save[saved_index(2 * g + w.h, w.s)] = x0;
                 save[saved_index(2 * (g + 1) + w.h, w.s)] = x1;
             }
             mma_group<OT>(acc, wa0, x0);
             mma_group<OT>(acc, wa1, x1);
-            const int gn = g + 4 < G ? g + 4 : g;     // redundant reload on the very last trip
-            load_weights<OT>(wa0, wp, gn);
-            load_weights<OT>(wa1, wp, gn + 1);
+            wnext = wnext + 2 * kGroupStride < wlast ? wnext + 2 * kGroupStride : wlast;  // clamp at the end
+            load_group<OT>(wa0, wnext);
+            load_group<OT>(wa1, wnext + kGroupStride);
+            xa += 256;
             if (g + 4 < GA) {
-                x0 = w.act[(g + 4) * 64 + w.lane];
-                x1 = w.act[(g + 5) * 64 + w.lane];
+                x0 = xa[0];
+                x1 = xa[64];
             }
             if (MODE != kInfer && save != nullptr) {
                 save[saved_index(2 * (g + 2) + w.h, w.s)] = x2;
@@ -216,6 +264,9 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
             }
             mma_group<OT>(acc, wb0, x2);
             mma_group<OT>(acc, wb1, x3);
+            wnext = wnext + 2 * kGroupStride < wlast ? wnext + 2 * kGroupStride : wlast;
+            pipeline_plain<OT>();
+            pipeline_plain<OT>();
         }
     }
 
@@ -240,22 +291,31 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
             const float p2 = L.enc_id == 0 ? w.x2 : w.v2;
             x0 = feature_group(enc, 0, w.h, p0, p1, p2);
             x1 = feature_group(enc, 1, w.h, p0, p1, p2);
+            FeatTab t2 = feature_tables(enc, 2, w.h);
+            FeatTab t3 = feature_tables(enc, 3, w.h);
             for (int e = 0; e < GX; e += 4) {
-                load_weights<OT>(wb0, wp, GA + e + 2);
-                load_weights<OT>(wb1, wp, GA + e + 3);
-                x2 = feature_group(enc, e + 2, w.h, p0, p1, p2);
-                x3 = feature_group(enc, e + 3, w.h, p0, p1, p2);
+                load_group<OT>(wb0, wnext);
+                load_group<OT>(wb1, wnext + kGroupStride);
+                const int en = e + 4 < GX ? e + 4 : e;
+                // tables for the groups after next come from LDS now, are used next trip
+                const FeatTab t0n = feature_tables(enc, en, w.h);
+                const FeatTab t1n = feature_tables(enc, en + 1, w.h);
+                x2 = feature_compute(enc, t2, e + 2, w.h, p0, p1, p2);
+                x3 = feature_compute(enc, t3, e + 3, w.h, p0, p1, p2);
                 mma_group<OT>(acc, wa0, x0);
                 mma_group<OT>(acc, wa1, x1);
-                interleave_hint<2 * OT>(3);
-                const int en = e + 4 < GX ? e + 4 : e;
-                load_weights<OT>(wa0, wp, GA + en);
-                load_weights<OT>(wa1, wp, GA + en + 1);
-                x0 = feature_group(enc, en, w.h, p0, p1, p2);
-                x1 = feature_group(enc, en + 1, w.h, p0, p1, p2);
+                wnext = wnext + 2 * kGroupStride < wlast ? wnext + 2 * kGroupStride : wlast;
+                load_group<OT>(wa0, wnext);
+                load_group<OT>(wa1, wnext + kGroupStride);
+                t2 = feature_tables(enc, en + 2, w.h);
+                t3 = feature_tables(enc, en + 3, w.h);
+                x0 = feature_compute(enc, t0n, en, w.h, p0, p1, p2);
+                x1 = feature_compute(enc, t1n, en + 1, w.h, p0, p1, p2);
                 mma_group<OT>(acc, wb0, x2);
                 mma_group<OT>(acc, wb1, x3);
-                interleave_hint<2 * OT>(3);
+                wnext = wnext + 2 * kGroupStride < wlast ? wnext + 2 * kGroupStride : wlast;
+                pipeline_features<OT>();
+                pipeline_features<OT>();
             }
         }
     }
@@ -273,7 +333,6 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
     }
 
     // ---- epilogue: bias / activation / mask, hand-off -------------------------------
-    const float* bv = w.bias_lds + L.b_off + 4 * w.h;
     f32x4* save_out = nullptr;
     if (MODE == kBackward && L.save_out_slot >= 0) save_out = slab_block(ch, slab_out, L.save_out_slot, w);
     unsigned sign_bits[4] = {0u, 0u, 0u, 0u};
@@ -293,12 +352,11 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
                 w.act[group * 64 + w.lane] = y;
                 if (save_out != nullptr) save_out[saved_index(2 * group + w.h, w.s)] = y;
             } else {
-                const f32x4 b4 = *reinterpret_cast<const f32x4*>(bv + 32 * o + 8 * q);
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
-                    float t = acc[o][4 * q + p] + b4[p];
+                    float t = acc[o][4 * q + p];
                     if (MODE == kTrainFwd) sign_bits[o >> 1] |= (t > 0.0f ? 1u : 0u) << (16 * (o & 1) + 4 * q + p);
-                    if (L.relu) t = t > 0.0f ? t : 0.0f;
+                    if (L.relu) t = __builtin_fmaxf(t, 0.0f);
                     y[p] = t;
                 }
                 if (L.dst == 0) {
