@@ -102,6 +102,22 @@ __device__ __forceinline__ f32x4 feature_compute(const EncRegs& enc, const FeatT
                                                  float x0, float x1, float x2) {
     f32x4 v;
     const float s0 = enc.scale * x0, s1 = enc.scale * x1, s2 = enc.scale * x2;
+    if (4 * g + 3 < enc.F) {
+        // wave-uniform fast path: every frequency of this K group is a real one, so the
+        // raw-input / padding selects drop out (f32 VALU work is paid in full next to
+        // f32 MFMA, every instruction counts)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float ang = s0 * t.b0[j];
+            ang = __builtin_fmaf(s1, t.b1[j], ang);
+            ang = __builtin_fmaf(s2, t.b2[j], ang);
+            float sn, cs;
+            fast_sincos(ang, sn, cs);
+            v[2 * j] = t.amp[j] * cs;
+            v[2 * j + 1] = t.amp[j] * sn;
+        }
+        return v;
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int k = 4 * g + 2 * h + j;

@@ -242,6 +242,11 @@ __device__ __forceinline__ void stage_slab(const f32x4* __restrict__ block_base,
     }
 }
 
+// LDS map of the unit kernel: [2 x (A image 32 KiB | B image 32 KiB)] [encoding tables]
+// [512 B of zeros: the row idle lanes of a narrow window read instead of branching/selecting]
+constexpr int kUnitZeroOffset = 2 * kUnitBufBytes + kEncTableBytes;
+constexpr int kUnitLdsBytes = kUnitZeroOffset + 512;
+
 template <bool ENC>
 __device__ __forceinline__ void unit_segment(const ffn_mlp_chain& ch, const ffn_wgrad_unit& unit,
                                              const ffn_wgrad_segment& seg, char* smem,
@@ -255,9 +260,8 @@ __device__ __forceinline__ void unit_segment(const ffn_mlp_chain& ch, const ffn_
     const int li = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int mp = wave >> 1, np = wave & 1;
-    const int m_valid = unit.m_quads - 32 * mp;   // quads of this wave's M panel (may be <= 0)
-    const int n_valid = unit.n_quads - 32 * np;
-    const bool a_ok = li < m_valid, b_ok = li < n_valid;
+    const bool a_ok = li < unit.m_quads - 32 * mp;   // this lane's quad exists in the M window
+    const bool b_ok = li < unit.n_quads - 32 * np;
     const f32x4* a_slab = reinterpret_cast<const f32x4*>(dz + ch.slot_offset[unit.m_slot] * num_blocks * 32) + unit.m_cq0 * 32;
     const int64_t a_stride = ch.slot_channels[unit.m_slot] * 8;
     const f32x4* b_slab = nullptr;
@@ -269,9 +273,51 @@ __device__ __forceinline__ void unit_segment(const ffn_mlp_chain& ch, const ffn_
         b_slab = reinterpret_cast<const f32x4*>(saved + ch.slot_offset[unit.n_slot] * num_blocks * 32) + unit.n_cq0 * 32;
         b_stride = ch.slot_channels[unit.n_slot] * 8;
     }
-    // feature generation: thread -> sample tid&31, quads (tid>>5) + 8j, j = 0..7
+    // feature generation: thread -> sample tid&31, quads (tid>>5) + 8j, j = 0..7, one
+    // frequency (cos, sin) per MFMA step: step u makes frequency 2*quad + (u&1) of j = u>>1
     const int f_s = tid & 31;
     const int f_q = tid >> 5;
+    struct Tab { float b0, b1, b2, amp; };
+    auto table_of = [&](int u) {
+        Tab t;
+        const int cq = f_q + 8 * (u >> 1);
+        const int k = 2 * (unit.n_cq0 + cq) + (u & 1);
+        const int kk = k < enc.Fi ? k : enc.Fi - 1;
+        t.b0 = enc.b[kk]; t.b1 = enc.b[enc.Fi + kk]; t.b2 = enc.b[2 * enc.Fi + kk]; t.amp = enc.a[kk];
+        return t;
+    };
+    auto feature_store = [&](char* buf, int u, const Tab& t, float x0, float x1, float x2) {
+        const int cq = f_q + 8 * (u >> 1);
+        const int k = 2 * (unit.n_cq0 + cq) + (u & 1);
+        const float s0 = enc.scale * x0, s1 = enc.scale * x1, s2 = enc.scale * x2;
+        float ang = s0 * t.b0;
+        ang = __builtin_fmaf(s1, t.b1, ang);
+        ang = __builtin_fmaf(s2, t.b2, ang);
+        float sn, cs;
+        fast_sincos(ang, sn, cs);
+        float2 v;
+        // wave-uniform: the highest frequency any lane of this wave touches in this step
+        const int k_top = 2 * (unit.n_cq0 + 2 * wave + 1 + 8 * (u >> 1)) + 1;
+        if (k_top < enc.F && 2 * wave + 1 + 8 * (u >> 1) < unit.n_quads) {
+            v.x = t.amp * cs;                      // all-trig fast path: no selects
+            v.y = t.amp * sn;
+            *reinterpret_cast<float2*>(buf + 32 * 1024 + (cq * 32 + (f_s ^ (cq & 15))) * 16 + (u & 1) * 8) = v;
+            return;
+        }
+        const int c = 2 * (k - enc.F);
+        const float raw_even = (enc.raw && c == 0) ? x0 : ((enc.raw && c == 2) ? x2 : 0.0f);
+        const float raw_odd = (enc.raw && c == 0) ? x1 : 0.0f;
+        const bool trig = k < enc.F;
+        v.x = trig ? t.amp * cs : raw_even;
+        v.y = trig ? t.amp * sn : raw_odd;
+        if (cq < unit.n_quads)
+            *reinterpret_cast<float2*>(buf + 32 * 1024 + (cq * 32 + (f_s ^ (cq & 15))) * 16 + (u & 1) * 8) = v;
+    };
+    auto load_xyz = [&](int64_t blk, float& x0, float& x1, float& x2) {
+        int64_t sample = blk * 32 + f_s;
+        sample = sample < n ? sample : n - 1;
+        x0 = xyz[sample * 3 + 0]; x1 = xyz[sample * 3 + 1]; x2 = xyz[sample * 3 + 2];
+    };
 
     f32x16 acc[4][4];
 #pragma unroll
@@ -282,35 +328,6 @@ __device__ __forceinline__ void unit_segment(const ffn_mlp_chain& ch, const ffn_
             for (int r = 0; r < 16; ++r) acc[p][q][r] = 0.0f;
     f32x4 bsum = zero4();
 
-    auto feature_store = [&](char* buf, int j, int half, float x0, float x1, float x2) {
-        const int cq = f_q + 8 * j;                 // quad inside the window
-        if (cq < unit.n_quads) {
-            const int k = 2 * (unit.n_cq0 + cq) + half;
-            const int kk = k < enc.Fi ? k : enc.Fi - 1;
-            const float s0 = enc.scale * x0, s1 = enc.scale * x1, s2 = enc.scale * x2;
-            float ang = s0 * enc.b[kk];
-            ang = __builtin_fmaf(s1, enc.b[enc.Fi + kk], ang);
-            ang = __builtin_fmaf(s2, enc.b[2 * enc.Fi + kk], ang);
-            float sn, cs;
-            fast_sincos(ang, sn, cs);
-            const float amp = enc.a[kk];
-            const int c = 2 * (k - enc.F);
-            const float raw_even = (enc.raw && c == 0) ? x0 : ((enc.raw && c == 2) ? x2 : 0.0f);
-            const float raw_odd = (enc.raw && c == 0) ? x1 : 0.0f;
-            const bool trig = k < enc.F;
-            float2 v;
-            v.x = trig ? amp * cs : raw_even;
-            v.y = trig ? amp * sn : raw_odd;
-            char* dst = buf + 32 * 1024 + (cq * 32 + (f_s ^ (cq & 15))) * 16 + half * 8;
-            *reinterpret_cast<float2*>(dst) = v;
-        }
-    };
-    auto load_xyz = [&](int64_t blk, float& x0, float& x1, float& x2) {
-        int64_t sample = blk * 32 + f_s;
-        sample = sample < n ? sample : n - 1;
-        x0 = xyz[sample * 3 + 0]; x1 = xyz[sample * 3 + 1]; x2 = xyz[sample * 3 + 2];
-    };
-
     // ---- prologue: stage the first block into buffer 0
     {
         char* buf = smem;
@@ -318,7 +335,7 @@ __device__ __forceinline__ void unit_segment(const ffn_mlp_chain& ch, const ffn_
         if (ENC) {
             float x0, x1, x2;
             load_xyz(seg.blk_begin, x0, x1, x2);
-            for (int u = 0; u < 16; ++u) feature_store(buf, u >> 1, u & 1, x0, x1, x2);
+            for (int u = 0; u < 16; ++u) feature_store(buf, u, table_of(u), x0, x1, x2);
         } else {
             stage_slab(b_slab + seg.blk_begin * b_stride, unit.n_quads, buf + 32 * 1024, tid, wave);
         }
@@ -326,6 +343,8 @@ __device__ __forceinline__ void unit_segment(const ffn_mlp_chain& ch, const ffn_
         __syncthreads();
     }
 
+    const int sw = li & 15;
+    const int zero_row = kUnitZeroOffset / 16;     // float4 index of the zero row
     for (int64_t blk = seg.blk_begin; blk < seg.blk_end; ++blk) {
         const int cur = (int)((blk - seg.blk_begin) & 1);
         char* buf = smem + cur * kUnitBufBytes;
@@ -337,27 +356,46 @@ __device__ __forceinline__ void unit_segment(const ffn_mlp_chain& ch, const ffn_
             if (ENC) load_xyz(blk + 1, x0, x1, x2);
             else stage_slab(b_slab + (blk + 1) * b_stride, unit.n_quads, nxt + 32 * 1024, tid, wave);
         }
-        const f32x4* la = reinterpret_cast<const f32x4*>(buf) + (32 * mp + (a_ok ? li : 0)) * 32;
-        const f32x4* lb = reinterpret_cast<const f32x4*>(buf + 32 * 1024) + (32 * np + (b_ok ? li : 0)) * 32;
-        const int sw = li & 15;
-        f32x4 a = la[hh ^ sw];
-        f32x4 b = lb[hh ^ sw];
+        // idle lanes of a narrow window read the zero row: no select in the MFMA stream.
+        // Operand reads are hand-issued (inline asm, so hipcc's waitcnt pass does not see
+        // them) right behind the step's MFMAs have started, and waited for by hand at the end
+        // of the step: a full ~1000 cycles of matrix work covers the LDS latency.
+        const unsigned lds0 = (unsigned)(size_t)smem;
+        const unsigned a_base = a_ok ? lds0 + cur * kUnitBufBytes + (32 * mp + li) * 512 : lds0 + kUnitZeroOffset;
+        const unsigned b_base = b_ok ? lds0 + cur * kUnitBufBytes + 32 * 1024 + (32 * np + li) * 512 : lds0 + kUnitZeroOffset;
+        f32x4 a, b, a_n, b_n;
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(a), "=&v"(b) : "v"(a_base + ((hh ^ sw) << 4)), "v"(b_base + ((hh ^ sw) << 4)) : "memory");
+        Tab tn = table_of(0);
 #pragma unroll 2
         for (int u = 0; u < 16; ++u) {
             const int un = u + 1 < 16 ? u + 1 : u;
-            const f32x4 a_n = la[(2 * un + hh) ^ sw];
-            const f32x4 b_n = lb[(2 * un + hh) ^ sw];
-            if (ENC && more) feature_store(nxt, u >> 1, u & 1, x0, x1, x2);
-            {   // idle quadrants (narrow windows) multiply zeros rather than branch
-                const f32x4 av = a_ok ? a : zero4();
-                const f32x4 bv = b_ok ? b : zero4();
-                bsum += av;
-#pragma unroll
-                for (int p = 0; p < 4; ++p)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        acc[p][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p], bv[q], acc[p][q], 0, 0, 0);
+            const unsigned off_n = (unsigned)(((2 * un + hh) ^ sw) << 4);
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3"
+                         : "=&v"(a_n), "=&v"(b_n) : "v"(a_base + off_n), "v"(b_base + off_n) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (ENC) {
+                const Tab t = tn;
+                tn = table_of(un);
+                if (more) feature_store(nxt, u, t, x0, x1, x2);
             }
+            bsum += a;
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    acc[p][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[p], b[q], acc[p][q], 0, 0, 0);
+            if (ENC) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
             a = a_n;
             b = b_n;
         }
@@ -386,6 +424,7 @@ wgrad_unit_kernel(const ffn_mlp_chain ch, const ffn_wgrad_unit* __restrict__ uni
                   const float* __restrict__ views, int64_t n, float* __restrict__ partials) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     stage_encoding_tables(ch.enc, reinterpret_cast<float*>(smem + 2 * kUnitBufBytes), threadIdx.x, 256);
+    if (threadIdx.x < 128) reinterpret_cast<float*>(smem + kUnitZeroOffset)[threadIdx.x] = 0.0f;
     __syncthreads();
     const int64_t num_blocks = (n + 31) / 32;
     const int seg_lo = seg_start[blockIdx.x], seg_hi = seg_start[blockIdx.x + 1];
@@ -479,7 +518,7 @@ extern "C" int ffn_mlp_wgrad_units(const ffn_mlp_chain* chain, const ffn_wgrad_u
                                    const float* positions, const float* views, int64_t n,
                                    float* partials, void* stream) {
     if (n <= 0 || num_groups <= 0) return fail_arg("ffn_mlp_wgrad_units: shape");
-    const size_t lds = 2 * kUnitBufBytes + kEncTableBytes;
+    const size_t lds = kUnitLdsBytes;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_unit_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(wgrad_unit_kernel, dim3(num_groups), dim3(256), lds, (hipStream_t)stream,

@@ -397,7 +397,10 @@ class MlpProgram:
         slot = 0
         reduce_jobs = []
         # ---- units: one workgroup-segment = 4 consecutive partial slots (one per quadrant)
-        raw, unit_starts = self._split([1] * len(self.wgrad_units), blocks, WGRAD_GROUPS)
+        # measured on MI355X: a block of an encoding unit (features regenerated in-loop, and
+        # f32 VALU work does not hide under f32 MFMA) costs ~26.3k cycles, a slab unit ~19.7k
+        unit_costs = [4 if u.n_kind == 1 else 3 for u in self.wgrad_units]
+        raw, unit_starts = self._split(unit_costs, blocks, WGRAD_GROUPS)
         unit_segments = []
         unit_slots = [[] for _ in self.wgrad_units]
         for (u, b0, b1) in raw:
