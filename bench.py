@@ -209,6 +209,20 @@ def main():
     elapsed = time.perf_counter() - t0
     timed_call.on = False
     engine.check_finite()
+
+    # ---- render leg: 400x400 frames of the first cameras (replicas only: frame f -> rank f%world)
+    caster = ffn.Raycaster(model)
+    frames = [f for f in range(8 * world) if f % world == rank]
+    for f in frames[:1]:
+        caster.render_image(dataset.sampler, f, 32768)
+    torch.cuda.synchronize()
+    barrier()
+    r0 = time.perf_counter()
+    for f in frames:
+        caster.render_image(dataset.sampler, f, 32768)
+    torch.cuda.synchronize()
+    barrier()
+    render_s = time.perf_counter() - r0
     if world > 1:
         import torch.distributed as dist
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -270,6 +284,10 @@ def main():
                          "frac": kernels[dominant]["frac"], "traffic": traffic,
                          "algorithmic_flop_per_launch": kernels[dominant]["flop_per_sample"] * n_samples},
             "kernels": {names[k]: v for k, v in kernels.items()},
+            "render": {"metric": "frames/sec %dx%d render" % (args.size, args.size),
+                       "value": 8 * world / render_s, "frames": 8 * world,
+                       "samples_per_ray": args.samples, "includes": "sampling, fused MLP, "
+                       "composite, u8 assembly and the D2H copy of each frame"},
         }
         if not args.no_cpu_baseline and world == 1:
             state = {k: v.detach() for k, v in model.state_dict().items()}

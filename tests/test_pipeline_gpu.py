@@ -227,3 +227,65 @@ def test_render_image_and_checkpoint_roundtrip(golden, tmp_path):
         x = torch.rand(100, 3, device=dev()) * 2 - 1
         assert torch.equal(loaded(x), model(x))
     assert ffn.load_model(str(tmp_path / "missing.pt")) is None
+
+
+def test_nerf_train_step_matches_oracle(golden):
+    """Full NeRF topology (skip concat, sigma head, linear bottleneck, view branch) through
+    TrainEngine: one optimisation step == the oracle's step from the same weights/samples."""
+    import fourier_feature_nets_amd as ffn
+    from tests.test_kernels_gpu import _load_nerf
+    g = golden("models")
+    model, params = _load_nerf(g, "nerf_small", [2], False)
+    ref = orc.OracleNeRF(params, [2], False)
+    train = _quiet(ffn.ImageDataset.load, SCENE, "train", 16, True, True)
+    train.sampler.noise_source = "host"
+    engine = ffn.TrainEngine(model)
+    batch = torch.arange(0, len(train), 3, device=dev())
+    torch.manual_seed(5)
+    loss = float(engine.train_step(train, batch, None, 5e-4))
+    engine.check_finite()
+    # the oracle on the same rays / noise
+    rays = train.ray_ids(batch).cpu()
+    torch.manual_seed(5)
+    noise = torch.rand((len(rays), 16))
+    state = {"starts": train.sampler.starts.cpu(), "directions": train.sampler.directions.cpu(),
+             "near_far": train.sampler.near_far.cpu()}
+    pos, view, t, _ = orc.sample(state, rays.numpy(), None, 16, noise=noise)
+    gc, ga = orc.ground_truth(train.colors.cpu(), train.alphas.cpu(), rays)
+    trainer = orc.OracleTrainer(ref, 5e-4)
+    ref_loss = trainer.step(pos, view, t, gc, ga, 5e-4)
+    assert abs(loss - ref_loss) < 2e-6 * max(1.0, abs(ref_loss))
+    for key, par in model.named_parameters():
+        if par.requires_grad:
+            np.testing.assert_allclose(par.detach().cpu().numpy(), ref.p[key].detach().numpy(),
+                                       rtol=0, atol=3e-5, err_msg=key)
+
+
+def test_focus_sampling_with_fused_opacity_model(golden):
+    """orbit_video's configuration: the radiance field itself is the opacity model of the
+    sampler (orbit_video.py:66-78); CDFs and merged samples against the oracle."""
+    import fourier_feature_nets_amd as ffn
+    g, r = golden("training"), golden("raygen")
+    model = _small_model(g)
+    ref = _oracle_model(g)
+    cams = [ffn.CameraInfo.create("c%d" % i, ffn.Resolution(int(r["width"]), int(r["height"])), k, e)
+            for i, (k, e) in enumerate(zip(r["intrinsics"], r["extrinsics"]))]
+    S = 16
+    smp = _quiet(ffn.RaySampler, r["bounds_eye2"], cams, S, False, model, 100, 0.5, 0)
+    n_focus = S - S // 2
+    near, far = smp.near_far.cpu()
+    t_probe = orc.linspace_rows(near, far, n_focus)
+    pos = smp.starts.cpu().unsqueeze(1) + t_probe.unsqueeze(2) * smp.directions.cpu().unsqueeze(1)
+    valid = smp.valid.cpu().numpy() == 1
+    with torch.no_grad():
+        sigma = torch.nn.functional.softplus(ref(pos[valid].reshape(-1, 3))[:, -1]).reshape(-1, n_focus)
+    cdf = orc.determine_cdf(t_probe[valid], sigma)
+    np.testing.assert_allclose(smp.cdfs.cpu().numpy()[valid], cdf.numpy(), atol=1e-4)
+    idx = np.nonzero(valid)[0][::7]
+    out = smp.sample(idx.tolist(), None)
+    u = torch.linspace(0., 1., n_focus).unsqueeze(0).repeat(len(idx), 1)
+    state = {"starts": smp.starts.cpu(), "directions": smp.directions.cpu(), "near_far": smp.near_far.cpu()}
+    _, _, t_ref, _ = orc.sample(state, idx, None, S, cdfs=smp.cdfs.cpu(), focus_u=u)
+    assert np.array_equal(out.t_values.cpu().numpy(), t_ref.numpy())
+    image = ffn.Raycaster(model).render_image(smp, 1, 64)
+    assert image.shape == (int(r["height"]), int(r["width"]), 3)
