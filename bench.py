@@ -39,6 +39,9 @@ def parse_args():
     ap.add_argument("--cameras", type=int, default=100)
     ap.add_argument("--size", type=int, default=400)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--model", default="tiny", choices=["tiny", "nerf"],
+                    help="tiny = BASELINE configs[1] (the metric's config); nerf = configs[2]-shaped "
+                         "full NeRF (8x256, skip, view branch), use with --samples 128")
     return ap.parse_args()
 
 
@@ -142,7 +145,10 @@ def main():
     from fourier_feature_nets_amd import ops
 
     torch.manual_seed(20080524)
-    model = ffn.PositionalFourierMLP(3, 4, 5.5).to(device)
+    if args.model == "nerf":
+        model = ffn.NeRF(8, 256, 9, 10, 3, 4, [4], True).to(device)
+    else:
+        model = ffn.PositionalFourierMLP(3, 4, 5.5).to(device)
     intr, poses = synthetic_rig(args.cameras, args.size)
     cams = [ffn.CameraInfo.create("train%03d" % i, ffn.Resolution(args.size, args.size), intr, p)
             for i, p in enumerate(poses)]
@@ -230,11 +236,10 @@ def main():
         elapsed = float(tmax.item())
 
     if rank == 0:
-        layer_dims = [(w.shape[0], w.shape[1]) for w in
-                      [l.weight for l in model.layers]]
-        fwd_flops = 2 * sum(o * k for o, k in layer_dims)
-        dgrad_flops = 2 * sum(o * k for o, k in layer_dims[1:])
-        head_flops = 2 * layer_dims[-1][0] * layer_dims[-1][1]
+        specs = prog.layers
+        fwd_flops = 2 * sum(sp.out * sp.ld for sp in specs)
+        dgrad_flops = 2 * sum(sp.out * sp.act_in for sp in specs)      # no dgrad into encodings
+        head_flops = 2 * sum(sp.out * sp.ld for sp in specs if sp.to_logits is not None)
         flops = {"fwd": fwd_flops, "dgrad": dgrad_flops, "wgrad": fwd_flops - head_flops,
                  "wgrad_heads": head_flops}
         kernels = {}
@@ -255,7 +260,7 @@ def main():
         if os.path.exists(tpath):
             with open(tpath) as f:
                 tdata = json.load(f)
-            if tdata["config"] == {"rays": args.rays, "samples": args.samples}:
+            if tdata["config"] == {"rays": args.rays, "samples": args.samples} and args.model == "tiny":
                 traffic = tdata["kernels"].get(symbol[dominant], {}).get("hbm_bytes")
         names = {"fwd": "mlp_forward_kernel<train>", "dgrad": "mlp_backward_data_kernel",
                  "wgrad": "wgrad_unit_kernel", "wgrad_heads": "wgrad_kernel(heads)"}
@@ -272,10 +277,12 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "antinous_400-shaped tiny NeRF train step: %d cams x %dx%d, "
-                                   "PositionalFourierMLP(3,4,5.5) 256ch, %d samples/ray, "
-                                   "%d rays/GPU/step, exact-f32 MFMA"
-                                   % (args.cameras, args.size, args.size, args.samples, args.rays),
+            "config": {"workload": "antinous_400-shaped %s train step: %d cams x %dx%d, %s, "
+                                   "%d samples/ray, %d rays/GPU/step, exact-f32 MFMA"
+                                   % ("tiny NeRF" if args.model == "tiny" else "full NeRF",
+                                      args.cameras, args.size, args.size,
+                                      "PositionalFourierMLP(3,4,5.5) 256ch" if args.model == "tiny"
+                                      else "NeRF(8,256,9,10,3,4,[4],True)", args.samples, args.rays),
                        "rays_per_gpu": args.rays, "samples_per_ray": args.samples,
                        "parallelism": "dp%d" % world, "final_loss": float(loss)},
             "roofline": {"bound": "mfma", "kernel": names[dominant],
@@ -289,7 +296,7 @@ def main():
                        "samples_per_ray": args.samples, "includes": "sampling, fused MLP, "
                        "composite, u8 assembly and the D2H copy of each frame"},
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.model == "tiny":
             state = {k: v.detach() for k, v in model.state_dict().items()}
             result["cpu_baseline"] = cpu_baseline(args, state, None)
         else:

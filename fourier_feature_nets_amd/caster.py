@@ -51,8 +51,14 @@ class _Composite(torch.autograd.Function):
 class TrainEngine:
     """One optimisation step as a straight line of kernel launches over flat buffers."""
 
-    def __init__(self, model: nn.Module, weight_decay: float = 0.0, process_group=None):
+    def __init__(self, model: nn.Module, weight_decay: float = 0.0, process_group=None,
+                 max_samples_per_launch: int = 1 << 23):
+        """``max_samples_per_launch`` bounds the activation slabs kept for backward (3.2 KB per
+        sample for the tiny NeRF, 19.5 KB for the full one): larger batches run as several
+        forward/backward launches whose gradients are summed before the (single) all-reduce
+        and optimiser step -- numerically the same step."""
         self.model = model
+        self.max_samples = int(max_samples_per_launch)
         params = model._dense_params()
         device = params[0].device
         if device.type != "cuda":
@@ -117,18 +123,28 @@ class TrainEngine:
         alphas = dataset._gt_alphas()
         aw = float(dataset.alpha_weight) if alphas is not None else 0.0
         prog = self.model.program()
-        if count > 0:
-            t, pos, views = self._samples(sampler, rays, step)
+        sums = torch.zeros((2,), dtype=torch.float32, device=self.device)
+        per_launch = max(1, self.max_samples // sampler.num_samples)
+        if count == 0:
+            self.grads.zero_()
+        for lo in range(0, count, per_launch):
+            chunk = rays[lo:lo + per_launch]
+            first = lo == 0
+            t, pos, views = self._samples(sampler, chunk, step)
             saved = self._saved_buffer(prog, pos.shape[0])
             logits = prog.forward(pos, views, saved)
             color, alpha, _ = ops.composite_fwd(logits, t, False, self.nan_flag)
-            sums, d_color, d_alpha = ops.mse_loss(color, alpha, dataset.colors, alphas, rays,
+            part, d_color, d_alpha = ops.mse_loss(color, alpha, dataset.colors, alphas, chunk,
                                                   1.0 / (3 * global_count), aw / global_count)
             d_logits = ops.composite_bwd(logits, t, d_color, d_alpha)
-            prog.backward(d_logits.view(-1, 4), pos, views, saved, self.grads)
-        else:
-            sums = torch.zeros((2,), dtype=torch.float32, device=self.device)
-            self.grads.zero_()
+            if first:
+                prog.backward(d_logits.view(-1, 4), pos, views, saved, self.grads)
+            else:
+                if getattr(self, "_grads_part", None) is None:
+                    self._grads_part = torch.empty_like(self.grads)
+                prog.backward(d_logits.view(-1, 4), pos, views, saved, self._grads_part)
+                self.grads.add_(self._grads_part)
+            sums = sums + part
         if self.group is not None:
             import torch.distributed as dist
             dist.all_reduce(self.grads, group=self.group)      # RCCL over xGMI, one flat buffer

@@ -289,3 +289,26 @@ def test_focus_sampling_with_fused_opacity_model(golden):
     assert np.array_equal(out.t_values.cpu().numpy(), t_ref.numpy())
     image = ffn.Raycaster(model).render_image(smp, 1, 64)
     assert image.shape == (int(r["height"]), int(r["width"]), 3)
+
+
+def test_micro_batched_step_equals_single_launch(golden):
+    """Bounding the activation memory (several forward/backward launches per step, summed
+    gradients) gives the same optimisation step."""
+    import fourier_feature_nets_amd as ffn
+    g = golden("training")
+    results = []
+    for limit in (1 << 23, 16 * 40):          # one launch vs chunks of 40 rays
+        model = _small_model(g)
+        train = _quiet(ffn.ImageDataset.load, SCENE, "train", 16, True, True)
+        train.sampler.noise_source = "host"
+        engine = ffn.TrainEngine(model, max_samples_per_launch=limit)
+        torch.manual_seed(3)
+        # same noise stream in both runs: draw the whole block once and slice it
+        rays = train.ray_ids(torch.arange(0, len(train), 2, device=dev()))
+        noise = torch.rand((rays.numel(), 16)).to(dev())
+        chunks = iter(noise.split(40) if limit < (1 << 23) else [noise])
+        train.sampler._noise = lambda rows, count, it=chunks: next(it)
+        loss = float(engine.train_step(train, torch.arange(0, len(train), 2, device=dev()), None, 5e-4))
+        results.append((loss, engine.flat.clone()))
+    assert abs(results[0][0] - results[1][0]) < 1e-6
+    np.testing.assert_allclose(results[0][1].cpu().numpy(), results[1][1].cpu().numpy(), rtol=0, atol=2e-6)
