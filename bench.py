@@ -240,10 +240,14 @@ def main():
         fwd_flops = 2 * sum(sp.out * sp.ld for sp in specs)
         dgrad_flops = 2 * sum(sp.out * sp.act_in for sp in specs)      # no dgrad into encodings
         head_flops = 2 * sum(sp.out * sp.ld for sp in specs if sp.to_logits is not None)
-        flops = {"fwd": fwd_flops, "dgrad": dgrad_flops, "wgrad": fwd_flops - head_flops,
-                 "wgrad_heads": head_flops}
+        enc_heads = any(sp.to_logits is not None and sp.enc_id is not None for sp in specs)
+        flops = {"fwd": fwd_flops, "dgrad": dgrad_flops,
+                 "wgrad": fwd_flops - (head_flops if enc_heads else 0),
+                 "wgrad_heads": head_flops if enc_heads else 0}
         kernels = {}
         for key, pairs in timers.items():
+            if not pairs:
+                continue
             ms = [a.elapsed_time(b) for a, b in pairs]
             avg = sum(ms) / max(len(ms), 1)
             achieved = flops[key] * n_samples / (avg * 1e-3) / 1e12 if avg > 0 else 0.0
@@ -263,7 +267,7 @@ def main():
             if tdata["config"] == {"rays": args.rays, "samples": args.samples} and args.model == "tiny":
                 traffic = tdata["kernels"].get(symbol[dominant], {}).get("hbm_bytes")
         names = {"fwd": "mlp_forward_kernel<train>", "dgrad": "mlp_backward_data_kernel",
-                 "wgrad": "wgrad_unit_kernel", "wgrad_heads": "wgrad_kernel(heads)"}
+                 "wgrad": "wgrad_unit_kernel", "wgrad_heads": "wgrad_kernel"}
         result = {
             "metric": "rays/sec (train)",
             "value": global_batch * args.steps / elapsed,

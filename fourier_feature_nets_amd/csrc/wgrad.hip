@@ -416,12 +416,87 @@ __device__ __forceinline__ void unit_segment(const ffn_mlp_chain& ch, const ffn_
     }
 }
 
+// Logits-head rows inside the LDS-staged kernel: dW_head[j][k] = sum_s dl[s][j] * X[k][s] for
+// the <= 4 head outputs j.  X (<= 256 channels) is staged like any slab; wave w owns channel
+// half (w & 1) and sample half (w >> 1) of every block: 8 steps x 4 MFMAs -- the kernel is
+// HBM-bound (32 KiB per ~2k cycles per CU), which is the point: no scattered global reads.
+__device__ __forceinline__ void head_segment(const ffn_mlp_chain& ch, const ffn_wgrad_unit& unit,
+                                             const ffn_wgrad_segment& seg, char* smem,
+                                             const float* __restrict__ saved,
+                                             const float* __restrict__ d_logits, int64_t n,
+                                             int64_t num_blocks, float* __restrict__ partials) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int hh = lane >> 5;
+    const int li = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = wave & 1, sh = wave >> 1;
+    const int lg_col = unit.m_slot, lg_n = unit.m_cq0;      // head units reuse the M fields
+    const bool x_ok = li < unit.n_quads - 32 * half;
+    const bool col_ok = li < lg_n;
+    const int col = col_ok ? lg_col + li : 0;
+    const f32x4* x_slab = reinterpret_cast<const f32x4*>(saved + ch.slot_offset[unit.n_slot] * num_blocks * 32) + unit.n_cq0 * 32;
+    const int64_t x_stride = ch.slot_channels[unit.n_slot] * 8;
+    f32x16 acc[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.0f;
+    float bsum = 0.0f;
+    // this wave's 8 sample pairs of a block; d_logits straight from HBM (512 B / block),
+    // fetched one block ahead so that their latency hides behind the previous block
+    auto load_dl = [&](int64_t blk, float (&dst)[8]) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int64_t sample = blk * 32 + 2 * (8 * sh + k) + hh;
+            const int64_t sc = sample < n ? sample : n - 1;
+            const float v = d_logits[sc * 4 + col];
+            dst[k] = (col_ok && sample < n) ? v : 0.0f;
+        }
+    };
+    float dl[8], dl_next[8];
+    load_dl(seg.blk_begin, dl);
+    stage_slab(x_slab + seg.blk_begin * x_stride, unit.n_quads, smem, tid, wave);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int sw = li & 15;
+    const f32x4* all = reinterpret_cast<const f32x4*>(smem);
+    for (int64_t blk = seg.blk_begin; blk < seg.blk_end; ++blk) {
+        const int cur = (int)((blk - seg.blk_begin) & 1);
+        char* buf = smem + cur * kUnitBufBytes;
+        const int64_t nb = blk + 1 < seg.blk_end ? blk + 1 : blk;
+        if (blk + 1 < seg.blk_end)
+            stage_slab(x_slab + (blk + 1) * x_stride, unit.n_quads, smem + (cur ^ 1) * kUnitBufBytes, tid, wave);
+        load_dl(nb, dl_next);
+        const f32x4* lx = x_ok ? reinterpret_cast<const f32x4*>(buf) + (32 * half + li) * 32 : all + kUnitZeroOffset / 16;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const f32x4 a = lx[(2 * (8 * sh + k) + hh) ^ sw];
+            bsum += dl[k];
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[p], dl[k], acc[p], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dl[k] = dl_next[k];
+    }
+    float* out = partials + (int64_t)(seg.slot + wave) * kPartialFloats;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[(p * 16 + r) * 64 + lane] = acc[p][r];
+    out[16 * 16 * 64 + lane] = bsum;
+}
+
 __global__ void __launch_bounds__(256, 1)
 wgrad_unit_kernel(const ffn_mlp_chain ch, const ffn_wgrad_unit* __restrict__ units,
                   const ffn_wgrad_segment* __restrict__ segments,
                   const int32_t* __restrict__ seg_start, const float* __restrict__ saved,
-                  const float* __restrict__ dz, const float* __restrict__ positions,
-                  const float* __restrict__ views, int64_t n, float* __restrict__ partials) {
+                  const float* __restrict__ dz, const float* __restrict__ d_logits,
+                  const float* __restrict__ positions, const float* __restrict__ views, int64_t n,
+                  float* __restrict__ partials) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     stage_encoding_tables(ch.enc, reinterpret_cast<float*>(smem + 2 * kUnitBufBytes), threadIdx.x, 256);
     if (threadIdx.x < 128) reinterpret_cast<float*>(smem + kUnitZeroOffset)[threadIdx.x] = 0.0f;
@@ -432,7 +507,9 @@ wgrad_unit_kernel(const ffn_mlp_chain ch, const ffn_wgrad_unit* __restrict__ uni
         const ffn_wgrad_segment seg = segments[si];
         if (seg.blk_end <= seg.blk_begin) continue;
         const ffn_wgrad_unit unit = units[seg.job];
-        if (unit.n_kind == 1) {
+        if (unit.kind == 1) {
+            head_segment(ch, unit, seg, smem, saved, d_logits, n, num_blocks, partials);
+        } else if (unit.n_kind == 1) {
             const float* xyz = unit.n_slot == 1 ? views : positions;
             unit_segment<true>(ch, unit, seg, smem, saved, dz, xyz, n, num_blocks, partials);
         } else {
@@ -515,14 +592,15 @@ extern "C" int ffn_mlp_wgrad(const ffn_mlp_chain* chain, const ffn_wgrad_job* jo
 extern "C" int ffn_mlp_wgrad_units(const ffn_mlp_chain* chain, const ffn_wgrad_unit* units,
                                    const ffn_wgrad_segment* segments, const int32_t* seg_start,
                                    int num_groups, const float* saved, const float* dz,
-                                   const float* positions, const float* views, int64_t n,
-                                   float* partials, void* stream) {
+                                   const float* d_logits, const float* positions,
+                                   const float* views, int64_t n, float* partials, void* stream) {
     if (n <= 0 || num_groups <= 0) return fail_arg("ffn_mlp_wgrad_units: shape");
     const size_t lds = kUnitLdsBytes;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_unit_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(wgrad_unit_kernel, dim3(num_groups), dim3(256), lds, (hipStream_t)stream,
-                       *chain, units, segments, seg_start, saved, dz, positions, views, n, partials);
+                       *chain, units, segments, seg_start, saved, dz, d_logits, positions, views, n,
+                       partials);
     return check_launch("ffn_mlp_wgrad_units");
 }
 

@@ -60,7 +60,7 @@ class FfnWgradJob(ctypes.Structure):
 class FfnWgradUnit(ctypes.Structure):
     _fields_ = [("m_slot", ctypes.c_int32), ("m_cq0", ctypes.c_int32), ("m_quads", ctypes.c_int32),
                 ("n_kind", ctypes.c_int32), ("n_slot", ctypes.c_int32), ("n_cq0", ctypes.c_int32),
-                ("n_quads", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("n_quads", ctypes.c_int32), ("kind", ctypes.c_int32)]
 
 
 class FfnWgradSegment(ctypes.Structure):
@@ -357,7 +357,15 @@ class MlpProgram:
                                                    first=(wi == 0)))
             else:
                 col, cnt = spec.to_logits
+                slab_windows = [wd for wd in windows if wd[0] == 0]
+                for wi, (nk, ns, q0, nq, kb) in enumerate(slab_windows):
+                    # logits-head rows over a slab window: one LDS-staged head unit
+                    self.wgrad_units.append(FfnWgradUnit(col, cnt, 0, 0, ns, q0, nq, 1))
+                    self.unit_meta.append(dict(layer=i, head=True, n_quad0=q0, n_quads=nq,
+                                               k_base=kb, first=(wi == 0), lg_n=cnt))
                 for wi, (nk, ns, q0, nq, kb) in enumerate(windows):
+                    if nk == 0:
+                        continue
                     for p0 in range(0, nq, 32):
                         self.wgrad_jobs.append(FfnWgradJob(1, 0, 0, 0, nk, ns, q0 + p0,
                                                            min(32, nq - p0), col, cnt, 0, 0))
@@ -399,7 +407,8 @@ class MlpProgram:
         # ---- units: one workgroup-segment = 4 consecutive partial slots (one per quadrant)
         # measured on MI355X: a block of an encoding unit (features regenerated in-loop, and
         # f32 VALU work does not hide under f32 MFMA) costs ~26.3k cycles, a slab unit ~19.7k
-        unit_costs = [4 if u.n_kind == 1 else 3 for u in self.wgrad_units]
+        # a head unit is HBM-bound (32 KiB per block): ~3k cycles
+        unit_costs = [9 if u.kind == 1 else (32 if u.n_kind == 1 else 24) for u in self.wgrad_units]
         raw, unit_starts = self._split(unit_costs, blocks, WGRAD_GROUPS)
         unit_segments = []
         unit_slots = [[] for _ in self.wgrad_units]
@@ -411,6 +420,17 @@ class MlpProgram:
             spec = self.layers[meta["layer"]]
             sl = unit_slots[u]
             assert sl == list(range(sl[0], sl[-1] + 4, 4))
+            if meta.get("head"):
+                for half in range(2):           # channel halves; both sample halves summed
+                    if meta["n_quads"] - 32 * half <= 0:
+                        continue
+                    reduce_jobs.append(FfnReduceJob(
+                        1, sl[0] + half, sl[-1] + 4, 0, spec.out, meta["n_quad0"] + 32 * half,
+                        min(32, meta["n_quads"] - 32 * half), meta["k_base"], spec.ld,
+                        int(meta["first"] and half == 0), meta["lg_n"], 2,
+                        self.grad_w_off[meta["layer"]], self.grad_b_off[meta["layer"]],
+                        self.col_maps[meta["layer"]].data_ptr()))
+                continue
             for mp in range(2):
                 for np_ in range(2):
                     if meta["m_quads"] - 32 * mp <= 0 or meta["n_quads"] - 32 * np_ <= 0:
@@ -511,8 +531,8 @@ class MlpProgram:
             _lib.call("ffn_mlp_wgrad_units", ctypes.byref(self.fwd),
                       _dev(self.wgrad_units_dev, torch.uint8), _dev(ws.unit_segments, torch.uint8),
                       _dev(ws.unit_seg_start, torch.int32), c_i(WGRAD_GROUPS), _dev(saved),
-                      _dev(ws.dz), _dev(positions), _dev(views), c_i64(n), _dev(ws.partials),
-                      _stream())
+                      _dev(ws.dz), _dev(d_logits), _dev(positions), _dev(views), c_i64(n),
+                      _dev(ws.partials), _stream())
         if self.wgrad_jobs:
             _lib.call("ffn_mlp_wgrad", ctypes.byref(self.fwd),
                       _dev(self.wgrad_jobs_dev, torch.uint8), _dev(ws.segments, torch.uint8),

@@ -289,21 +289,22 @@ int ffn_mlp_wgrad(const ffn_mlp_chain* chain, const ffn_wgrad_job* jobs,
  * seg_start[g] .. seg_start[g+1] (segment.job indexes `units`), its four waves own the four
  * 128x128 quadrants and write partial slots segment.slot + {0,1,2,3}. */
 typedef struct ffn_wgrad_unit {
-    int32_t m_slot;    /* dZ slab                                                      */
-    int32_t m_cq0;     /* first channel quad of the output window inside the slab      */
+    int32_t m_slot;    /* dZ slab                        (head unit: first d_logits column) */
+    int32_t m_cq0;     /* first channel quad of the output window (head unit: #columns)    */
     int32_t m_quads;   /* valid quads (<= 64, multiple of 8)                           */
     int32_t n_kind;    /* input window: 0 = saved activation slab, 1 = encoding        */
     int32_t n_slot;    /* slab index, or encoding id                                   */
     int32_t n_cq0;     /* first channel quad / internal quad of the window             */
     int32_t n_quads;   /* valid quads (<= 64, multiple of 8 for slabs)                 */
-    int32_t reserved;
+    int32_t kind;      /* 0 = dW block; 1 = logits-head rows: waves own (channel half,
+                          sample half), partial slots segment.slot + 2*sample_half + half */
 } ffn_wgrad_unit;
 
 int ffn_mlp_wgrad_units(const ffn_mlp_chain* chain, const ffn_wgrad_unit* units,
                         const ffn_wgrad_segment* segments, const int32_t* seg_start,
                         int num_groups, const float* saved, const float* dz,
-                        const float* positions, const float* views, int64_t n,
-                        float* partials, void* stream);
+                        const float* d_logits, const float* positions, const float* views,
+                        int64_t n, float* partials, void* stream);
 
 /* Fixed-order reduction of the partials of each job into the flat natural-layout
  * gradient buffer (nn.Linear weight (out,in) row-major, then bias). */
