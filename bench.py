@@ -39,6 +39,7 @@ def parse_args():
     ap.add_argument("--cameras", type=int, default=100)
     ap.add_argument("--size", type=int, default=400)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-render", action="store_true", help="skip the frames/sec leg")
     ap.add_argument("--model", default="tiny", choices=["tiny", "nerf"],
                     help="tiny = BASELINE configs[1] (the metric's config); nerf = configs[2]-shaped "
                          "full NeRF (8x256, skip, view branch), use with --samples 128")
@@ -218,7 +219,7 @@ def main():
 
     # ---- render leg: 400x400 frames of the first cameras (replicas only: frame f -> rank f%world)
     caster = ffn.Raycaster(model)
-    frames = [f for f in range(8 * world) if f % world == rank]
+    frames = [] if args.no_render else [f for f in range(8 * world) if f % world == rank]
     for f in frames[:1]:
         caster.render_image(dataset.sampler, f, 32768)
     torch.cuda.synchronize()
@@ -295,7 +296,8 @@ def main():
                          "frac": kernels[dominant]["frac"], "traffic": traffic,
                          "algorithmic_flop_per_launch": kernels[dominant]["flop_per_sample"] * n_samples},
             "kernels": {names[k]: v for k, v in kernels.items()},
-            "render": {"metric": "frames/sec %dx%d render" % (args.size, args.size),
+            "render": None if args.no_render else {
+                       "metric": "frames/sec %dx%d render" % (args.size, args.size),
                        "value": 8 * world / render_s, "frames": 8 * world,
                        "samples_per_ray": args.samples, "includes": "sampling, fused MLP, "
                        "composite, u8 assembly and the D2H copy of each frame"},

@@ -20,11 +20,13 @@ class _FusedChainFunction(torch.autograd.Function):
     """logits = chain(positions[, views]); backward = dgrad + wgrad + reduce kernels."""
 
     @staticmethod
-    def forward(ctx, module, positions, views, *params):
+    def forward(ctx, module, grad_mode, positions, views, *params):
         prog = module.program()
         positions = positions.contiguous()
         views = None if views is None else views.contiguous()
-        track = any(ctx.needs_input_grad[3:])
+        # grad mode is sampled by the caller: inside Function.forward it is always off, and
+        # needs_input_grad stays true for parameters even under torch.no_grad()
+        track = grad_mode and any(ctx.needs_input_grad[4:])
         saved = None
         if track:
             saved = torch.empty((prog.saved_floats(positions.shape[0]),), dtype=torch.float32,
@@ -48,7 +50,7 @@ class _FusedChainFunction(torch.autograd.Function):
             outs.append(grads[w0:w0 + spec.out * spec.ld].view(spec.out, spec.ld))
             b0 = prog.grad_b_off[i]
             outs.append(grads[b0:b0 + spec.out])
-        return (None, None, None) + tuple(outs)
+        return (None, None, None, None) + tuple(outs)
 
 
 class _FusedModel(nn.Module):
@@ -163,7 +165,8 @@ class FourierFeatureMLP(_FusedModel):
             raise NotImplementedError("keep_activations is a lecture visualisation hook; it is "
                                       "outside the HIP hot path")
         self.activations.clear()
-        out = _FusedChainFunction.apply(self, inputs, None, *self._dense_params())
+        out = _FusedChainFunction.apply(self, torch.is_grad_enabled(), inputs, None,
+                                        *self._dense_params())
         return out if self.num_outputs == 4 else out[:, :self.num_outputs]
 
     def save(self, path: str):
@@ -299,7 +302,8 @@ class NeRF(_FusedModel):
 
     def forward(self, position: torch.Tensor, view: torch.Tensor) -> torch.Tensor:
         """(N,3) positions and (N,3) unit view directions -> (N,4) raw [r,g,b,sigma]."""
-        return _FusedChainFunction.apply(self, position, view, *self._dense_params())
+        return _FusedChainFunction.apply(self, torch.is_grad_enabled(), position, view,
+                                         *self._dense_params())
 
     def save(self, path: str):
         """Checkpoint in the reference format: state dict + "type" + "params"."""

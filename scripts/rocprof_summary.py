@@ -19,7 +19,7 @@ def main(db_path, out_path):
                            "from top_kernels order by total_duration desc"))
     with open(out_path, "w", newline="") as f:
         w = csv.writer(f)
-        w.writerow(["kernel", "calls", "total_ns", "avg_ns", "percent"])
+        w.writerow(["kernel", "calls", "total_us", "avg_us", "percent"])
         for name, calls, total, avg, pct in rows:
             w.writerow([short(name), calls, int(total), int(avg), round(pct, 3)])
     print("wrote", out_path, len(rows), "kernels")
