@@ -171,13 +171,13 @@ def main():
     n_samples = args.rays * args.samples
 
     # per-kernel timing with events on the launch stream
-    timers = {"fwd": [], "dgrad": [], "wgrad": [], "wgrad_heads": []}
+    timers = {"fwd": [], "dgrad": [], "wgrad": []}
     from fourier_feature_nets_amd import _lib as lib_mod
     orig_call = lib_mod.call
 
     def timed_call(name, *a):
         key = {"ffn_mlp_forward": "fwd", "ffn_mlp_backward_data": "dgrad",
-               "ffn_mlp_wgrad_units": "wgrad", "ffn_mlp_wgrad": "wgrad_heads"}.get(name)
+               "ffn_mlp_wgrad_units": "wgrad"}.get(name)
         if key is None or not timed_call.on:
             return orig_call(name, *a)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -240,11 +240,7 @@ def main():
         specs = prog.layers
         fwd_flops = 2 * sum(sp.out * sp.ld for sp in specs)
         dgrad_flops = 2 * sum(sp.out * sp.act_in for sp in specs)      # no dgrad into encodings
-        head_flops = 2 * sum(sp.out * sp.ld for sp in specs if sp.to_logits is not None)
-        enc_heads = any(sp.to_logits is not None and sp.enc_id is not None for sp in specs)
-        flops = {"fwd": fwd_flops, "dgrad": dgrad_flops,
-                 "wgrad": fwd_flops - (head_flops if enc_heads else 0),
-                 "wgrad_heads": head_flops if enc_heads else 0}
+        flops = {"fwd": fwd_flops, "dgrad": dgrad_flops, "wgrad": fwd_flops}
         kernels = {}
         for key, pairs in timers.items():
             if not pairs:
@@ -261,14 +257,14 @@ def main():
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
         symbol = {"fwd": "ffn::mlp_forward_kernel<1>", "dgrad": "ffn::mlp_backward_data_kernel",
-                  "wgrad": "ffn::wgrad_unit_kernel", "wgrad_heads": "ffn::wgrad_kernel"}
+                  "wgrad": "ffn::wgrad_unit_kernel"}
         if os.path.exists(tpath):
             with open(tpath) as f:
                 tdata = json.load(f)
             if tdata["config"] == {"rays": args.rays, "samples": args.samples} and args.model == "tiny":
                 traffic = tdata["kernels"].get(symbol[dominant], {}).get("hbm_bytes")
         names = {"fwd": "mlp_forward_kernel<train>", "dgrad": "mlp_backward_data_kernel",
-                 "wgrad": "wgrad_unit_kernel", "wgrad_heads": "wgrad_kernel"}
+                 "wgrad": "wgrad_unit_kernel"}
         result = {
             "metric": "rays/sec (train)",
             "value": global_batch * args.steps / elapsed,

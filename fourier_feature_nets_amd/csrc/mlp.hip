@@ -309,9 +309,15 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
             x1 = feature_group(enc, 1, w.h, p0, p1, p2);
             FeatTab t2 = feature_tables(enc, 2, w.h);
             FeatTab t3 = feature_tables(enc, 3, w.h);
+            f32x4* fsave = nullptr;
+            if (MODE == kTrainFwd && L.save_enc_slot >= 0) fsave = slab_block(ch, slab_out, L.save_enc_slot, w);
             for (int e = 0; e < GX; e += 4) {
                 load_group<OT>(wb0, wnext);
                 load_group<OT>(wb1, wnext + kGroupStride);
+                if (MODE == kTrainFwd && fsave != nullptr) {
+                    fsave[saved_index(2 * e + w.h, w.s)] = x0;
+                    fsave[saved_index(2 * (e + 1) + w.h, w.s)] = x1;
+                }
                 const int en = e + 4 < GX ? e + 4 : e;
                 // tables for the groups after next come from LDS now, are used next trip
                 const FeatTab t0n = feature_tables(enc, en, w.h);
@@ -325,6 +331,10 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
                 load_group<OT>(wa1, wnext + kGroupStride);
                 t2 = feature_tables(enc, en + 2, w.h);
                 t3 = feature_tables(enc, en + 3, w.h);
+                if (MODE == kTrainFwd && fsave != nullptr) {
+                    fsave[saved_index(2 * (e + 2) + w.h, w.s)] = x2;
+                    fsave[saved_index(2 * (e + 3) + w.h, w.s)] = x3;
+                }
                 x0 = feature_compute(enc, t0n, en, w.h, p0, p1, p2);
                 x1 = feature_compute(enc, t1n, en + 1, w.h, p0, p1, p2);
                 mma_group<OT>(acc, wb0, x2);

@@ -19,10 +19,12 @@ from ._lib import c_i, c_i64, c_p
 from .ops import _dev, _stream
 
 MAX_STEPS = 16
-WGRAD_WAVES = 1024          # one persistent wave per SIMD: 256 CUs x 4
 WGRAD_GROUPS = 256          # one persistent workgroup per CU for the LDS-staged units
-COST_FULL = 256             # MFMAs per 32-sample block of a 128x128 patch
-COST_HEAD = 64
+# relative cost of one 32-sample block of a unit, by the number of 128x128 quadrants it has
+# (measured on MI355X: ~19.7k cycles for a full unit, of which ~16.4k are MFMA), and of a head
+# unit (HBM-bound, 32 KiB per block)
+UNIT_COST = {4: 24, 2: 13, 1: 8}
+HEAD_COST = 9
 
 
 class FfnEncoding(ctypes.Structure):
@@ -37,7 +39,7 @@ class FfnStep(ctypes.Structure):
                 ("out_tiles", ctypes.c_int32), ("relu", ctypes.c_int32), ("dst", ctypes.c_int32),
                 ("out_col", ctypes.c_int32), ("out_n", ctypes.c_int32),
                 ("save_in_slot", ctypes.c_int32), ("save_out_slot", ctypes.c_int32),
-                ("mask_slot", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("mask_slot", ctypes.c_int32), ("save_enc_slot", ctypes.c_int32),
                 ("w_off", ctypes.c_int64), ("b_off", ctypes.c_int64)]
 
 
@@ -47,14 +49,6 @@ class FfnMlpChain(ctypes.Structure):
                 ("bias_floats", ctypes.c_int32), ("reserved", ctypes.c_int32),
                 ("slot_channels", ctypes.c_int32 * MAX_STEPS),
                 ("slot_offset", ctypes.c_int64 * MAX_STEPS)]
-
-
-class FfnWgradJob(ctypes.Structure):
-    _fields_ = [("kind", ctypes.c_int32), ("m_slot", ctypes.c_int32), ("m_cq0", ctypes.c_int32),
-                ("m_quads", ctypes.c_int32), ("n_kind", ctypes.c_int32),
-                ("n_slot", ctypes.c_int32), ("n_cq0", ctypes.c_int32), ("n_quads", ctypes.c_int32),
-                ("lg_col", ctypes.c_int32), ("lg_n", ctypes.c_int32),
-                ("reserved0", ctypes.c_int32), ("reserved1", ctypes.c_int32)]
 
 
 class FfnWgradUnit(ctypes.Structure):
@@ -149,13 +143,10 @@ class Workspace:
         dev = prog.device
         self.n = n
         blocks = (n + 31) // 32
-        slab = prog.saved_channels * 32 * blocks
-        self.dz = torch.empty((slab,), dtype=torch.float32, device=dev)
+        self.dz = torch.empty((prog.dz_channels * 32 * blocks,), dtype=torch.float32, device=dev)
         plan = prog._plan_wgrad(blocks)
         self.unit_segments = _struct_array_to_device(plan["unit_segments"], dev)
         self.unit_seg_start = torch.tensor(plan["unit_starts"], dtype=torch.int32, device=dev)
-        self.segments = _struct_array_to_device(plan["head_segments"], dev)
-        self.seg_start = torch.tensor(plan["head_starts"], dtype=torch.int32, device=dev)
         self.reduce_jobs = _struct_array_to_device(plan["reduce_jobs"], dev)
         self.num_reduce_jobs = len(plan["reduce_jobs"])
         self.partials = torch.empty((plan["slots"] * prog.partial_floats,), dtype=torch.float32,
@@ -225,7 +216,7 @@ class MlpProgram:
             L.enc_id = 0 if spec.enc_id is None else spec.enc_id
             L.out_tiles = _tiles(spec.out)
             L.relu = 1 if spec.relu else 0
-            L.save_in_slot = L.save_out_slot = L.mask_slot = -1
+            L.save_in_slot = L.save_out_slot = L.mask_slot = L.save_enc_slot = -1
             self.producer_of.append(last_producer if spec.act_in > 0 else -1)
             if spec.act_in > 0:
                 if last_producer < 0 or self.layers[last_producer].out != spec.act_in:
@@ -266,6 +257,21 @@ class MlpProgram:
         fwd.num_steps = len(self.layers)
         fwd.num_slots = len(self.slot_of)
         fwd.bias_floats = b_off
+        # encoding features are saved by the first step that generates them (slabs after the
+        # hidden-layer ones), so that every weight-gradient window is an ordinary slab window
+        self.dz_channels = slot_off
+        self.enc_slot: Dict[int, int] = {}
+        for i, spec in enumerate(self.layers):
+            if spec.enc_id is None or spec.enc_id in self.enc_slot:
+                continue
+            slot = fwd.num_slots + len(self.enc_slot)
+            if slot >= MAX_STEPS:
+                raise NotImplementedError("too many activation slabs")
+            self.enc_slot[spec.enc_id] = slot
+            fwd.step[i].save_enc_slot = slot
+            fwd.slot_channels[slot] = self.encodings[spec.enc_id].width
+            fwd.slot_offset[slot] = slot_off
+            slot_off += self.encodings[spec.enc_id].width
         if b_off > 4096:
             raise NotImplementedError("more than 4096 (padded) bias values")
         self.fwd = fwd
@@ -279,7 +285,7 @@ class MlpProgram:
         the network from the outputs to the first layer."""
         bwd = FfnMlpChain()
         self._fill_encodings(bwd)
-        for s in range(self.fwd.num_slots):
+        for s in range(MAX_STEPS):
             bwd.slot_channels[s] = self.fwd.slot_channels[s]
             bwd.slot_offset[s] = self.fwd.slot_offset[s]
         bwd.num_slots = self.fwd.num_slots
@@ -327,53 +333,41 @@ class MlpProgram:
         self.packed_bwd = torch.zeros((max(wt_off, 1),), dtype=torch.float32, device=self.device)
 
     def _build_wgrad_jobs(self):
-        """Weight-gradient work list: LDS-staged 256x256 units for the hidden layers, per-wave
-        head jobs (<=4 output rows) for the logits heads."""
+        """Weight-gradient work list: LDS-staged units of <=256 output x <=256 input channels
+        for the hidden layers, head units (<=4 output rows) for the logits heads.  Inputs are
+        slab windows: hidden activations or the saved encoding features."""
         self.wgrad_units: List[FfnWgradUnit] = []
         self.unit_meta = []     # per unit: reducer metadata
-        self.wgrad_jobs: List[FfnWgradJob] = []
-        self.job_meta = []
         for i, spec in enumerate(self.layers):
             enc = None if spec.enc_id is None else self.encodings[spec.enc_id]
-            windows = []        # (n_kind, n_slot, first quad, quads, k_base, first-of-layer)
+            windows = []        # (slot, first quad, quads, k_base)
             if spec.act_in > 0:
                 slot = self.slot_of[self.producer_of[i]]
                 quads = spec.act_in // 4
                 for q0 in range(0, quads, 64):
-                    windows.append((0, slot, q0, min(64, quads - q0), 0))
+                    windows.append((slot, q0, min(64, quads - q0), 0))
             if enc is not None:
                 quads = enc.width // 4
                 for q0 in range(0, quads, 64):
-                    windows.append((1, spec.enc_id, q0, min(64, quads - q0), spec.act_in))
+                    windows.append((self.enc_slot[spec.enc_id], q0, min(64, quads - q0),
+                                    spec.act_in))
             if spec.to_logits is None:
                 m_slot = self.slot_of[i]
                 out_quads = spec.out // 4
                 for m0 in range(0, out_quads, 64):
-                    for wi, (nk, ns, q0, nq, kb) in enumerate(windows):
+                    for wi, (ns, q0, nq, kb) in enumerate(windows):
                         self.wgrad_units.append(FfnWgradUnit(m_slot, m0, min(64, out_quads - m0),
-                                                             nk, ns, q0, nq, 0))
+                                                             0, ns, q0, nq, 0))
                         self.unit_meta.append(dict(layer=i, m0=m0, m_quads=min(64, out_quads - m0),
                                                    n_quad0=q0, n_quads=nq, k_base=kb,
                                                    first=(wi == 0)))
             else:
                 col, cnt = spec.to_logits
-                slab_windows = [wd for wd in windows if wd[0] == 0]
-                for wi, (nk, ns, q0, nq, kb) in enumerate(slab_windows):
-                    # logits-head rows over a slab window: one LDS-staged head unit
+                for wi, (ns, q0, nq, kb) in enumerate(windows):
                     self.wgrad_units.append(FfnWgradUnit(col, cnt, 0, 0, ns, q0, nq, 1))
                     self.unit_meta.append(dict(layer=i, head=True, n_quad0=q0, n_quads=nq,
                                                k_base=kb, first=(wi == 0), lg_n=cnt))
-                for wi, (nk, ns, q0, nq, kb) in enumerate(windows):
-                    if nk == 0:
-                        continue
-                    for p0 in range(0, nq, 32):
-                        self.wgrad_jobs.append(FfnWgradJob(1, 0, 0, 0, nk, ns, q0 + p0,
-                                                           min(32, nq - p0), col, cnt, 0, 0))
-                        self.job_meta.append(dict(layer=i, n_quad0=q0 + p0,
-                                                  n_quads=min(32, nq - p0), k_base=kb,
-                                                  has_bias=int(wi == 0 and p0 == 0), lg_n=cnt))
         self.wgrad_units_dev = _struct_array_to_device(self.wgrad_units, self.device)
-        self.wgrad_jobs_dev = _struct_array_to_device(self.wgrad_jobs, self.device)
 
     @staticmethod
     def _split(costs: List[int], blocks: int, workers: int):
@@ -400,15 +394,23 @@ class MlpProgram:
         assert job == len(costs), "work left unassigned"
         return segs, starts
 
+    @staticmethod
+    def _quadrants(m_quads: int, n_quads: int):
+        """(m halves, n halves) of a unit: the 128x128 quadrants that exist."""
+        return (2 if m_quads > 32 else 1), (2 if n_quads > 32 else 1)
+
     def _plan_wgrad(self, blocks: int):
-        """Segments for both weight-gradient kernels + the reducer's job table."""
+        """Segments of the weight-gradient kernel + the reducer's job table.  One
+        workgroup-segment = 4 consecutive partial slots (one per wave)."""
         slot = 0
         reduce_jobs = []
-        # ---- units: one workgroup-segment = 4 consecutive partial slots (one per quadrant)
-        # measured on MI355X: a block of an encoding unit (features regenerated in-loop, and
-        # f32 VALU work does not hide under f32 MFMA) costs ~26.3k cycles, a slab unit ~19.7k
-        # a head unit is HBM-bound (32 KiB per block): ~3k cycles
-        unit_costs = [9 if u.kind == 1 else (32 if u.n_kind == 1 else 24) for u in self.wgrad_units]
+        unit_costs = []
+        for u, meta in zip(self.wgrad_units, self.unit_meta):
+            if u.kind == 1:
+                unit_costs.append(HEAD_COST)
+            else:
+                mh, nh = self._quadrants(meta["m_quads"], meta["n_quads"])
+                unit_costs.append(UNIT_COST[mh * nh])
         raw, unit_starts = self._split(unit_costs, blocks, WGRAD_GROUPS)
         unit_segments = []
         unit_slots = [[] for _ in self.wgrad_units]
@@ -431,36 +433,18 @@ class MlpProgram:
                         self.grad_w_off[meta["layer"]], self.grad_b_off[meta["layer"]],
                         self.col_maps[meta["layer"]].data_ptr()))
                 continue
-            for mp in range(2):
-                for np_ in range(2):
-                    if meta["m_quads"] - 32 * mp <= 0 or meta["n_quads"] - 32 * np_ <= 0:
-                        continue
-                    q = 2 * mp + np_
+            mh, nh = self._quadrants(meta["m_quads"], meta["n_quads"])
+            for mp in range(mh):
+                for np_ in range(nh):
+                    # wave w owns quadrant w % (mh*nh): its slots are qd, qd + mh*nh, ...
+                    qd = mp * nh + np_
                     reduce_jobs.append(FfnReduceJob(
-                        0, sl[0] + q, sl[-1] + q + 1, 4 * (meta["m0"] + 32 * mp), spec.out,
+                        0, sl[0] + qd, sl[-1] + 4, 4 * (meta["m0"] + 32 * mp), spec.out,
                         meta["n_quad0"] + 32 * np_, min(32, meta["n_quads"] - 32 * np_),
-                        meta["k_base"], spec.ld, int(meta["first"] and np_ == 0), 0, 4,
+                        meta["k_base"], spec.ld, int(meta["first"] and np_ == 0), 0, mh * nh,
                         self.grad_w_off[meta["layer"]], self.grad_b_off[meta["layer"]],
                         self.col_maps[meta["layer"]].data_ptr()))
-        # ---- logits heads: per-wave jobs
-        raw, head_starts = self._split([COST_HEAD] * len(self.wgrad_jobs), blocks, WGRAD_WAVES)
-        head_segments = []
-        job_slots = [[] for _ in self.wgrad_jobs]
-        for (j, b0, b1) in raw:
-            head_segments.append(FfnWgradSegment(j, slot, b0, b1))
-            job_slots[j].append(slot)
-            slot += 1
-        for j, meta in enumerate(self.job_meta):
-            spec = self.layers[meta["layer"]]
-            sl = job_slots[j]
-            assert sl == list(range(sl[0], sl[-1] + 1))
-            reduce_jobs.append(FfnReduceJob(
-                1, sl[0], sl[-1] + 1, 0, spec.out, meta["n_quad0"], meta["n_quads"],
-                meta["k_base"], spec.ld, meta["has_bias"], meta["lg_n"], 1,
-                self.grad_w_off[meta["layer"]], self.grad_b_off[meta["layer"]],
-                self.col_maps[meta["layer"]].data_ptr()))
         return dict(unit_segments=unit_segments, unit_starts=unit_starts,
-                    head_segments=head_segments, head_starts=head_starts,
                     reduce_jobs=reduce_jobs, slots=slot)
 
     # ------------------------------------------------------------------ packing
@@ -527,18 +511,10 @@ class MlpProgram:
         if self.bwd.num_steps > 0:
             _lib.call("ffn_mlp_backward_data", ctypes.byref(self.bwd), _dev(self.packed_bwd),
                       _dev(d_logits), c_i64(n), _dev(masks), _dev(ws.dz), _stream())
-        if self.wgrad_units:
-            _lib.call("ffn_mlp_wgrad_units", ctypes.byref(self.fwd),
-                      _dev(self.wgrad_units_dev, torch.uint8), _dev(ws.unit_segments, torch.uint8),
-                      _dev(ws.unit_seg_start, torch.int32), c_i(WGRAD_GROUPS), _dev(saved),
-                      _dev(ws.dz), _dev(d_logits), _dev(positions), _dev(views), c_i64(n),
-                      _dev(ws.partials), _stream())
-        if self.wgrad_jobs:
-            _lib.call("ffn_mlp_wgrad", ctypes.byref(self.fwd),
-                      _dev(self.wgrad_jobs_dev, torch.uint8), _dev(ws.segments, torch.uint8),
-                      _dev(ws.seg_start, torch.int32), c_i(WGRAD_WAVES), _dev(saved), _dev(ws.dz),
-                      _dev(d_logits), _dev(positions), _dev(views), c_i64(n), _dev(ws.partials),
-                      _stream())
+        _lib.call("ffn_mlp_wgrad_units", ctypes.byref(self.fwd),
+                  _dev(self.wgrad_units_dev, torch.uint8), _dev(ws.unit_segments, torch.uint8),
+                  _dev(ws.unit_seg_start, torch.int32), c_i(WGRAD_GROUPS), _dev(saved),
+                  _dev(ws.dz), _dev(d_logits), c_i64(n), _dev(ws.partials), _stream())
         _lib.call("ffn_mlp_wgrad_reduce", _dev(ws.reduce_jobs, torch.uint8),
                   c_i(ws.num_reduce_jobs), _dev(ws.partials), _dev(grads), _stream())
         return grads

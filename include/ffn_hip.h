@@ -204,7 +204,9 @@ typedef struct ffn_step {
     int32_t mask_slot;     /* ReLU sign-mask slot: a forward step writes the sign bits of
                               its output there, the backward step that differentiates that
                               layer reads them; -1 = no ReLU                           */
-    int32_t reserved;
+    int32_t save_enc_slot; /* forward: slab that receives the generated encoding features
+                              of this step (so the weight gradients read them back instead
+                              of regenerating them), or -1                             */
     int64_t w_off;         /* float offset of this step's packed operand weights       */
     int64_t b_off;         /* forward: float offset of the bias (padded to 32*tiles)   */
 } ffn_step;
@@ -213,7 +215,9 @@ typedef struct ffn_mlp_chain {
     ffn_encoding enc[2];
     ffn_step step[FFN_MAX_STEPS];
     int32_t num_steps;
-    int32_t num_slots;                     /* activation slabs                        */
+    int32_t num_slots;                     /* hidden-layer slabs (= sign-mask slots);
+                                              entries num_slots.. of the two arrays below
+                                              describe the encoding-feature slabs        */
     int32_t bias_floats;                   /* total padded bias floats (<= 4096)      */
     int32_t reserved;
     int32_t slot_channels[FFN_MAX_STEPS];  /* channels of each slab (multiple of 32)  */
@@ -251,26 +255,17 @@ int ffn_mlp_backward_data(const ffn_mlp_chain* chain, const float* packed_wt,
                           const float* d_logits, int64_t n, uint32_t* masks, float* dz,
                           void* stream);
 
-/* Weight gradients.  A job is one 128x128 patch of some dW (kind 0) or the <=4 rows of a
- * logits head against 128 input channels (kind 1); segments assign contiguous ranges of
- * 32-sample blocks of a job to persistent waves (seg_start[w] .. seg_start[w+1]); every
- * segment writes one partial of ffn_mlp_wgrad_partial_floats() floats into slot
- * `slot` of `partials`. */
-typedef struct ffn_wgrad_job {
-    int32_t kind;      /* 0 = dW patch, 1 = head rows                                  */
-    int32_t m_slot;    /* kind 0: dZ slab providing the 128 output channels            */
-    int32_t m_cq0;     /*         first channel quad inside that slab                  */
-    int32_t m_quads;   /*         valid quads (<= 32)                                  */
-    int32_t n_kind;    /* input panel: 0 = saved activation slab, 1 = encoding         */
-    int32_t n_slot;    /*         slab index, or encoding id                           */
-    int32_t n_cq0;     /*         first channel quad (slab) / internal quad (encoding) */
-    int32_t n_quads;   /*         valid quads (<= 32)                                  */
-    int32_t lg_col;    /* kind 1: d_logits columns [lg_col, lg_col+lg_n)               */
-    int32_t lg_n;
-    int32_t reserved0;
-    int32_t reserved1;
-} ffn_wgrad_job;
-
+/* Weight gradients  dW_l = sum over samples of dZ_l (x) X_l  (autograd of the nn.Linear
+ * layers, fourier_feature_models.py:70-78 / nerf_model.py:103-124).  Every operand is a
+ * slab: dZ from ffn_mlp_backward_data, X = hidden activations and encoding features saved by
+ * ffn_mlp_forward.  A unit is a (<=256 output channels) x (<=256 input channels) block of
+ * some dW; segments assign contiguous ranges of 32-sample blocks of a unit to persistent
+ * workgroups: workgroup g (256 threads) processes segments seg_start[g] .. seg_start[g+1]
+ * (segment.job indexes `units`).  Its four waves own the 128x128 quadrants of the unit that
+ * exist (quadrant id = 2*m_half + n_half when both sides are wider than 128 channels,
+ * otherwise the half index of the wide side, otherwise 0); when fewer than four exist, wave
+ * w takes quadrant w % Q and the (w / Q)-th share of every block's samples.  Each wave
+ * writes one partial of ffn_mlp_wgrad_partial_floats() floats into slot segment.slot + w. */
 typedef struct ffn_wgrad_segment {
     int32_t job;
     int32_t slot;
@@ -278,24 +273,14 @@ typedef struct ffn_wgrad_segment {
     int64_t blk_end;
 } ffn_wgrad_segment;
 
-int ffn_mlp_wgrad(const ffn_mlp_chain* chain, const ffn_wgrad_job* jobs,
-                  const ffn_wgrad_segment* segments, const int32_t* seg_start, int num_waves,
-                  const float* saved, const float* dz, const float* d_logits,
-                  const float* positions, const float* views, int64_t n, float* partials,
-                  void* stream);
-
-/* LDS-staged variant for full products: a unit is a (<=256 output channels) x (<=256 input
- * channels) block of some dW; workgroup g (256 threads) processes the segments
- * seg_start[g] .. seg_start[g+1] (segment.job indexes `units`), its four waves own the four
- * 128x128 quadrants and write partial slots segment.slot + {0,1,2,3}. */
 typedef struct ffn_wgrad_unit {
     int32_t m_slot;    /* dZ slab                        (head unit: first d_logits column) */
     int32_t m_cq0;     /* first channel quad of the output window (head unit: #columns)    */
     int32_t m_quads;   /* valid quads (<= 64, multiple of 8)                           */
-    int32_t n_kind;    /* input window: 0 = saved activation slab, 1 = encoding        */
-    int32_t n_slot;    /* slab index, or encoding id                                   */
-    int32_t n_cq0;     /* first channel quad / internal quad of the window             */
-    int32_t n_quads;   /* valid quads (<= 64, multiple of 8 for slabs)                 */
+    int32_t n_kind;    /* must be 0 (input window = saved slab)                        */
+    int32_t n_slot;    /* slab index of the input window                               */
+    int32_t n_cq0;     /* first channel quad of the window                             */
+    int32_t n_quads;   /* valid quads (<= 64, multiple of 8)                           */
     int32_t kind;      /* 0 = dW block; 1 = logits-head rows: waves own (channel half,
                           sample half), partial slots segment.slot + 2*sample_half + half */
 } ffn_wgrad_unit;
@@ -303,8 +288,7 @@ typedef struct ffn_wgrad_unit {
 int ffn_mlp_wgrad_units(const ffn_mlp_chain* chain, const ffn_wgrad_unit* units,
                         const ffn_wgrad_segment* segments, const int32_t* seg_start,
                         int num_groups, const float* saved, const float* dz,
-                        const float* d_logits, const float* positions, const float* views,
-                        int64_t n, float* partials, void* stream);
+                        const float* d_logits, int64_t n, float* partials, void* stream);
 
 /* Fixed-order reduction of the partials of each job into the flat natural-layout
  * gradient buffer (nn.Linear weight (out,in) row-major, then bias). */

@@ -36,7 +36,7 @@ def test_plan_struct_sizes_match_header():
              sizeof(ffn_step), sizeof(ffn_mlp_chain), offsetof(ffn_mlp_chain, step),
              offsetof(ffn_mlp_chain, num_steps), offsetof(ffn_mlp_chain, bias_floats),
              offsetof(ffn_mlp_chain, slot_offset), offsetof(ffn_step, w_off),
-             sizeof(ffn_wgrad_job), sizeof(ffn_wgrad_unit), sizeof(ffn_wgrad_segment),
+             offsetof(ffn_step, save_enc_slot), sizeof(ffn_wgrad_unit), sizeof(ffn_wgrad_segment),
              sizeof(ffn_reduce_job));
       return 0; }'''
     with tempfile.TemporaryDirectory() as tmp:
@@ -50,7 +50,7 @@ def test_plan_struct_sizes_match_header():
     got = [ctypes.sizeof(me.FfnEncoding), ctypes.sizeof(me.FfnStep), ctypes.sizeof(me.FfnMlpChain),
            me.FfnMlpChain.step.offset, me.FfnMlpChain.num_steps.offset,
            me.FfnMlpChain.bias_floats.offset, me.FfnMlpChain.slot_offset.offset,
-           me.FfnStep.w_off.offset, ctypes.sizeof(me.FfnWgradJob), ctypes.sizeof(me.FfnWgradUnit),
+           me.FfnStep.w_off.offset, me.FfnStep.save_enc_slot.offset, ctypes.sizeof(me.FfnWgradUnit),
            ctypes.sizeof(me.FfnWgradSegment), ctypes.sizeof(me.FfnReduceJob)]
     assert [int(v) for v in out] == got, (out, got)
 

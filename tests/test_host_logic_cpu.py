@@ -80,9 +80,7 @@ def test_chain_and_wgrad_plans(make):
         cover = {}
         for seg in plan["unit_segments"]:
             cover.setdefault(("u", seg.job), []).append((seg.blk_begin, seg.blk_end))
-        for seg in plan["head_segments"]:
-            cover.setdefault(("h", seg.job), []).append((seg.blk_begin, seg.blk_end))
-        assert len(cover) == len(prog.wgrad_units) + len(prog.wgrad_jobs)
+        assert len(cover) == len(prog.wgrad_units)
         for spans in cover.values():
             spans.sort()
             assert spans[0][0] == 0 and spans[-1][1] == blocks
