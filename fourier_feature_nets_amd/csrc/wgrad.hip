@@ -26,9 +26,16 @@ __device__ __forceinline__ f32x4 zero4() { f32x4 z; z[0] = z[1] = z[2] = z[3] = 
 // ---------------------------------------------------------------------------------- units
 // A 256-thread workgroup owns one unit (dZ slab window of <=256 channels  x  input slab
 // window of <=256 channels) over a range of sample blocks.  Per block the two operand images
-// are brought into LDS exactly as they sit in HBM (global_load_lds, 1 KiB per
-// wave-instruction, double buffered).  Each wave computes a 128x128 quadrant from LDS with two
-// conflict-free ds_read_b128 per 16 MFMAs.  HBM/L2 traffic = the unique operand bytes.
+// (<= 32 KiB each) are copied into LDS exactly as they sit in HBM, double buffered; each wave
+// computes a 128x128 quadrant from LDS with two conflict-free ds_read_b128 per 16 MFMAs.
+// HBM/L2 traffic = the unique operand bytes.
+//
+// The copy goes through registers: block b+2 is requested (16 global_load_dwordx4 per lane,
+// spread over the middle steps of block b) into 64 otherwise idle VGPRs, and deposited into
+// the free LDS buffer during the first steps of block b+1 -- more than a block of latency
+// tolerance, and no issue slot that is not under a running MFMA.  (global_load_lds was
+// measured at ~130 exposed cycles per instruction in this loop: 9 % of the kernel.)
+//
 // A window of <=128 channels has only one quadrant along that side; the waves that would own
 // the missing quadrants split the block's 16 sample pairs with their siblings instead (so a
 // 256x128 unit costs half, a 128x128 unit a quarter, of a full one).
@@ -50,30 +57,38 @@ __device__ __forceinline__ void stage_slab(const f32x4* __restrict__ block_base,
 constexpr int kUnitZeroOffset = 2 * kUnitBufBytes;
 constexpr int kUnitLdsBytes = kUnitZeroOffset + 512;
 
+// CA / CB = 4 KiB chunks staged per block for the A / B image: 8 for a window wider than 128
+// channels (two quadrants along that side), 4 otherwise; BIAS = this wave also sums dZ.
+template <int CA, int CB, bool BIAS>
 __device__ __forceinline__ void unit_segment(const ffn_mlp_chain& ch, const ffn_wgrad_unit& unit,
                                              const ffn_wgrad_segment& seg, char* smem,
                                              const float* __restrict__ saved,
                                              const float* __restrict__ dz, int64_t num_blocks,
                                              float* __restrict__ partials) {
+    constexpr int NQ = (CA / 4) * (CB / 4);   // quadrants that exist: 4, 2 or 1
+    constexpr int NCH = CA + CB;
+    constexpr int S = 4 * NQ;                 // sample pairs of a block this wave multiplies
+    constexpr int WPS = NCH / (S / 4);        // chunks deposited per step, steps [0, S/4)
+    constexpr int LPS = NCH / (S / 2);        // chunks requested per step, steps [S/4, 3S/4)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int hh = lane >> 5;
     const int li = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // quadrant / sample-part of this wave (all wave-uniform)
-    const int nh = unit.n_quads > 32 ? 2 : 1;
-    const int nq = (unit.m_quads > 32 ? 2 : 1) * nh;     // quadrants that exist: 1, 2 or 4
-    const int qd = wave & (nq - 1);
-    const int part = nq == 4 ? 0 : (nq == 2 ? wave >> 1 : wave);
-    const int mp = nh == 2 ? qd >> 1 : qd, np = nh == 2 ? (qd & 1) : 0;
-    const int steps = 4 * nq;                            // sample pairs of a block per wave
-    const int u0 = part * steps;
+    const int qd = wave & (NQ - 1);
+    const int part = NQ == 4 ? 0 : (NQ == 2 ? wave >> 1 : wave);
+    const int mp = CB == 8 ? qd >> 1 : qd, np = CB == 8 ? (qd & 1) : 0;
     const bool a_ok = li < unit.m_quads - 32 * mp;   // this lane's quad exists in the M window
     const bool b_ok = li < unit.n_quads - 32 * np;
-    const f32x4* a_slab = reinterpret_cast<const f32x4*>(dz + ch.slot_offset[unit.m_slot] * num_blocks * 32) + unit.m_cq0 * 32;
-    const int64_t a_stride = ch.slot_channels[unit.m_slot] * 8;
-    const f32x4* b_slab = reinterpret_cast<const f32x4*>(saved + ch.slot_offset[unit.n_slot] * num_blocks * 32) + unit.n_cq0 * 32;
-    const int64_t b_stride = ch.slot_channels[unit.n_slot] * 8;
+    const int64_t a_stride = (int64_t)ch.slot_channels[unit.m_slot] * 128;   // bytes per block
+    const int64_t b_stride = (int64_t)ch.slot_channels[unit.n_slot] * 128;
+    // wave-uniform base of the block being requested; lanes add tid*16
+    const char* a_s = reinterpret_cast<const char*>(dz + ch.slot_offset[unit.m_slot] * num_blocks * 32) +
+                      unit.m_cq0 * 512 + seg.blk_begin * a_stride;
+    const char* b_s = reinterpret_cast<const char*>(saved + ch.slot_offset[unit.n_slot] * num_blocks * 32) +
+                      unit.n_cq0 * 512 + seg.blk_begin * b_stride;
+    const int ca_last = (unit.m_quads >> 3) - 1, cb_last = (unit.n_quads >> 3) - 1;
+    const int t16 = tid * 16;
 
     f32x16 acc[4][4];
 #pragma unroll
@@ -84,53 +99,87 @@ __device__ __forceinline__ void unit_segment(const ffn_mlp_chain& ch, const ffn_
             for (int r = 0; r < 16; ++r) acc[p][q][r] = 0.0f;
     f32x4 bsum = zero4();
 
-    // ---- prologue: stage the first block into buffer 0
-    stage_slab(a_slab + seg.blk_begin * a_stride, unit.m_quads, smem, tid, wave);
-    stage_slab(b_slab + seg.blk_begin * b_stride, unit.n_quads, smem + 32 * 1024, tid, wave);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // staging registers: R[j] = chunk j of the A image (j < CA) / chunk j-CA of the B image.
+    // Chunks past the end of a window re-read its last chunk (never consumed: the lanes that
+    // would are pointed at the zero row), which keeps the loop free of branches.
+    f32x4 R[NCH];
+#define FFN_REQUEST(j)                                                                         \
+    R[j] = (j) < CA ? *reinterpret_cast<const f32x4*>(a_s + ((j) < ca_last ? (j) : ca_last) * 4096 + t16) \
+                    : *reinterpret_cast<const f32x4*>(b_s + ((j) - CA < cb_last ? (j) - CA : cb_last) * 4096 + t16)
+#define FFN_DEPOSIT(buf, j)                                                                    \
+    *reinterpret_cast<f32x4*>((buf) + ((j) < CA ? (j) * 4096 : 32 * 1024 + ((j) - CA) * 4096) + t16) = R[j]
 
-    const int sw = li & 15;
+    // ---- prologue: first block -> LDS buffer 0, second block -> registers
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) FFN_REQUEST(j);
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) FFN_DEPOSIT(smem, j);
+    a_s += a_stride;
+    b_s += b_stride;
+    if (seg.blk_begin + 1 < seg.blk_end) {
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) FFN_REQUEST(j);
+    }
+    a_s += a_stride;       // from here on: the block after next
+    b_s += b_stride;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // LDS byte offset of sample pair u inside a quad row: ((2u + hh) ^ (li & 15)) * 16
+    //   = x0 ^ (i << 5)  for u = part*S + i, x0 = ((hh ^ (li & 15)) << 4) ^ (part*S << 5)
+    const unsigned x0 = (unsigned)(((hh ^ (li & 15)) << 4) ^ ((part * S) << 5));
+    const unsigned lds0 = (unsigned)(size_t)smem;
     for (int64_t blk = seg.blk_begin; blk < seg.blk_end; ++blk) {
         const int cur = (int)((blk - seg.blk_begin) & 1);
         char* nxt = smem + (cur ^ 1) * kUnitBufBytes;
-        if (blk + 1 < seg.blk_end) {
-            stage_slab(a_slab + (blk + 1) * a_stride, unit.m_quads, nxt, tid, wave);
-            stage_slab(b_slab + (blk + 1) * b_stride, unit.n_quads, nxt + 32 * 1024, tid, wave);
-        }
+        const bool has1 = blk + 1 < seg.blk_end, has2 = blk + 2 < seg.blk_end;
         // idle lanes of a narrow window read the zero row: no select in the MFMA stream.
         // Operand reads are hand-issued (inline asm, so hipcc's waitcnt pass does not see
         // them) right behind the step's MFMAs have started, and waited for by hand at the end
         // of the step: a full ~1000 cycles of matrix work covers the LDS latency.
-        const unsigned lds0 = (unsigned)(size_t)smem;
         const unsigned a_base = a_ok ? lds0 + cur * kUnitBufBytes + (32 * mp + li) * 512 : lds0 + kUnitZeroOffset;
         const unsigned b_base = b_ok ? lds0 + cur * kUnitBufBytes + 32 * 1024 + (32 * np + li) * 512 : lds0 + kUnitZeroOffset;
         f32x4 a, b, a_n, b_n;
-        const unsigned off_0 = (unsigned)(((2 * u0 + hh) ^ sw) << 4);
         asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(a), "=&v"(b) : "v"(a_base + off_0), "v"(b_base + off_0) : "memory");
-#pragma unroll 2
-        for (int i = 0; i < steps; ++i) {
-            const int un = u0 + (i + 1 < steps ? i + 1 : i);
-            const unsigned off_n = (unsigned)(((2 * un + hh) ^ sw) << 4);
+                     : "=&v"(a), "=&v"(b) : "v"(a_base + x0), "v"(b_base + x0) : "memory");
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            const unsigned off_n = x0 ^ (unsigned)((i + 1 < S ? i + 1 : i) << 5);
             asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3"
                          : "=&v"(a_n), "=&v"(b_n) : "v"(a_base + off_n), "v"(b_base + off_n) : "memory");
             __builtin_amdgcn_sched_barrier(0);
-            bsum += a;
+            if (BIAS) bsum += a;
 #pragma unroll
-            for (int p = 0; p < 4; ++p)
+            for (int p = 0; p < 4; ++p) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     acc[p][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[p], b[q], acc[p][q], 0, 0, 0);
+                if (p == 0) {
+                    if (i < S / 4) {
+                        if (has1) {
+#pragma unroll
+                            for (int jj = 0; jj < WPS; ++jj) FFN_DEPOSIT(nxt, i * WPS + jj);
+                        }
+                    } else if (i < 3 * S / 4) {
+                        if (has2) {
+#pragma unroll
+                            for (int jj = 0; jj < LPS; ++jj) FFN_REQUEST((i - S / 4) * LPS + jj);
+                        }
+                    }
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             a = a_n;
             b = b_n;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        a_s += a_stride;
+        b_s += b_stride;
+        __builtin_amdgcn_s_barrier();     // LDS traffic of this block is complete (lgkmcnt(0) above)
     }
+#undef FFN_REQUEST
+#undef FFN_DEPOSIT
 
     {
         float* out = partials + (int64_t)(seg.slot + wave) * kPartialFloats;
@@ -234,8 +283,25 @@ wgrad_unit_kernel(const ffn_mlp_chain ch, const ffn_wgrad_unit* __restrict__ uni
         const ffn_wgrad_segment seg = segments[si];
         if (seg.blk_end <= seg.blk_begin) continue;
         const ffn_wgrad_unit unit = units[seg.job];
-        if (unit.kind == 1) head_segment(ch, unit, seg, smem, saved, d_logits, n, num_blocks, partials);
-        else unit_segment(ch, unit, seg, smem, saved, dz, num_blocks, partials);
+        if (unit.kind == 1) {
+            head_segment(ch, unit, seg, smem, saved, d_logits, n, num_blocks, partials);
+        } else {
+            const bool m_wide = unit.m_quads > 32, n_wide = unit.n_quads > 32;
+            const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+            // the bias gradient rides on the waves of the layer's first window that own
+            // an n-half 0 quadrant (all variants execute the same barriers)
+            const bool bias = unit.want_bias != 0 && (!n_wide || (wave & 1) == 0);
+#define FFN_UNIT(CA, CB)                                                                       \
+    do {                                                                                       \
+        if (bias) unit_segment<CA, CB, true>(ch, unit, seg, smem, saved, dz, num_blocks, partials);  \
+        else unit_segment<CA, CB, false>(ch, unit, seg, smem, saved, dz, num_blocks, partials);      \
+    } while (0)
+            if (m_wide && n_wide) FFN_UNIT(8, 8);
+            else if (m_wide) FFN_UNIT(8, 4);
+            else if (n_wide) FFN_UNIT(4, 8);
+            else FFN_UNIT(4, 4);
+#undef FFN_UNIT
+        }
         __syncthreads();
     }
 }

@@ -53,7 +53,7 @@ class FfnMlpChain(ctypes.Structure):
 
 class FfnWgradUnit(ctypes.Structure):
     _fields_ = [("m_slot", ctypes.c_int32), ("m_cq0", ctypes.c_int32), ("m_quads", ctypes.c_int32),
-                ("n_kind", ctypes.c_int32), ("n_slot", ctypes.c_int32), ("n_cq0", ctypes.c_int32),
+                ("want_bias", ctypes.c_int32), ("n_slot", ctypes.c_int32), ("n_cq0", ctypes.c_int32),
                 ("n_quads", ctypes.c_int32), ("kind", ctypes.c_int32)]
 
 
@@ -357,7 +357,7 @@ class MlpProgram:
                 for m0 in range(0, out_quads, 64):
                     for wi, (ns, q0, nq, kb) in enumerate(windows):
                         self.wgrad_units.append(FfnWgradUnit(m_slot, m0, min(64, out_quads - m0),
-                                                             0, ns, q0, nq, 0))
+                                                             int(wi == 0), ns, q0, nq, 0))
                         self.unit_meta.append(dict(layer=i, m0=m0, m_quads=min(64, out_quads - m0),
                                                    n_quad0=q0, n_quads=nq, k_base=kb,
                                                    first=(wi == 0)))

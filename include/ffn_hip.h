@@ -277,7 +277,8 @@ typedef struct ffn_wgrad_unit {
     int32_t m_slot;    /* dZ slab                        (head unit: first d_logits column) */
     int32_t m_cq0;     /* first channel quad of the output window (head unit: #columns)    */
     int32_t m_quads;   /* valid quads (<= 64, multiple of 8)                           */
-    int32_t n_kind;    /* must be 0 (input window = saved slab)                        */
+    int32_t want_bias; /* != 0: also produce the bias gradient (sum of dZ over samples)
+                          in the bias strip of the n-half-0 partials               */
     int32_t n_slot;    /* slab index of the input window                               */
     int32_t n_cq0;     /* first channel quad of the window                             */
     int32_t n_quads;   /* valid quads (<= 64, multiple of 8)                           */
