@@ -36,20 +36,25 @@ __device__ __forceinline__ float np_min(float a, float b) {
     return (a != a || b != b) ? __builtin_nanf("") : (a < b ? a : b);
 }
 
-// Encoding tables live in LDS while a kernel runs: per encoding [b row 0 | b row 1 | b row 2 |
-// a], each max(F,1) floats, at a fixed 1024-float pitch.  Feature arithmetic then waits on
-// lgkmcnt only and never drains the weight / operand prefetches that sit on vmcnt.
-constexpr int kEncTablePitch = 1024;            // floats per encoding (F <= 256)
+// Encoding tables live in LDS while a kernel runs: per encoding four rows [b row 0 | b row 1 |
+// b row 2 | a] of 256 floats (F <= 256; the tail of a row is zero), so that the entries of
+// two consecutive frequencies are one aligned 8-byte read.
+constexpr int kEncRowPitch = 256;
+constexpr int kEncTablePitch = 4 * kEncRowPitch;   // floats per encoding
 constexpr int kEncTableBytes = 2 * kEncTablePitch * 4;
 
 __device__ __forceinline__ void stage_encoding_tables(const ffn_encoding* enc, float* table,
                                                       int tid, int nthreads) {
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-        const int fi = enc[e].num_freq > 0 ? enc[e].num_freq : 1;
+        const int f = enc[e].num_freq;
         float* dst = table + e * kEncTablePitch;
-        for (int i = tid; i < 3 * fi; i += nthreads) dst[i] = enc[e].b[i];
-        for (int i = tid; i < fi; i += nthreads) dst[3 * fi + i] = enc[e].a[i];
+        for (int i = tid; i < kEncTablePitch; i += nthreads) {
+            const int row = i / kEncRowPitch, k = i % kEncRowPitch;
+            float v = 0.0f;
+            if (k < f) v = row < 3 ? enc[e].b[row * f + k] : enc[e].a[k];
+            dst[i] = v;
+        }
     }
 }
 
@@ -76,6 +81,43 @@ __device__ __forceinline__ void fast_sincos(float x, float& sn, float& cs) {
     const float c0 = swap ? sp : cp;
     sn = (q & 2) ? -s0 : s0;
     cs = ((q + 1) & 2) ? -c0 : c0;
+}
+
+// N angles at once (N = 2 or 4) on the packed-f32 pipe (v_pk_fma_f32 / v_pk_mul_f32: identical
+// rounding per component, half the instructions for the polynomial part).  With N = 4 every
+// source line becomes two independent packed instructions, which is the instruction-level
+// parallelism a lone in-order wave needs to cover the packed-FMA latency.
+typedef float ffn_f32x2 __attribute__((ext_vector_type(2)));
+typedef float ffn_f32x4 __attribute__((ext_vector_type(4)));
+
+template <typename V, int N>
+__device__ __forceinline__ void fast_sincos_n(V x, V& sn, V& cs) {
+    const V t = x * 0.6366197466850281f;
+    V k;
+#pragma unroll
+    for (int j = 0; j < N; ++j) k[j] = __builtin_rintf(t[j]);
+    const V nk = -k;
+    V r = __builtin_elementwise_fma(nk, (V)(1.5707963705062866f), x);
+    r = __builtin_elementwise_fma(nk, (V)(-4.371138828673793e-08f), r);
+    r = __builtin_elementwise_fma(nk, (V)(-1.7151245100058819e-15f), r);
+    const V z = r * r;
+    V sp = __builtin_elementwise_fma((V)(-1.9515295891e-4f), z, (V)(8.3321608736e-3f));
+    V cp = __builtin_elementwise_fma((V)(2.443315711809948e-5f), z, (V)(-1.388731625493765e-3f));
+    sp = __builtin_elementwise_fma(sp, z, (V)(-1.6666654611e-1f));
+    cp = __builtin_elementwise_fma(cp, z, (V)(4.166664568298827e-2f));
+    const V half = __builtin_elementwise_fma((V)(-0.5f), z, (V)(1.0f));
+    sp = __builtin_elementwise_fma(sp * z, r, r);
+    cp = __builtin_elementwise_fma(cp * z, z, half);
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const int q = (int)k[j];
+        const bool swap = (q & 1) != 0;
+        const float s0 = swap ? cp[j] : sp[j];
+        const float c0 = swap ? sp[j] : cp[j];
+        // sign flips as integer XORs of the sign bit
+        sn[j] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, s0) ^ ((unsigned)(q & 2) << 30));
+        cs[j] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, c0) ^ ((unsigned)((q + 1) & 2) << 30));
+    }
 }
 
 }  // namespace ffn

@@ -61,84 +61,110 @@ pack_kernel(const float* __restrict__ src, int rows, int cols, int ld, int trans
 // needs for K group g is channels 8g + 4h + {0,1,2,3}, i.e. frequencies 4g+2h and 4g+2h+1.
 // Branch-free: out-of-range frequencies are clamped for the table reads and masked after.
 struct EncRegs {
-    const float* b;
-    const float* a;
-    int F;        // real number of frequencies
-    int Fi;       // max(F, 1): row stride of the table actually allocated
-    int raw;      // raw inputs follow the trig block
+    const float* tab;  // LDS copy: rows b0 | b1 | b2 | a, kEncRowPitch floats each
+    int F;             // number of frequencies
+    int raw;           // raw inputs follow the trig block
     float scale;
 };
 
 __device__ __forceinline__ EncRegs load_enc(const ffn_encoding& e, const float* table) {
     EncRegs r;
-    r.F = e.num_freq; r.Fi = e.num_freq > 0 ? e.num_freq : 1;
-    r.b = table; r.a = table + 3 * r.Fi;          // LDS copies (stage_encoding_tables)
+    r.F = e.num_freq;
+    r.tab = table;
     r.raw = (e.include_input != 0 || e.num_freq == 0) ? 1 : 0;
     r.scale = e.scale;
     return r;
 }
 
-// Table entries of the two frequencies (4g+2h, 4g+2h+1) a lane needs for K group g, fetched
-// from LDS one loop trip ahead of their use so that no ds_read latency sits in the MFMA stream.
-struct FeatTab {
-    float b0[2], b1[2], b2[2], amp[2];
-};
+typedef ffn_f32x2 f32x2;
 
-__device__ __forceinline__ FeatTab feature_tables(const EncRegs& enc, int g, int h) {
-    FeatTab t;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int k = 4 * g + 2 * h + j;
-        const int kk = k < enc.Fi ? k : enc.Fi - 1;
-        t.b0[j] = enc.b[kk];
-        t.b1[j] = enc.b[enc.Fi + kk];
-        t.b2[j] = enc.b[2 * enc.Fi + kk];
-        t.amp[j] = enc.a[kk];
-    }
-    return t;
-}
-
-__device__ __forceinline__ f32x4 feature_compute(const EncRegs& enc, const FeatTab& t, int g, int h,
-                                                 float x0, float x1, float x2) {
+// Features of K group g for this lane's sample: two frequencies on the packed-f32 pipe.
+// f32 VALU work does not overlap f32 MFMA on gfx950 (it is paid in full, and costs about
+// twice as much when interleaved with matrix instructions), so features are produced in a
+// burst between K loops -- and every instruction counts.  TRIG_ONLY: all four frequencies
+// of the group are real ones (no raw-input / padding selects, no branches).
+template <bool TRIG_ONLY>
+__device__ __forceinline__ f32x4 feature_quad(const EncRegs& enc, int g, int h, float x0, float x1,
+                                              float x2, f32x2 s0, f32x2 s1, f32x2 s2) {
+    const int k = 4 * g + 2 * h;                                     // even
+    const int kk = TRIG_ONLY ? k : (k < kEncRowPitch - 2 ? k : kEncRowPitch - 2);
+    const f32x2 b0 = *reinterpret_cast<const f32x2*>(enc.tab + kk);
+    const f32x2 b1 = *reinterpret_cast<const f32x2*>(enc.tab + kEncRowPitch + kk);
+    const f32x2 b2 = *reinterpret_cast<const f32x2*>(enc.tab + 2 * kEncRowPitch + kk);
+    const f32x2 amp = *reinterpret_cast<const f32x2*>(enc.tab + 3 * kEncRowPitch + kk);
+    // same operation order as the reference's (scale * x) @ B row: mul, fma, fma
+    f32x2 ang = b0 * s0;
+    ang = __builtin_elementwise_fma(s1, b1, ang);
+    ang = __builtin_elementwise_fma(s2, b2, ang);
+    f32x2 sn, cs;
+    fast_sincos_n<f32x2, 2>(ang, sn, cs);
+    const f32x2 c = amp * cs, s = amp * sn;
     f32x4 v;
-    const float s0 = enc.scale * x0, s1 = enc.scale * x1, s2 = enc.scale * x2;
-    if (4 * g + 3 < enc.F) {
-        // wave-uniform fast path: every frequency of this K group is a real one, so the
-        // raw-input / padding selects drop out (f32 VALU work is paid in full next to
-        // f32 MFMA, every instruction counts)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            float ang = s0 * t.b0[j];
-            ang = __builtin_fmaf(s1, t.b1[j], ang);
-            ang = __builtin_fmaf(s2, t.b2[j], ang);
-            float sn, cs;
-            fast_sincos(ang, sn, cs);
-            v[2 * j] = t.amp[j] * cs;
-            v[2 * j + 1] = t.amp[j] * sn;
-        }
+    if (TRIG_ONLY) {
+        v[0] = c[0]; v[1] = s[0]; v[2] = c[1]; v[3] = s[1];
         return v;
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int k = 4 * g + 2 * h + j;
-        float ang = s0 * t.b0[j];
-        ang = __builtin_fmaf(s1, t.b1[j], ang);
-        ang = __builtin_fmaf(s2, t.b2[j], ang);
-        float sn, cs;
-        fast_sincos(ang, sn, cs);
-        const int c = 2 * (k - enc.F);  // offset past the trig block
-        const float raw_even = (enc.raw && c == 0) ? x0 : ((enc.raw && c == 2) ? x2 : 0.0f);
-        const float raw_odd = (enc.raw && c == 0) ? x1 : 0.0f;
-        const bool trig = k < enc.F;
-        v[2 * j] = trig ? t.amp[j] * cs : raw_even;
-        v[2 * j + 1] = trig ? t.amp[j] * sn : raw_odd;
+        const int off = 2 * (k + j - enc.F);   // offset past the trig block
+        const float raw_even = (enc.raw && off == 0) ? x0 : ((enc.raw && off == 2) ? x2 : 0.0f);
+        const float raw_odd = (enc.raw && off == 0) ? x1 : 0.0f;
+        const bool trig = k + j < enc.F;
+        v[2 * j] = trig ? c[j] : raw_even;
+        v[2 * j + 1] = trig ? s[j] : raw_odd;
     }
     return v;
 }
 
-__device__ __forceinline__ f32x4 feature_group(const EncRegs& enc, int g, int h, float x0,
-                                               float x1, float x2) {
-    return feature_compute(enc, feature_tables(enc, g, h), g, h, x0, x1, x2);
+// K groups g and g+1 at once, all four frequencies real: 4-wide source = pairs of independent
+// packed instructions.
+__device__ __forceinline__ void feature_oct(const EncRegs& enc, int g, int h, f32x4 s0, f32x4 s1,
+                                            f32x4 s2, f32x4& va, f32x4& vb) {
+    const float* t = enc.tab + 4 * g + 2 * h;
+    auto two = [](const float* p) {
+        const f32x2 lo = *reinterpret_cast<const f32x2*>(p), hi = *reinterpret_cast<const f32x2*>(p + 4);
+        f32x4 v; v[0] = lo[0]; v[1] = lo[1]; v[2] = hi[0]; v[3] = hi[1];
+        return v;
+    };
+    const f32x4 b0 = two(t), b1 = two(t + kEncRowPitch), b2 = two(t + 2 * kEncRowPitch);
+    const f32x4 amp = two(t + 3 * kEncRowPitch);
+    f32x4 ang = b0 * s0;
+    ang = __builtin_elementwise_fma(s1, b1, ang);
+    ang = __builtin_elementwise_fma(s2, b2, ang);
+    f32x4 sn, cs;
+    fast_sincos_n<f32x4, 4>(ang, sn, cs);
+    const f32x4 c = amp * cs, s = amp * sn;
+    va[0] = c[0]; va[1] = s[0]; va[2] = c[1]; va[3] = s[1];
+    vb[0] = c[2]; vb[1] = s[2]; vb[2] = c[3]; vb[3] = s[3];
+}
+
+// K groups [c0, c0+count) of an encoding into the wave's slab (and, when training, into the
+// saved-feature slab `fsave`).  Four independent groups per trip give the in-order wave the
+// instruction-level parallelism that hides the packed-FMA latency.
+template <bool SAVE>
+__device__ __forceinline__ void generate_features(const EncRegs& enc, int c0, int count, int h,
+                                                  int s, int lane, float x0, float x1, float x2,
+                                                  f32x4* act, f32x4* fsave) {
+    const f32x2 s0 = (f32x2)(enc.scale * x0), s1 = (f32x2)(enc.scale * x1), s2 = (f32x2)(enc.scale * x2);
+    int g_trig = (enc.F >> 2) - c0;               // groups with 4g+3 < F
+    g_trig = g_trig < 0 ? 0 : (g_trig > count ? count : g_trig);
+    g_trig &= ~3;
+    const f32x4 q0 = (f32x4)(enc.scale * x0), q1 = (f32x4)(enc.scale * x1), q2 = (f32x4)(enc.scale * x2);
+    for (int g = 0; g < g_trig; g += 4) {
+        f32x4 v[4];
+        feature_oct(enc, c0 + g, h, q0, q1, q2, v[0], v[1]);
+        feature_oct(enc, c0 + g + 2, h, q0, q1, q2, v[2], v[3]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            act[(g + u) * 64 + lane] = v[u];
+            if (SAVE) fsave[(2 * (c0 + g + u) + h) * 32 + (s ^ ((2 * (c0 + g + u) + h) & 15))] = v[u];
+        }
+    }
+    for (int g = g_trig; g < count; ++g) {
+        const f32x4 v = feature_quad<false>(enc, c0 + g, h, x0, x1, x2, s0, s1, s2);
+        act[g * 64 + lane] = v;
+        if (SAVE) fsave[(2 * (c0 + g) + h) * 32 + (s ^ ((2 * (c0 + g) + h) & 15))] = v;
+    }
 }
 
 // ---------------------------------------------------------------------------------- MFMA block
@@ -162,17 +188,6 @@ __device__ __forceinline__ void pipeline_plain() {
     __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
     __builtin_amdgcn_sched_group_barrier(0x008, 8 * OT, 0);
 }
-template <int OT>
-__device__ __forceinline__ void pipeline_features() {
-    __builtin_amdgcn_sched_group_barrier(0x020, 2 * OT, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
-#pragma unroll
-    for (int i = 0; i < OT * 8; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-    }
-}
-
 // `wg` points at this lane's float4 of tile 0 of the wanted K group; tiles are 64 float4 apart
 template <int OT>
 __device__ __forceinline__ void load_group(f32x4 (&a)[OT], const f32x4* __restrict__ wg) {
@@ -248,14 +263,34 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
     if (MODE == kBackward && L.mask_slot >= 0)
         mbits = w.masks[((int64_t)L.mask_slot * w.num_blocks + w.block) * 64 + w.lane];
 
-    // ---- segment 1: K groups read back from the activation slab ------------------
-    if (GA > 0) {
+    // ---- K segments.  Every operand comes out of the wave's slab: first the activations
+    // the previous step left there (GA groups), then the encoding features, generated into
+    // the slab in bursts of up to 32 K groups (256 channels) between two K loops.
+    const int feat_chunks = MODE == kBackward ? 0 : (GX + 31) >> 5;
+    const int segs = (GA > 0 ? 1 : 0) + feat_chunks;
+    for (int sg = 0; sg < segs; ++sg) {
+        const bool feat = !(GA > 0 && sg == 0);
+        int count = GA;
         f32x4* save = nullptr;
-        if (MODE != kInfer && L.save_in_slot >= 0) save = slab_block(ch, slab_out, L.save_in_slot, w);
+        if (!feat) {
+            if (MODE != kInfer && L.save_in_slot >= 0) save = slab_block(ch, slab_out, L.save_in_slot, w);
+        } else {
+            const int c0 = (sg - (GA > 0 ? 1 : 0)) << 5;
+            count = GX - c0 < 32 ? GX - c0 : 32;
+            const EncRegs enc = load_enc(ch.enc[L.enc_id], w.enc_table + L.enc_id * kEncTablePitch);
+            const float p0 = L.enc_id == 0 ? w.x0 : w.v0;
+            const float p1 = L.enc_id == 0 ? w.x1 : w.v1;
+            const float p2 = L.enc_id == 0 ? w.x2 : w.v2;
+            if (MODE == kTrainFwd && L.save_enc_slot >= 0)
+                generate_features<true>(enc, c0, count, w.h, w.s, w.lane, p0, p1, p2, w.act,
+                                        slab_block(ch, slab_out, L.save_enc_slot, w));
+            else
+                generate_features<false>(enc, c0, count, w.h, w.s, w.lane, p0, p1, p2, w.act, nullptr);
+        }
         const f32x4* xa = w.act + w.lane;
         x0 = xa[0];
         x1 = xa[64];
-        for (int g = 0; g < GA; g += 4) {
+        for (int g = 0; g < count; g += 4) {
             load_group<OT>(wb0, wnext);
             load_group<OT>(wb1, wnext + kGroupStride);
             x2 = xa[128];
@@ -270,7 +305,7 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
             load_group<OT>(wa0, wnext);
             load_group<OT>(wa1, wnext + kGroupStride);
             xa += 256;
-            if (g + 4 < GA) {
+            if (g + 4 < count) {
                 x0 = xa[0];
                 x1 = xa[64];
             }
@@ -286,64 +321,19 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
         }
     }
 
-    // ---- segment 2: generated operands --------------------------------------------
-    if (GX > 0) {
-        if (MODE == kBackward) {
-            // d_logits columns [lg_col, lg_col+lg_n) are K channels 0..lg_n-1: group 0, h == 0
-            f32x4 d = w.dl;
-            f32x4 sel;
+    // ---- backward: the d_logits columns are one more (register) K group --------------
+    if (MODE == kBackward && GX > 0) {
+        // d_logits columns [lg_col, lg_col+lg_n) are K channels 0..lg_n-1: group 0, h == 0
+        f32x4 d = w.dl;
+        f32x4 sel;
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                float v = 0.0f;
+        for (int p = 0; p < 4; ++p) {
+            float v = 0.0f;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) v = (c == L.lg_col + p && p < L.lg_n) ? d[c] : v;
-                sel[p] = w.h == 0 ? v : 0.0f;
-            }
-            mma_group<OT>(acc, wa0, sel);   // group GA; the padding groups are all zero
-        } else {
-            const EncRegs enc = load_enc(ch.enc[L.enc_id], w.enc_table + L.enc_id * kEncTablePitch);
-            const float p0 = L.enc_id == 0 ? w.x0 : w.v0;
-            const float p1 = L.enc_id == 0 ? w.x1 : w.v1;
-            const float p2 = L.enc_id == 0 ? w.x2 : w.v2;
-            x0 = feature_group(enc, 0, w.h, p0, p1, p2);
-            x1 = feature_group(enc, 1, w.h, p0, p1, p2);
-            FeatTab t2 = feature_tables(enc, 2, w.h);
-            FeatTab t3 = feature_tables(enc, 3, w.h);
-            f32x4* fsave = nullptr;
-            if (MODE == kTrainFwd && L.save_enc_slot >= 0) fsave = slab_block(ch, slab_out, L.save_enc_slot, w);
-            for (int e = 0; e < GX; e += 4) {
-                load_group<OT>(wb0, wnext);
-                load_group<OT>(wb1, wnext + kGroupStride);
-                if (MODE == kTrainFwd && fsave != nullptr) {
-                    fsave[saved_index(2 * e + w.h, w.s)] = x0;
-                    fsave[saved_index(2 * (e + 1) + w.h, w.s)] = x1;
-                }
-                const int en = e + 4 < GX ? e + 4 : e;
-                // tables for the groups after next come from LDS now, are used next trip
-                const FeatTab t0n = feature_tables(enc, en, w.h);
-                const FeatTab t1n = feature_tables(enc, en + 1, w.h);
-                x2 = feature_compute(enc, t2, e + 2, w.h, p0, p1, p2);
-                x3 = feature_compute(enc, t3, e + 3, w.h, p0, p1, p2);
-                mma_group<OT>(acc, wa0, x0);
-                mma_group<OT>(acc, wa1, x1);
-                wnext = wnext + 2 * kGroupStride < wlast ? wnext + 2 * kGroupStride : wlast;
-                load_group<OT>(wa0, wnext);
-                load_group<OT>(wa1, wnext + kGroupStride);
-                t2 = feature_tables(enc, en + 2, w.h);
-                t3 = feature_tables(enc, en + 3, w.h);
-                if (MODE == kTrainFwd && fsave != nullptr) {
-                    fsave[saved_index(2 * (e + 2) + w.h, w.s)] = x2;
-                    fsave[saved_index(2 * (e + 3) + w.h, w.s)] = x3;
-                }
-                x0 = feature_compute(enc, t0n, en, w.h, p0, p1, p2);
-                x1 = feature_compute(enc, t1n, en + 1, w.h, p0, p1, p2);
-                mma_group<OT>(acc, wb0, x2);
-                mma_group<OT>(acc, wb1, x3);
-                wnext = wnext + 2 * kGroupStride < wlast ? wnext + 2 * kGroupStride : wlast;
-                pipeline_features<OT>();
-                pipeline_features<OT>();
-            }
+            for (int c = 0; c < 4; ++c) v = (c == L.lg_col + p && p < L.lg_n) ? d[c] : v;
+            sel[p] = w.h == 0 ? v : 0.0f;
         }
+        mma_group<OT>(acc, wa0, sel);   // group GA; the padding groups are all zero
     }
 
     // ---- next step's first weight group rides under this step's epilogue -----------
@@ -360,7 +350,16 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
 
     // ---- epilogue: bias / activation / mask, hand-off -------------------------------
     f32x4* save_out = nullptr;
-    if (MODE == kBackward && L.save_out_slot >= 0) save_out = slab_block(ch, slab_out, L.save_out_slot, w);
+    if (MODE != kInfer && L.save_out_slot >= 0) save_out = slab_block(ch, slab_out, L.save_out_slot, w);
+    // fused logits head: this lane holds channels 8*group + 4h + p of its sample; their
+    // products with the head's rows accumulate per lane, the two halves meet at the end
+    const bool fused_head = MODE != kBackward && L.head_off >= 0;
+    const float* hw = w.bias_lds + (fused_head ? L.head_off : 0) + 4 + 16 * w.h;
+    if (fused_head && w.h == 0) {
+        const f32x4 hb = *reinterpret_cast<const f32x4*>(w.bias_lds + L.head_off);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) w.logit[c] += hb[c];
+    }
     unsigned sign_bits[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int o = 0; o < OT; ++o) {
@@ -387,6 +386,15 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
                 }
                 if (L.dst == 0) {
                     w.act[group * 64 + w.lane] = y;
+                    if (fused_head) {
+#pragma unroll
+                        for (int p = 0; p < 4; ++p) {
+                            const f32x4 w4 = *reinterpret_cast<const f32x4*>(hw + group * 32 + p * 4);
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) w.logit[c] = __builtin_fmaf(y[p], w4[c], w.logit[c]);
+                        }
+                        if (MODE == kTrainFwd && save_out != nullptr) save_out[saved_index(2 * group + w.h, w.s)] = y;
+                    }
                 } else if (o == 0 && q == 0) {
                     // real outputs = rows 0..out_n-1 of tile 0 = registers 0..3 of h == 0
 #pragma unroll
@@ -479,9 +487,11 @@ mlp_forward_kernel(const ffn_mlp_chain ch, const float* __restrict__ packed_w,
         }
         w.logit[0] = w.logit[1] = w.logit[2] = w.logit[3] = 0.0f;
         run_chain<MODE>(ch, w, packed_w, saved);
+        f32x4 out;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)   // MFMA heads leave their rows on h == 0, fused heads on both halves
+            out[c] = w.logit[c] + __shfl_xor(w.logit[c], 32);
         if (w.h == 0 && sample < n) {
-            f32x4 out;
-            out[0] = w.logit[0]; out[1] = w.logit[1]; out[2] = w.logit[2]; out[3] = w.logit[3];
             reinterpret_cast<f32x4*>(logits)[sample] = out;
         }
     }

@@ -40,6 +40,7 @@ class FfnStep(ctypes.Structure):
                 ("out_col", ctypes.c_int32), ("out_n", ctypes.c_int32),
                 ("save_in_slot", ctypes.c_int32), ("save_out_slot", ctypes.c_int32),
                 ("mask_slot", ctypes.c_int32), ("save_enc_slot", ctypes.c_int32),
+                ("head_off", ctypes.c_int32), ("reserved", ctypes.c_int32),
                 ("w_off", ctypes.c_int64), ("b_off", ctypes.c_int64)]
 
 
@@ -194,11 +195,16 @@ class MlpProgram:
             chain.enc[i].scale, chain.enc[i].width = src.scale, src.width
 
     def _build_forward(self):
+        """Forward chain.  Hidden layers (and heads that read an encoding or have no hidden
+        producer) are MFMA steps; a logits head that reads a hidden layer is fused into that
+        layer's epilogue (``head_off``) and has no step of its own."""
         fwd = FfnMlpChain()
         self._fill_encodings(fwd)
         w_off = b_off = 0
         self.col_maps: List[torch.Tensor] = []
-        self.fwd_shapes = []
+        self.step_of: List[Optional[int]] = []   # layer index -> forward step (None = fused head)
+        self.fwd_shapes: Dict[int, tuple] = {}
+        self.fused_heads = []                    # (head layer, bias-buffer offset, channels)
         self.grad_w_off, self.grad_b_off = [], []
         self.slot_of: Dict[int, int] = {}      # producer layer index -> slab slot
         self.producer_of: List[int] = []       # layer index -> layer whose output it consumes
@@ -206,25 +212,55 @@ class MlpProgram:
         g_off = 0
         last_producer = -1
         saved_already = set()
+        num_steps = 0
         for i, spec in enumerate(self.layers):
-            L = fwd.step[i]
             if spec.act_in % 32:
                 raise NotImplementedError("activation widths must be multiples of 32")
             enc = None if spec.enc_id is None else self.encodings[spec.enc_id]
-            L.act_groups = spec.act_in // 8
+            self.producer_of.append(last_producer if spec.act_in > 0 else -1)
+            if spec.act_in > 0 and (last_producer < 0 or
+                                    self.layers[last_producer].out != spec.act_in):
+                raise ValueError("layer %d consumes %d channels but the previous producer "
+                                 "wrote a different width" % (i, spec.act_in))
+            act_groups = spec.act_in // 8
+            cmap = [c if c < spec.act_in else -1 for c in range(8 * act_groups)]
+            if enc is not None:
+                for c in range(enc.width):
+                    nat = enc.natural_index(c)
+                    cmap.append(-1 if nat < 0 else spec.act_in + nat)
+            self.col_maps.append(torch.tensor(cmap, dtype=torch.int32, device=self.device))
+            self.grad_w_off.append(g_off)
+            g_off += spec.out * spec.ld
+            self.grad_b_off.append(g_off)
+            g_off += spec.out
+            fuse = (spec.to_logits is not None and enc is None and spec.act_in > 0
+                    and self.step_of[last_producer] is not None)
+            if fuse:
+                P = fwd.step[self.step_of[last_producer]]
+                if P.head_off >= 0:
+                    raise NotImplementedError("a layer may feed at most one logits head")
+                P.head_off = b_off
+                self.fused_heads.append((i, b_off, spec.act_in))
+                b_off += 4 + 4 * spec.act_in
+                if last_producer not in saved_already:
+                    P.save_out_slot = self.slot_of[last_producer]
+                    saved_already.add(last_producer)
+                self.step_of.append(None)
+                continue
+            if num_steps >= MAX_STEPS:
+                raise NotImplementedError("at most %d forward steps" % MAX_STEPS)
+            L = fwd.step[num_steps]
+            self.step_of.append(num_steps)
+            num_steps += 1
+            L.act_groups = act_groups
             L.aux_groups = 0 if enc is None else enc.width // 8
             L.enc_id = 0 if spec.enc_id is None else spec.enc_id
             L.out_tiles = _tiles(spec.out)
             L.relu = 1 if spec.relu else 0
-            L.save_in_slot = L.save_out_slot = L.mask_slot = L.save_enc_slot = -1
-            self.producer_of.append(last_producer if spec.act_in > 0 else -1)
-            if spec.act_in > 0:
-                if last_producer < 0 or self.layers[last_producer].out != spec.act_in:
-                    raise ValueError("layer %d consumes %d channels but the previous producer "
-                                     "wrote a different width" % (i, spec.act_in))
-                if last_producer not in saved_already:
-                    L.save_in_slot = self.slot_of[last_producer]
-                    saved_already.add(last_producer)
+            L.save_in_slot = L.save_out_slot = L.mask_slot = L.save_enc_slot = L.head_off = -1
+            if spec.act_in > 0 and last_producer not in saved_already:
+                L.save_in_slot = self.slot_of[last_producer]
+                saved_already.add(last_producer)
             if spec.to_logits is None:
                 L.dst, L.out_col, L.out_n = 0, 0, 0
                 if spec.out % 32:
@@ -241,20 +277,10 @@ class MlpProgram:
                 L.dst, L.out_col, L.out_n = 1, spec.to_logits[0], spec.to_logits[1]
             groups = L.act_groups + L.aux_groups
             L.w_off, L.b_off = w_off, b_off
-            cmap = [c if c < spec.act_in else -1 for c in range(8 * L.act_groups)]
-            if enc is not None:
-                for c in range(enc.width):
-                    nat = enc.natural_index(c)
-                    cmap.append(-1 if nat < 0 else spec.act_in + nat)
-            self.col_maps.append(torch.tensor(cmap, dtype=torch.int32, device=self.device))
-            self.fwd_shapes.append((groups, L.out_tiles))
+            self.fwd_shapes[i] = (groups, L.out_tiles)
             w_off += groups * L.out_tiles * 256
             b_off += 32 * L.out_tiles
-            self.grad_w_off.append(g_off)
-            g_off += spec.out * spec.ld
-            self.grad_b_off.append(g_off)
-            g_off += spec.out
-        fwd.num_steps = len(self.layers)
+        fwd.num_steps = num_steps
         fwd.num_slots = len(self.slot_of)
         fwd.bias_floats = b_off
         # encoding features are saved by the first step that generates them (slabs after the
@@ -268,16 +294,16 @@ class MlpProgram:
             if slot >= MAX_STEPS:
                 raise NotImplementedError("too many activation slabs")
             self.enc_slot[spec.enc_id] = slot
-            fwd.step[i].save_enc_slot = slot
+            fwd.step[self.step_of[i]].save_enc_slot = slot
             fwd.slot_channels[slot] = self.encodings[spec.enc_id].width
             fwd.slot_offset[slot] = slot_off
             slot_off += self.encodings[spec.enc_id].width
         if b_off > 4096:
-            raise NotImplementedError("more than 4096 (padded) bias values")
+            raise NotImplementedError("more than 4096 bias + fused-head floats")
         self.fwd = fwd
         self.saved_channels = slot_off
         self.num_grad_floats = g_off
-        self.packed_fwd = torch.zeros((w_off,), dtype=torch.float32, device=self.device)
+        self.packed_fwd = torch.zeros((max(w_off, 1),), dtype=torch.float32, device=self.device)
         self.bias_buf = torch.zeros((b_off,), dtype=torch.float32, device=self.device)
 
     def _build_backward(self):
@@ -451,7 +477,9 @@ class MlpProgram:
     def pack(self):
         """Re-derives the MFMA-operand copies from the current nn.Linear weights."""
         for i, spec in enumerate(self.layers):
-            L = self.fwd.step[i]
+            if self.step_of[i] is None:
+                continue
+            L = self.fwd.step[self.step_of[i]]
             groups, tiles = self.fwd_shapes[i]
             w = spec.weight.detach()
             dst = self.packed_fwd[L.w_off:L.w_off + groups * tiles * 256]
@@ -459,6 +487,12 @@ class MlpProgram:
                       c_i(0), c_p(0), _dev(self.col_maps[i], torch.int32), c_i(groups), c_i(tiles),
                       _dev(dst), _stream())
             self.bias_buf[L.b_off:L.b_off + spec.out].copy_(spec.bias.detach())
+        for (i, off, channels) in self.fused_heads:
+            spec = self.layers[i]
+            col, cnt = spec.to_logits
+            self.bias_buf[off + col:off + col + cnt].copy_(spec.bias.detach())
+            self.bias_buf[off + 4:off + 4 + 4 * channels].view(channels, 4)[:, col:col + cnt].copy_(
+                spec.weight.detach().t())
         for (c, groups, tiles, off) in self.bwd_packs:
             w = self.layers[c].weight.detach()
             dst = self.packed_bwd[off:off + groups * tiles * 256]

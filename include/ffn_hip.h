@@ -200,13 +200,20 @@ typedef struct ffn_step {
     int32_t out_n;
     int32_t save_in_slot;  /* slab that receives the act-part INPUT while it is being
                               consumed (forward: H for backward; backward: dZ), or -1  */
-    int32_t save_out_slot; /* backward: slab that receives the step's output, or -1    */
+    int32_t save_out_slot; /* slab that receives the step's output (backward: dZ of the
+                              last step; forward: input of a fused head), or -1        */
     int32_t mask_slot;     /* ReLU sign-mask slot: a forward step writes the sign bits of
                               its output there, the backward step that differentiates that
                               layer reads them; -1 = no ReLU                           */
     int32_t save_enc_slot; /* forward: slab that receives the generated encoding features
                               of this step (so the weight gradients read them back instead
                               of regenerating them), or -1                             */
+    int32_t head_off;      /* forward: >= 0 fuses a logits head into this step's epilogue:
+                              float offset (inside the bias buffer) of 4 bias floats then
+                              channels*4 weights [channel][logits column], zero in the
+                              columns the head does not write; the step's output is then
+                              also stored into slab save_out_slot when training; -1 none */
+    int32_t reserved;
     int64_t w_off;         /* float offset of this step's packed operand weights       */
     int64_t b_off;         /* forward: float offset of the bias (padded to 32*tiles)   */
 } ffn_step;

@@ -28,15 +28,23 @@ for it in range(2):
 
 
 def report(name, t, steps):
-    per = 3 * steps
-    print(name, "steps/block", steps, "stamps", len(t))
-    for blk in range(min(3, len(t) // per)):
-        row = t[blk * per:(blk + 1) * per]
-        loops = [row[3 * i + 1] - row[3 * i] for i in range(steps)]
-        epis = [row[3 * i + 2] - row[3 * i + 1] for i in range(steps)]
-        print("  block %d: init+K-loop %s  epilogue %s  total %d" % (blk, loops, epis, row[-1] - row[0]))
-    if len(t) >= 2 * per:
-        print("  block period", t[per] - t[0])
+    """Stamps per step: start, (negative) one per K segment start, end of K loops, end of epilogue."""
+    print(name, "stamps", len(t))
+    blocks, cur = [], []
+    ends = 0
+    for v in t:
+        cur.append(v)
+        if v > 0 and len(cur) > 1 and cur[-2] > 0 and sum(1 for c in cur if c > 0) % 3 == 0:
+            ends += 1
+            if ends == steps:
+                blocks.append(cur)
+                cur, ends = [], 0
+    for blk in blocks[:3]:
+        out, i = [], 0
+        pos = [abs(v) for v in blk]
+        marks = ["S" if v > 0 else "k" for v in blk]
+        print("  block: " + " ".join("%s+%d" % (m, b - a) for m, a, b in zip(marks[1:], pos, pos[1:])),
+              " total", pos[-1] - pos[0])
 
 
 prog = model.program()

@@ -60,17 +60,27 @@ def test_chain_and_wgrad_plans(make):
     model = make()
     prog = _plan(model)
     n_dense = len(prog.layers)
-    assert prog.fwd.num_steps == n_dense
+    stepped = [i for i in range(n_dense) if prog.step_of[i] is not None]
+    assert prog.fwd.num_steps == len(stepped)
+    assert len(stepped) + len(prog.fused_heads) == n_dense
     assert prog.num_grad_floats == sum(p.numel() for p in model._dense_params())
     # forward steps: K groups multiples of 4, every hidden output has exactly one slab
-    for i in range(n_dense):
-        st = prog.fwd.step[i]
+    for k in range(prog.fwd.num_steps):
+        st = prog.fwd.step[k]
         assert st.act_groups % 4 == 0 and st.aux_groups % 4 == 0
         assert st.out_tiles in (1, 2, 4, 8)
-    assert prog.fwd.num_slots == len([s for s in prog.layers if s.to_logits is None])
-    saved_by = [prog.fwd.step[i].save_in_slot for i in range(n_dense)]
+    hidden = [i for i, sp in enumerate(prog.layers) if sp.to_logits is None]
+    assert prog.fwd.num_slots == len(hidden)
+    # a logits head that reads a hidden layer rides in that layer's epilogue
+    for (i, off, channels) in prog.fused_heads:
+        producer = prog.fwd.step[prog.step_of[prog.producer_of[i]]]
+        assert producer.head_off == off and channels == prog.layers[i].act_in
+    saved_by = [prog.fwd.step[k].save_in_slot for k in range(prog.fwd.num_steps)]
+    saved_by += [prog.fwd.step[k].save_out_slot for k in range(prog.fwd.num_steps)]
     used = [s for s in saved_by if s >= 0]
-    assert len(used) == len(set(used))           # each activation is saved by one consumer
+    assert len(used) == len(set(used))           # each activation is saved exactly once
+    consumed = {prog.slot_of[p] for p in prog.producer_of if p >= 0}
+    assert set(used) == consumed
     # backward chain ends by storing dZ of the first layer
     last = prog.bwd.step[prog.bwd.num_steps - 1]
     assert last.save_out_slot == 0
