@@ -144,26 +144,27 @@ __device__ __forceinline__ void feature_oct(const EncRegs& enc, int g, int h, f3
 template <bool SAVE>
 __device__ __forceinline__ void generate_features(const EncRegs& enc, int c0, int count, int h,
                                                   int s, int lane, float x0, float x1, float x2,
-                                                  f32x4* act, f32x4* fsave) {
+                                                  f32x4* act, f32x4* fsave, int g_begin, int g_step) {
+    // trips of 4 K groups: g_begin, g_begin + g_step, ... (two waves sharing a slab split them)
     const f32x2 s0 = (f32x2)(enc.scale * x0), s1 = (f32x2)(enc.scale * x1), s2 = (f32x2)(enc.scale * x2);
+    const f32x4 q0 = (f32x4)(enc.scale * x0), q1 = (f32x4)(enc.scale * x1), q2 = (f32x4)(enc.scale * x2);
     int g_trig = (enc.F >> 2) - c0;               // groups with 4g+3 < F
     g_trig = g_trig < 0 ? 0 : (g_trig > count ? count : g_trig);
     g_trig &= ~3;
-    const f32x4 q0 = (f32x4)(enc.scale * x0), q1 = (f32x4)(enc.scale * x1), q2 = (f32x4)(enc.scale * x2);
-    for (int g = 0; g < g_trig; g += 4) {
+    for (int g = g_begin; g < count; g += g_step) {
         f32x4 v[4];
-        feature_oct(enc, c0 + g, h, q0, q1, q2, v[0], v[1]);
-        feature_oct(enc, c0 + g + 2, h, q0, q1, q2, v[2], v[3]);
+        if (g < g_trig) {
+            feature_oct(enc, c0 + g, h, q0, q1, q2, v[0], v[1]);
+            feature_oct(enc, c0 + g + 2, h, q0, q1, q2, v[2], v[3]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = feature_quad<false>(enc, c0 + g + u, h, x0, x1, x2, s0, s1, s2);
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             act[(g + u) * 64 + lane] = v[u];
             if (SAVE) fsave[(2 * (c0 + g + u) + h) * 32 + (s ^ ((2 * (c0 + g + u) + h) & 15))] = v[u];
         }
-    }
-    for (int g = g_trig; g < count; ++g) {
-        const f32x4 v = feature_quad<false>(enc, c0 + g, h, x0, x1, x2, s0, s1, s2);
-        act[g * 64 + lane] = v;
-        if (SAVE) fsave[(2 * (c0 + g) + h) * 32 + (s ^ ((2 * (c0 + g) + h) & 15))] = v;
     }
 }
 
@@ -203,10 +204,12 @@ struct WaveCtx {
     f32x4* act;              // this wave's LDS slab, indexed [group*64 + lane]
     const float* enc_table;  // LDS copies of the encoding tables
     const float* bias_lds;   // LDS copy of every step's (padded) bias
-    uint4* masks;            // ReLU sign masks: [slot][block][lane] x 128 bit
+    uint4* masks;            // ReLU sign masks: [slot][block][half][lane] x 128 bit
     int64_t block;           // global 32-sample block id
     int64_t num_blocks;
     float logit[4];
+    int half;                // wide mode: which half of a step's output tiles this wave owns
+    bool active;             // wide mode: false = lockstep dummy pass (block clamped, no stores)
 };
 
 // float4 index of (channel quad cq, sample s) inside a saved-activation block
@@ -218,12 +221,24 @@ __device__ __forceinline__ f32x4* slab_block(const ffn_mlp_chain& ch, float* bas
            w.block * (int64_t)(ch.slot_channels[slot] * 8);
 }
 
-template <int OT, int MODE>
+// Wide mode (a layer wider than 256 channels): two waves share one 64 KiB slab and one block
+// of 32 samples; each owns half of every step's output tiles (OT = tiles / 2) and reads all
+// of its K groups.  The in-place slab hand-off then needs workgroup barriers: one before the
+// epilogue overwrites the slab (every reader of this step is done) and one after it.
+__device__ __forceinline__ void team_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
+template <int OT, int MODE, bool WIDE>
 __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step& L,
                                          const ffn_step* next, WaveCtx& w,
                                          const float* __restrict__ packed_w,
                                          f32x4 (&pre)[16],               // groups 0,1 weights, prefetched
                                          float* __restrict__ slab_out) { // fwd: saved; bwd: dZ
+    constexpr int TW = WIDE ? 2 : 1;              // waves sharing a step's output tiles
+    constexpr int kChunk = WIDE ? 64 : 32;        // K groups the slab holds
+    const int half = WIDE ? w.half : 0;
     // accumulators start at the bias (forward) or zero (backward): the 32 LDS reads go out
     // back to back here instead of sitting, each with its own wait, in the epilogue
     f32x16 acc[OT];
@@ -233,7 +248,7 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[o][r] = 0.0f;
     } else {
-        const float* bv = w.bias_lds + L.b_off + 4 * w.h;
+        const float* bv = w.bias_lds + L.b_off + 32 * OT * half + 4 * w.h;
 #pragma unroll
         for (int o = 0; o < OT; ++o)
 #pragma unroll
@@ -244,11 +259,11 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
             }
     }
 
-    const f32x4* wp = reinterpret_cast<const f32x4*>(packed_w + L.w_off) + w.lane;
+    const f32x4* wp = reinterpret_cast<const f32x4*>(packed_w + L.w_off) + half * OT * 64 + w.lane;
     const int GA = L.act_groups;   // multiple of 4
     const int GX = L.aux_groups;   // multiple of 4; encoding features (fwd) or d_logits (bwd)
     const int G = GA + GX;
-    constexpr int kGroupStride = OT * 64;   // float4 between consecutive K groups
+    constexpr int kGroupStride = TW * OT * 64;   // float4 between consecutive K groups
     // weights are double buffered two K groups deep: while pair A feeds the MFMAs, pair B
     // (two groups = 4096 MFMA cycles ahead) is in flight from L2.  `wnext` walks the packed
     // panel group by group: one 64-bit add per pair of groups, constant offsets otherwise.
@@ -259,34 +274,40 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
     const f32x4* wnext = wp + 2 * kGroupStride;          // group 2
     const f32x4* wlast = wp + (int64_t)(G - 2) * kGroupStride;
     // backward: the ReLU sign mask of the layer being differentiated, fetched a layer ahead
+    const int64_t mask_at = (((int64_t)(L.mask_slot < 0 ? 0 : L.mask_slot) * w.num_blocks + w.block) * TW + half) * 64 + w.lane;
     uint4 mbits = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
-    if (MODE == kBackward && L.mask_slot >= 0)
-        mbits = w.masks[((int64_t)L.mask_slot * w.num_blocks + w.block) * 64 + w.lane];
+    if (MODE == kBackward && L.mask_slot >= 0) mbits = w.masks[mask_at];
 
-    // ---- K segments.  Every operand comes out of the wave's slab: first the activations
-    // the previous step left there (GA groups), then the encoding features, generated into
-    // the slab in bursts of up to 32 K groups (256 channels) between two K loops.
-    const int feat_chunks = MODE == kBackward ? 0 : (GX + 31) >> 5;
+    // ---- K segments.  Every operand comes out of the slab: first the activations the
+    // previous step left there (GA groups), then the encoding features, generated into the
+    // slab in bursts of up to kChunk K groups between two K loops.
+    const int feat_chunks = MODE == kBackward ? 0 : (GX + kChunk - 1) / kChunk;
     const int segs = (GA > 0 ? 1 : 0) + feat_chunks;
     for (int sg = 0; sg < segs; ++sg) {
         const bool feat = !(GA > 0 && sg == 0);
         int count = GA;
         f32x4* save = nullptr;
         if (!feat) {
-            if (MODE != kInfer && L.save_in_slot >= 0) save = slab_block(ch, slab_out, L.save_in_slot, w);
+            if (MODE != kInfer && L.save_in_slot >= 0 && w.active) save = slab_block(ch, slab_out, L.save_in_slot, w);
         } else {
-            const int c0 = (sg - (GA > 0 ? 1 : 0)) << 5;
-            count = GX - c0 < 32 ? GX - c0 : 32;
+            const int c0 = (sg - (GA > 0 ? 1 : 0)) * kChunk;
+            count = GX - c0 < kChunk ? GX - c0 : kChunk;
             const EncRegs enc = load_enc(ch.enc[L.enc_id], w.enc_table + L.enc_id * kEncTablePitch);
             const float p0 = L.enc_id == 0 ? w.x0 : w.v0;
             const float p1 = L.enc_id == 0 ? w.x1 : w.v1;
             const float p2 = L.enc_id == 0 ? w.x2 : w.v2;
-            if (MODE == kTrainFwd && L.save_enc_slot >= 0)
+            if (WIDE && sg > 0) team_barrier();   // the partner may still read what we overwrite
+            if (MODE == kTrainFwd && L.save_enc_slot >= 0 && w.active)
                 generate_features<true>(enc, c0, count, w.h, w.s, w.lane, p0, p1, p2, w.act,
-                                        slab_block(ch, slab_out, L.save_enc_slot, w));
+                                        slab_block(ch, slab_out, L.save_enc_slot, w), 4 * half, 4 * TW);
             else
-                generate_features<false>(enc, c0, count, w.h, w.s, w.lane, p0, p1, p2, w.act, nullptr);
+                generate_features<false>(enc, c0, count, w.h, w.s, w.lane, p0, p1, p2, w.act, nullptr,
+                                         4 * half, 4 * TW);
+            if (WIDE) team_barrier();
         }
+        // wide mode: each wave of the pair saves half of what both consume
+        const bool save_lo = MODE != kInfer && save != nullptr && (!WIDE || half == 0);
+        const bool save_hi = MODE != kInfer && save != nullptr && (!WIDE || half == 1);
         const f32x4* xa = w.act + w.lane;
         x0 = xa[0];
         x1 = xa[64];
@@ -295,7 +316,7 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
             load_group<OT>(wb1, wnext + kGroupStride);
             x2 = xa[128];
             x3 = xa[192];
-            if (MODE != kInfer && save != nullptr) {
+            if (save_lo) {
                 save[saved_index(2 * g + w.h, w.s)] = x0;
                 save[saved_index(2 * (g + 1) + w.h, w.s)] = x1;
             }
@@ -309,7 +330,7 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
                 x0 = xa[0];
                 x1 = xa[64];
             }
-            if (MODE != kInfer && save != nullptr) {
+            if (save_hi) {
                 save[saved_index(2 * (g + 2) + w.h, w.s)] = x2;
                 save[saved_index(2 * (g + 3) + w.h, w.s)] = x3;
             }
@@ -338,34 +359,35 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
 
     // ---- next step's first weight group rides under this step's epilogue -----------
     if (next != nullptr) {
-        const f32x4* wn = reinterpret_cast<const f32x4*>(packed_w + next->w_off) + w.lane;
-        const int ot_next = next->out_tiles;
+        const int ot_next = next->out_tiles / TW;
+        const f32x4* wn = reinterpret_cast<const f32x4*>(packed_w + next->w_off) + half * ot_next * 64 + w.lane;
 #pragma unroll
         for (int o = 0; o < 8; ++o)
             if (o < ot_next) {
                 pre[o] = wn[o * 64];
-                pre[8 + o] = wn[(int64_t)(ot_next + o) * 64];
+                pre[8 + o] = wn[(int64_t)(TW * ot_next + o) * 64];
             }
     }
 
     // ---- epilogue: bias / activation / mask, hand-off -------------------------------
     f32x4* save_out = nullptr;
-    if (MODE != kInfer && L.save_out_slot >= 0) save_out = slab_block(ch, slab_out, L.save_out_slot, w);
+    if (MODE != kInfer && L.save_out_slot >= 0 && w.active) save_out = slab_block(ch, slab_out, L.save_out_slot, w);
     // fused logits head: this lane holds channels 8*group + 4h + p of its sample; their
-    // products with the head's rows accumulate per lane, the two halves meet at the end
+    // products with the head's rows accumulate per lane, the partial sums meet at the end
     const bool fused_head = MODE != kBackward && L.head_off >= 0;
     const float* hw = w.bias_lds + (fused_head ? L.head_off : 0) + 4 + 16 * w.h;
-    if (fused_head && w.h == 0) {
+    if (fused_head && w.h == 0 && half == 0) {
         const f32x4 hb = *reinterpret_cast<const f32x4*>(w.bias_lds + L.head_off);
 #pragma unroll
         for (int c = 0; c < 4; ++c) w.logit[c] += hb[c];
     }
+    if (WIDE) team_barrier();        // every K loop of this step has finished reading the slab
     unsigned sign_bits[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int o = 0; o < OT; ++o) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int group = 4 * o + q;
+            const int group = 4 * (OT * half + o) + q;   // K group of the next step
             f32x4 y;
             if (MODE == kBackward) {
                 const unsigned word = o < 2 ? mbits.x : (o < 4 ? mbits.y : (o < 6 ? mbits.z : mbits.w));
@@ -395,7 +417,7 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
                         }
                         if (MODE == kTrainFwd && save_out != nullptr) save_out[saved_index(2 * group + w.h, w.s)] = y;
                     }
-                } else if (o == 0 && q == 0) {
+                } else if (!WIDE && o == 0 && q == 0) {
                     // real outputs = rows 0..out_n-1 of tile 0 = registers 0..3 of h == 0
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {   // static register index, runtime select
@@ -409,56 +431,66 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
             }
         }
     }
-    if (MODE == kTrainFwd && L.relu && L.mask_slot >= 0)
-        w.masks[((int64_t)L.mask_slot * w.num_blocks + w.block) * 64 + w.lane] =
-            make_uint4(sign_bits[0], sign_bits[1], sign_bits[2], sign_bits[3]);
+    if (MODE == kTrainFwd && L.relu && L.mask_slot >= 0 && w.active)
+        w.masks[mask_at] = make_uint4(sign_bits[0], sign_bits[1], sign_bits[2], sign_bits[3]);
+    if (WIDE) team_barrier();        // the step's output is in the slab
 }
 
-template <int MODE>
+template <int MODE, bool WIDE>
 __device__ __forceinline__ void run_chain(const ffn_mlp_chain& ch, WaveCtx& w,
                                           const float* __restrict__ packed_w,
                                           float* __restrict__ slab_out) {
+    constexpr int TW = WIDE ? 2 : 1;
     f32x4 pre[16];
     {
         const ffn_step& first = ch.step[0];
-        const f32x4* wp = reinterpret_cast<const f32x4*>(packed_w + first.w_off) + w.lane;
+        const int ot = first.out_tiles / TW;
+        const f32x4* wp = reinterpret_cast<const f32x4*>(packed_w + first.w_off) + (WIDE ? w.half : 0) * ot * 64 + w.lane;
 #pragma unroll
         for (int o = 0; o < 8; ++o)
-            if (o < first.out_tiles) {
+            if (o < ot) {
                 pre[o] = wp[o * 64];
-                pre[8 + o] = wp[(int64_t)(first.out_tiles + o) * 64];
+                pre[8 + o] = wp[(int64_t)(TW * ot + o) * 64];
             }
     }
     for (int li = 0; li < ch.num_steps; ++li) {
         const ffn_step& L = ch.step[li];
         const ffn_step* next = li + 1 < ch.num_steps ? &ch.step[li + 1] : nullptr;
-        switch (L.out_tiles) {
-            case 8: run_step<8, MODE>(ch, L, next, w, packed_w, pre, slab_out); break;
-            case 4: run_step<4, MODE>(ch, L, next, w, packed_w, pre, slab_out); break;
-            case 2: run_step<2, MODE>(ch, L, next, w, packed_w, pre, slab_out); break;
-            default: run_step<1, MODE>(ch, L, next, w, packed_w, pre, slab_out); break;
+        switch (L.out_tiles / TW) {
+            case 8: run_step<8, MODE, WIDE>(ch, L, next, w, packed_w, pre, slab_out); break;
+            case 4: run_step<4, MODE, WIDE>(ch, L, next, w, packed_w, pre, slab_out); break;
+            case 2: run_step<2, MODE, WIDE>(ch, L, next, w, packed_w, pre, slab_out); break;
+            default: run_step<1, MODE, WIDE>(ch, L, next, w, packed_w, pre, slab_out); break;
         }
     }
 }
 
 // Persistent launch: one workgroup per CU; its four waves walk the 32-sample blocks
 // independently (block = first, first + stride, ...) -- no workgroup turnover, no tail of
-// SIMDs idling until the slowest sibling wave retires.
-__device__ __forceinline__ bool wave_setup(WaveCtx& w, char* smem, int64_t n, int64_t& stride) {
+// SIMDs idling until the slowest sibling wave retires.  Wide mode: two pairs of waves per
+// workgroup, every pair runs the same number of passes (the barriers are workgroup-wide);
+// a pair past the end re-runs the last block with its stores switched off.
+constexpr int kTeamScratchBytes = 2048;    // wide mode: partial logits of the odd waves
+
+template <bool WIDE>
+__device__ __forceinline__ void wave_setup(WaveCtx& w, char* smem, int64_t n, int64_t& stride) {
     w.lane = threadIdx.x & 63;
     w.h = w.lane >> 5;
     w.s = w.lane & 31;
     const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    stride = (int64_t)gridDim.x * kWavesPerBlock;
-    w.act = reinterpret_cast<f32x4*>(smem + wave_in_block * kActBytesPerWave);
+    const int teams = WIDE ? 2 : kWavesPerBlock;
+    const int team = WIDE ? wave_in_block >> 1 : wave_in_block;
+    w.half = WIDE ? (wave_in_block & 1) : 0;
+    stride = (int64_t)gridDim.x * teams;
+    w.act = reinterpret_cast<f32x4*>(smem + team * (kActBytesPerWave * kWavesPerBlock / teams));
     w.enc_table = reinterpret_cast<const float*>(smem + kWavesPerBlock * kActBytesPerWave);
     w.bias_lds = reinterpret_cast<const float*>(smem + kWavesPerBlock * kActBytesPerWave + kEncTableBytes);
     w.num_blocks = (n + kSamplesPerWave - 1) / kSamplesPerWave;
-    w.block = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block;
-    return w.block < w.num_blocks;  // no barriers anywhere, an idle wave may simply leave
+    w.block = (int64_t)blockIdx.x * teams + team;
+    w.active = true;
 }
 
-template <int MODE>
+template <int MODE, bool WIDE>
 __global__ void __launch_bounds__(256, 1)
 mlp_forward_kernel(const ffn_mlp_chain ch, const float* __restrict__ packed_w,
                    const float* __restrict__ bias, const float* __restrict__ positions,
@@ -471,12 +503,21 @@ mlp_forward_kernel(const ffn_mlp_chain ch, const float* __restrict__ packed_w,
         float* bl = reinterpret_cast<float*>(smem + kWavesPerBlock * kActBytesPerWave + kEncTableBytes);
         for (int i = threadIdx.x; i < ch.bias_floats; i += 256) bl[i] = bias[i];
     }
-    __syncthreads();                                  // the only barrier of the kernel
+    __syncthreads();                  // narrow mode: the only barrier of the kernel
     WaveCtx w;
     int64_t stride;
-    if (!wave_setup(w, smem, n, stride)) return;
+    wave_setup<WIDE>(w, smem, n, stride);
     w.masks = reinterpret_cast<uint4*>(masks);
-    for (; w.block < w.num_blocks; w.block += stride) {
+    f32x4* scratch = reinterpret_cast<f32x4*>(smem + kWavesPerBlock * kActBytesPerWave + kEncTableBytes +
+                                              kBiasLdsFloats * 4) + (threadIdx.x >> 7) * 64;
+    const int64_t passes = WIDE ? (w.num_blocks + stride - 1) / stride : 0;
+    const int64_t first = w.block;
+    for (int64_t pass = 0; WIDE ? pass < passes : w.block < w.num_blocks; ++pass) {
+        if (WIDE) {
+            w.block = first + pass * stride;
+            w.active = w.block < w.num_blocks;
+            if (!w.active) w.block = w.num_blocks - 1;
+        }
         const int64_t sample = w.block * kSamplesPerWave + w.s;
         const int64_t src = sample < n ? sample : n - 1;  // tail lanes recompute the last sample
         w.x0 = positions[src * 3 + 0]; w.x1 = positions[src * 3 + 1]; w.x2 = positions[src * 3 + 2];
@@ -486,19 +527,26 @@ mlp_forward_kernel(const ffn_mlp_chain ch, const float* __restrict__ packed_w,
             w.v0 = w.v1 = w.v2 = 0.0f;
         }
         w.logit[0] = w.logit[1] = w.logit[2] = w.logit[3] = 0.0f;
-        run_chain<MODE>(ch, w, packed_w, saved);
+        run_chain<MODE, WIDE>(ch, w, packed_w, saved);
         f32x4 out;
 #pragma unroll
         for (int c = 0; c < 4; ++c)   // MFMA heads leave their rows on h == 0, fused heads on both halves
             out[c] = w.logit[c] + __shfl_xor(w.logit[c], 32);
-        if (w.h == 0 && sample < n) {
+        if (WIDE) {                   // the two waves of a pair hold partial sums
+            if (w.half == 1) scratch[w.lane] = out;
+            team_barrier();
+            if (w.half == 0) out += scratch[w.lane];
+        }
+        if (w.h == 0 && w.half == 0 && w.active && sample < n) {
             reinterpret_cast<f32x4*>(logits)[sample] = out;
         }
+        if (!WIDE) w.block += stride;
     }
 }
 
 // Backward-data chain: consumes d_logits (N,4) and the saved forward activations, writes
 // dZ of every hidden layer (block layout) for the weight-gradient kernel.
+template <bool WIDE>
 __global__ void __launch_bounds__(256, 1)
 mlp_backward_data_kernel(const ffn_mlp_chain ch, const float* __restrict__ packed_wt,
                          const float* __restrict__ d_logits, int64_t n,
@@ -506,14 +554,22 @@ mlp_backward_data_kernel(const ffn_mlp_chain ch, const float* __restrict__ packe
     extern __shared__ __attribute__((aligned(16))) char smem[];
     WaveCtx w;
     int64_t stride;
-    if (!wave_setup(w, smem, n, stride)) return;
+    wave_setup<WIDE>(w, smem, n, stride);
     w.masks = reinterpret_cast<uint4*>(masks);
     w.x0 = w.x1 = w.x2 = w.v0 = w.v1 = w.v2 = 0.0f;
-    for (; w.block < w.num_blocks; w.block += stride) {
+    const int64_t passes = WIDE ? (w.num_blocks + stride - 1) / stride : 0;
+    const int64_t first = w.block;
+    for (int64_t pass = 0; WIDE ? pass < passes : w.block < w.num_blocks; ++pass) {
+        if (WIDE) {
+            w.block = first + pass * stride;
+            w.active = w.block < w.num_blocks;
+            if (!w.active) w.block = w.num_blocks - 1;
+        }
         const int64_t sample = w.block * kSamplesPerWave + w.s;
         f32x4 zero; zero[0] = zero[1] = zero[2] = zero[3] = 0.0f;
         w.dl = sample < n ? reinterpret_cast<const f32x4*>(d_logits)[sample] : zero;
-        run_chain<kBackward>(ch, w, packed_wt, dz);
+        run_chain<kBackward, WIDE>(ch, w, packed_wt, dz);
+        if (!WIDE) w.block += stride;
     }
 }
 
@@ -536,27 +592,29 @@ extern "C" int ffn_mlp_pack(const float* src, int rows, int cols, int ld, int tr
 static int validate_chain(const ffn_mlp_chain* ch, bool backward) {
     if (ch == nullptr || ch->num_steps < 1 || ch->num_steps > FFN_MAX_STEPS) return 1;
     if (ch->bias_floats < 0 || ch->bias_floats > kBiasLdsFloats) return 1;
+    const bool wide = ch->wide != 0;
     for (int i = 0; i < ch->num_steps; ++i) {
         const ffn_step& L = ch->step[i];
         const int ot = L.out_tiles;
-        if (!(ot == 1 || ot == 2 || ot == 4 || ot == 8)) return 1;
-        if (L.act_groups < 0 || L.aux_groups < 0 || L.act_groups > 32) return 1;
+        if (wide ? !(ot == 2 || ot == 4 || ot == 8 || ot == 16) : !(ot == 1 || ot == 2 || ot == 4 || ot == 8)) return 1;
+        if (L.act_groups < 0 || L.aux_groups < 0 || L.act_groups > (wide ? 64 : 32)) return 1;
         if ((L.act_groups & 3) || (L.aux_groups & 3) || L.act_groups + L.aux_groups == 0) return 1;
         if (!backward && L.aux_groups > 0 && (L.enc_id < 0 || L.enc_id > 1)) return 1;
         if (!backward && (ch->enc[0].num_freq > 256 || ch->enc[1].num_freq > 256)) return 1;
         if (backward && L.aux_groups != 0 && L.aux_groups != 4) return 1;
         if (backward && L.aux_groups && (L.lg_n < 1 || L.lg_col < 0 || L.lg_col + L.lg_n > 4)) return 1;
         if (!backward && L.dst == 1 &&
-            (L.out_n < 1 || L.out_n > 4 || L.out_col < 0 || L.out_col + L.out_n > 4))
+            (wide || L.out_n < 1 || L.out_n > 4 || L.out_col < 0 || L.out_col + L.out_n > 4))
             return 1;
     }
     return 0;
 }
 
-static const size_t kLdsBytes = (size_t)kWavesPerBlock * kActBytesPerWave + kEncTableBytes + kBiasLdsFloats * 4;
+static const size_t kLdsBytes = (size_t)kWavesPerBlock * kActBytesPerWave + kEncTableBytes +
+                                kBiasLdsFloats * 4 + kTeamScratchBytes;
 
 // one resident workgroup per CU (its ~150 KiB of LDS admit no second one)
-static int64_t persistent_grid(int64_t blocks32) {
+static int64_t persistent_grid(int64_t blocks32, int teams) {
     static int cus = 0;
     if (cus == 0) {
         int dev = 0;
@@ -565,7 +623,7 @@ static int64_t persistent_grid(int64_t blocks32) {
             cus = prop.multiProcessorCount;
         if (cus <= 0) cus = 256;
     }
-    const int64_t wgs = (blocks32 + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int64_t wgs = (blocks32 + teams - 1) / teams;
     return wgs < cus ? wgs : cus;
 }
 
@@ -575,6 +633,18 @@ static void allow_big_lds(K kernel) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
 }
 
+template <int MODE, bool WIDE>
+static void launch_forward(const ffn_mlp_chain* chain, const float* packed_w, const float* bias,
+                           const float* positions, const float* views, int64_t n, float* logits,
+                           float* saved, uint32_t* masks, void* stream) {
+    const int64_t blocks32 = (n + kSamplesPerWave - 1) / kSamplesPerWave;
+    const int64_t grid = persistent_grid(blocks32, WIDE ? 2 : kWavesPerBlock);
+    allow_big_lds(&mlp_forward_kernel<MODE, WIDE>);
+    hipLaunchKernelGGL((mlp_forward_kernel<MODE, WIDE>), dim3((unsigned)grid), dim3(256), kLdsBytes,
+                       (hipStream_t)stream, *chain, packed_w, bias, positions, views, n, logits, saved,
+                       masks);
+}
+
 extern "C" int ffn_mlp_forward(const ffn_mlp_chain* chain, const float* packed_w,
                                const float* bias, const float* positions, const float* views,
                                int64_t n, float* logits, float* saved, uint32_t* masks,
@@ -582,20 +652,25 @@ extern "C" int ffn_mlp_forward(const ffn_mlp_chain* chain, const float* packed_w
     if (n == 0) return 0;
     if (n < 0 || validate_chain(chain, false)) return fail_arg("ffn_mlp_forward: bad chain or size");
     if ((saved == nullptr) != (masks == nullptr)) return fail_arg("ffn_mlp_forward: saved and masks go together");
-    const int64_t blocks32 = (n + kSamplesPerWave - 1) / kSamplesPerWave;
-    const int64_t grid = persistent_grid(blocks32);
-    if (saved != nullptr) {
-        allow_big_lds(&mlp_forward_kernel<kTrainFwd>);
-        hipLaunchKernelGGL(mlp_forward_kernel<kTrainFwd>, dim3((unsigned)grid), dim3(256), kLdsBytes,
-                           (hipStream_t)stream, *chain, packed_w, bias, positions, views, n, logits,
-                           saved, masks);
+    const bool train = saved != nullptr;
+    if (chain->wide) {
+        if (train) launch_forward<kTrainFwd, true>(chain, packed_w, bias, positions, views, n, logits, saved, masks, stream);
+        else launch_forward<kInfer, true>(chain, packed_w, bias, positions, views, n, logits, saved, masks, stream);
     } else {
-        allow_big_lds(&mlp_forward_kernel<kInfer>);
-        hipLaunchKernelGGL(mlp_forward_kernel<kInfer>, dim3((unsigned)grid), dim3(256), kLdsBytes,
-                           (hipStream_t)stream, *chain, packed_w, bias, positions, views, n, logits,
-                           saved, masks);
+        if (train) launch_forward<kTrainFwd, false>(chain, packed_w, bias, positions, views, n, logits, saved, masks, stream);
+        else launch_forward<kInfer, false>(chain, packed_w, bias, positions, views, n, logits, saved, masks, stream);
     }
     return check_launch("ffn_mlp_forward");
+}
+
+template <bool WIDE>
+static void launch_backward(const ffn_mlp_chain* chain, const float* packed_wt, const float* d_logits,
+                            int64_t n, uint32_t* masks, float* dz, void* stream) {
+    const int64_t blocks32 = (n + kSamplesPerWave - 1) / kSamplesPerWave;
+    const int64_t grid = persistent_grid(blocks32, WIDE ? 2 : kWavesPerBlock);
+    allow_big_lds(&mlp_backward_data_kernel<WIDE>);
+    hipLaunchKernelGGL((mlp_backward_data_kernel<WIDE>), dim3((unsigned)grid), dim3(256), kLdsBytes,
+                       (hipStream_t)stream, *chain, packed_wt, d_logits, n, masks, dz);
 }
 
 extern "C" int ffn_mlp_backward_data(const ffn_mlp_chain* chain, const float* packed_wt,
@@ -603,10 +678,7 @@ extern "C" int ffn_mlp_backward_data(const ffn_mlp_chain* chain, const float* pa
                                      float* dz, void* stream) {
     if (n == 0) return 0;
     if (n < 0 || validate_chain(chain, true)) return fail_arg("ffn_mlp_backward_data: bad chain or size");
-    const int64_t blocks32 = (n + kSamplesPerWave - 1) / kSamplesPerWave;
-    const int64_t grid = persistent_grid(blocks32);
-    allow_big_lds(&mlp_backward_data_kernel);
-    hipLaunchKernelGGL(mlp_backward_data_kernel, dim3((unsigned)grid), dim3(256), kLdsBytes,
-                       (hipStream_t)stream, *chain, packed_wt, d_logits, n, masks, dz);
+    if (chain->wide) launch_backward<true>(chain, packed_wt, d_logits, n, masks, dz, stream);
+    else launch_backward<false>(chain, packed_wt, d_logits, n, masks, dz, stream);
     return check_launch("ffn_mlp_backward_data");
 }

@@ -47,7 +47,7 @@ class FfnStep(ctypes.Structure):
 class FfnMlpChain(ctypes.Structure):
     _fields_ = [("enc", FfnEncoding * 2), ("step", FfnStep * MAX_STEPS),
                 ("num_steps", ctypes.c_int32), ("num_slots", ctypes.c_int32),
-                ("bias_floats", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("bias_floats", ctypes.c_int32), ("wide", ctypes.c_int32),
                 ("slot_channels", ctypes.c_int32 * MAX_STEPS),
                 ("slot_offset", ctypes.c_int64 * MAX_STEPS)]
 
@@ -129,11 +129,12 @@ class DenseSpec:
         self.ld = int(weight.shape[1])
 
 
-def _tiles(channels: int) -> int:
+def _tiles(channels: int, wide: bool = False) -> int:
     tiles = (channels + 31) // 32
-    if tiles not in (1, 2, 4, 8):
+    if tiles not in ((2, 4, 8, 16) if wide else (1, 2, 4, 8)):
         raise NotImplementedError(
-            "fused MLP kernels support layer widths of 32/64/128/256 channels (got %d)" % channels)
+            "fused MLP kernels support layer widths of 32/64/128/256 channels, or "
+            "64/128/256/512 next to a 512-wide layer (got %d)" % channels)
     return tiles
 
 
@@ -200,6 +201,10 @@ class MlpProgram:
         layer's epilogue (``head_off``) and has no step of its own."""
         fwd = FfnMlpChain()
         self._fill_encodings(fwd)
+        # a layer wider than 256 channels switches the whole chain to the two-waves-per-block
+        # kernels (64 KiB slab per pair)
+        self.wide = any(sp.to_logits is None and sp.out > 256 for sp in self.layers)
+        fwd.wide = 1 if self.wide else 0
         w_off = b_off = 0
         self.col_maps: List[torch.Tensor] = []
         self.step_of: List[Optional[int]] = []   # layer index -> forward step (None = fused head)
@@ -255,7 +260,7 @@ class MlpProgram:
             L.act_groups = act_groups
             L.aux_groups = 0 if enc is None else enc.width // 8
             L.enc_id = 0 if spec.enc_id is None else spec.enc_id
-            L.out_tiles = _tiles(spec.out)
+            L.out_tiles = _tiles(spec.out, self.wide and spec.to_logits is None)
             L.relu = 1 if spec.relu else 0
             L.save_in_slot = L.save_out_slot = L.mask_slot = L.save_enc_slot = L.head_off = -1
             if spec.act_in > 0 and last_producer not in saved_already:
@@ -274,6 +279,9 @@ class MlpProgram:
                 slot_off += spec.out
                 last_producer = i
             else:
+                if self.wide:
+                    raise NotImplementedError("a 512-wide model needs its logits heads to read a "
+                                              "hidden layer (fused heads only)")
                 L.dst, L.out_col, L.out_n = 1, spec.to_logits[0], spec.to_logits[1]
             groups = L.act_groups + L.aux_groups
             L.w_off, L.b_off = w_off, b_off
@@ -302,6 +310,7 @@ class MlpProgram:
             raise NotImplementedError("more than 4096 bias + fused-head floats")
         self.fwd = fwd
         self.saved_channels = slot_off
+        self.mask_words = 512 if self.wide else 256     # uint32 of ReLU sign bits per slot and block
         self.num_grad_floats = g_off
         self.packed_fwd = torch.zeros((max(w_off, 1),), dtype=torch.float32, device=self.device)
         self.bias_buf = torch.zeros((b_off,), dtype=torch.float32, device=self.device)
@@ -311,6 +320,7 @@ class MlpProgram:
         the network from the outputs to the first layer."""
         bwd = FfnMlpChain()
         self._fill_encodings(bwd)
+        bwd.wide = self.fwd.wide
         for s in range(MAX_STEPS):
             bwd.slot_channels[s] = self.fwd.slot_channels[s]
             bwd.slot_offset[s] = self.fwd.slot_offset[s]
@@ -329,7 +339,7 @@ class MlpProgram:
             if len(hidden) > 1 or len(heads) > 1:
                 raise NotImplementedError("a layer may feed at most one hidden layer and one head")
             st = FfnStep()
-            st.out_tiles = _tiles(self.layers[j].out)
+            st.out_tiles = _tiles(self.layers[j].out, self.wide)
             st.act_groups = 0 if not hidden else self.layers[hidden[0]].out // 8
             st.aux_groups = 4 if heads else 0
             st.relu = 0
@@ -515,12 +525,12 @@ class MlpProgram:
         """Size (in floats) of the per-call training buffer: activation slabs followed by
         the ReLU sign masks (256 words per 32-sample block and slab)."""
         blocks = (n + 31) // 32
-        return self.saved_channels * 32 * blocks + self.fwd.num_slots * 256 * blocks
+        return self.saved_channels * 32 * blocks + self.fwd.num_slots * self.mask_words * blocks
 
     def _split_saved(self, saved: torch.Tensor, n: int):
         blocks = (n + 31) // 32
         acts = self.saved_channels * 32 * blocks
-        return saved[:acts], saved[acts:acts + self.fwd.num_slots * 256 * blocks]
+        return saved[:acts], saved[acts:acts + self.fwd.num_slots * self.mask_words * blocks]
 
     def forward(self, positions: torch.Tensor, views: Optional[torch.Tensor],
                 saved: Optional[torch.Tensor] = None) -> torch.Tensor:

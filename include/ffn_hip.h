@@ -193,7 +193,7 @@ typedef struct ffn_step {
     int32_t enc_id;        /* forward: 0 = position encoding, 1 = view encoding        */
     int32_t lg_col;        /* backward: first d_logits column feeding this step        */
     int32_t lg_n;
-    int32_t out_tiles;     /* ceil(out/32): 8, 4, 2 or 1                               */
+    int32_t out_tiles;     /* ceil(out/32): 8, 4, 2 or 1 (wide chains: 16, 8, 4 or 2)  */
     int32_t relu;          /* forward: ReLU on the output                              */
     int32_t dst;           /* forward: 0 = activation slab, 1 = logits [out_col,+out_n)*/
     int32_t out_col;
@@ -226,7 +226,11 @@ typedef struct ffn_mlp_chain {
                                               entries num_slots.. of the two arrays below
                                               describe the encoding-feature slabs        */
     int32_t bias_floats;                   /* total padded bias floats (<= 4096)      */
-    int32_t reserved;
+    int32_t wide;                          /* != 0: some layer is wider than 256 channels:
+                                              two waves share a 32-sample block and a 64 KiB
+                                              slab, out_tiles may be 16 and must be even,
+                                              act_groups <= 64, heads must be fused; the mask
+                                              buffer holds 512 uint32 per slot and block     */
     int32_t slot_channels[FFN_MAX_STEPS];  /* channels of each slab (multiple of 32)  */
     int64_t slot_offset[FFN_MAX_STEPS];    /* sum of channels of the slabs before it  */
 } ffn_mlp_chain;

@@ -253,8 +253,10 @@ def main():
                                                    embedding_size=48),
         "nerf": lambda: ffn.NeRF(8, 256, 9, 10, 3, 4, [4], True),
         "nerf_small": lambda: ffn.NeRF(4, 64, 5, 6, 2, 3, [2], False),
+        # BASELINE config 5: 512-wide hidden layers (train_tiny_nerf.py gaussian, --num-channels 512)
+        "gaussian512": lambda: ffn.GaussianFourierMLP(3, 4, 10.0, num_channels=512),
     }
-    full_size = {"positional", "nerf"}
+    full_size = {"positional", "nerf", "gaussian512"}
     for name, make in models.items():
         torch.manual_seed(77)
         model = make()

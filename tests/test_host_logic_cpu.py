@@ -55,6 +55,7 @@ def test_encoding_internal_order_covers_every_natural_column_once():
     lambda: ffn.NeRF(8, 256, 9, 10, 3, 4, [4], True),
     lambda: ffn.MLP(3, 4, num_channels=64),
     lambda: ffn.NeRF(4, 64, 5, 6, 2, 3, [2], False),
+    lambda: ffn.GaussianFourierMLP(3, 4, 10.0, num_channels=512),
 ])
 def test_chain_and_wgrad_plans(make):
     model = make()
@@ -68,7 +69,7 @@ def test_chain_and_wgrad_plans(make):
     for k in range(prog.fwd.num_steps):
         st = prog.fwd.step[k]
         assert st.act_groups % 4 == 0 and st.aux_groups % 4 == 0
-        assert st.out_tiles in (1, 2, 4, 8)
+        assert st.out_tiles in ((2, 4, 8, 16) if prog.wide else (1, 2, 4, 8))
     hidden = [i for i, sp in enumerate(prog.layers) if sp.to_logits is None]
     assert prog.fwd.num_slots == len(hidden)
     # a logits head that reads a hidden layer rides in that layer's epilogue
@@ -123,7 +124,9 @@ def test_chain_and_wgrad_plans(make):
 
 def test_unsupported_shapes_raise_not_fall_back():
     with pytest.raises(NotImplementedError):
-        _plan(ffn.GaussianFourierMLP(3, 4, 10.0, num_channels=512))
+        _plan(ffn.GaussianFourierMLP(3, 4, 10.0, num_channels=1024))
+    with pytest.raises(NotImplementedError):       # biases of a 512-wide NeRF exceed the LDS copy
+        _plan(ffn.NeRF(8, 512, 9, 10, 3, 4, [4], True))
     with pytest.raises(NotImplementedError):
         _plan(ffn.MLP(3, 4, num_channels=96))
     model = ffn.MLP(3, 4, num_channels=32)

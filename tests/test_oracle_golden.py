@@ -106,7 +106,7 @@ def _fourier_params(g, name):
     return a, b, ws, bs
 
 
-@pytest.mark.parametrize("name", ["mlp", "basic", "positional", "gaussian"])
+@pytest.mark.parametrize("name", ["mlp", "basic", "positional", "gaussian", "gaussian512"])
 def test_fourier_mlp_forward_and_grads(golden, name):
     g = golden("models")
     a, b, ws, bs = _fourier_params(g, name)
