@@ -40,7 +40,7 @@ def parse_args():
     ap.add_argument("--size", type=int, default=400)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-render", action="store_true", help="skip the frames/sec leg")
-    ap.add_argument("--model", default="tiny", choices=["tiny", "nerf"],
+    ap.add_argument("--model", default="tiny", choices=["tiny", "nerf", "gaussian512"],
                     help="tiny = BASELINE configs[1] (the metric's config); nerf = configs[2]-shaped "
                          "full NeRF (8x256, skip, view branch), use with --samples 128")
     return ap.parse_args()
@@ -148,6 +148,8 @@ def main():
     torch.manual_seed(20080524)
     if args.model == "nerf":
         model = ffn.NeRF(8, 256, 9, 10, 3, 4, [4], True).to(device)
+    elif args.model == "gaussian512":
+        model = ffn.GaussianFourierMLP(3, 4, 10.0, num_channels=512).to(device)
     else:
         model = ffn.PositionalFourierMLP(3, 4, 5.5).to(device)
     intr, poses = synthetic_rig(args.cameras, args.size)
@@ -280,10 +282,13 @@ def main():
             "data": "synthetic",
             "config": {"workload": "antinous_400-shaped %s train step: %d cams x %dx%d, %s, "
                                    "%d samples/ray, %d rays/GPU/step, exact-f32 MFMA"
-                                   % ("tiny NeRF" if args.model == "tiny" else "full NeRF",
+                                   % ({"tiny": "tiny NeRF", "nerf": "full NeRF",
+                                       "gaussian512": "512-wide Gaussian-feature"}[args.model],
                                       args.cameras, args.size, args.size,
-                                      "PositionalFourierMLP(3,4,5.5) 256ch" if args.model == "tiny"
-                                      else "NeRF(8,256,9,10,3,4,[4],True)", args.samples, args.rays),
+                                      {"tiny": "PositionalFourierMLP(3,4,5.5) 256ch",
+                                       "nerf": "NeRF(8,256,9,10,3,4,[4],True)",
+                                       "gaussian512": "GaussianFourierMLP(3,4,10.0,num_channels=512)"}[args.model],
+                                      args.samples, args.rays),
                        "rays_per_gpu": args.rays, "samples_per_ray": args.samples,
                        "parallelism": "dp%d" % world, "final_loss": float(loss)},
             "roofline": {"bound": "mfma", "kernel": names[dominant],

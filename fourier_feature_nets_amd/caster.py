@@ -112,11 +112,14 @@ class TrainEngine:
         return rays[rank * per:(rank + 1) * per].contiguous()
 
     # ------------------------------------------------------------------ train / eval
-    def train_step(self, dataset, batch, step: int, lr: float) -> torch.Tensor:
+    def train_step(self, dataset, batch, step: int, lr: float,
+                   rays: Optional[torch.Tensor] = None) -> torch.Tensor:
         """zero_grad -> loss -> backward -> clip value -> clip norm -> Adam, as
-        ray_caster.py:319-329.  Returns the (global) batch loss as a device scalar."""
+        ray_caster.py:319-329.  Returns the (global) batch loss as a device scalar.
+        ``rays`` = the already filtered global ray ids of ``batch`` (see
+        ``RayDataset.epoch_ray_ids``), which saves the per-step device-to-host sync."""
         sampler = dataset.sampler
-        all_rays = dataset.ray_ids(batch)
+        all_rays = dataset.ray_ids(batch) if rays is None else rays
         global_count = int(all_rays.numel())
         rays = self.shard(all_rays)
         count = int(rays.numel())
@@ -323,12 +326,15 @@ class Raycaster(nn.Module):
                 order = torch.from_numpy(order).to(engine.device)
             else:
                 order = torch.randperm(num_rays, device=engine.device)
-            for start in range(0, num_rays, batch_size):
+            # valid-ray filter of the whole epoch in one go (one sync per epoch, not per step)
+            epoch_rays, bounds = train_dataset.epoch_ray_ids(order, batch_size)
+            for bi, start in enumerate(range(0, num_rays, batch_size)):
                 if step > num_steps:
                     break
                 lr = learning_rate_at(learning_rate, step, decay_rate, decay_steps)
                 batch = order[start:min(start + batch_size, num_rays)]
-                engine.train_step(train_dataset, batch, step, lr)
+                engine.train_step(train_dataset, batch, step, lr,
+                                  rays=epoch_rays[bounds[bi]:bounds[bi + 1]])
 
                 if step < 10 or step % report_interval == 0:
                     engine.check_finite()

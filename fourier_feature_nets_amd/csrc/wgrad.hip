@@ -280,8 +280,15 @@ wgrad_unit_kernel(const ffn_mlp_chain ch, const ffn_wgrad_unit* __restrict__ uni
     const int64_t num_blocks = (n + 31) / 32;
     const int seg_lo = seg_start[blockIdx.x], seg_hi = seg_start[blockIdx.x + 1];
     for (int si = seg_lo; si < seg_hi; ++si) {
-        const ffn_wgrad_segment seg = segments[si];
-        if (seg.blk_end <= seg.blk_begin) continue;
+        ffn_wgrad_segment seg = segments[si];
+        // the host may plan for a rounded-up block count (one plan serves a range of batch
+        // sizes): clamp, and give the reducer zeros for a segment that fell off the end
+        if (seg.blk_end > num_blocks) seg.blk_end = num_blocks;
+        if (seg.blk_end <= seg.blk_begin) {
+            float* out = partials + (int64_t)(seg.slot + (threadIdx.x >> 6)) * kPartialFloats;
+            for (int e = threadIdx.x & 63; e < kPartialFloats; e += 64) out[e] = 0.0f;
+            continue;
+        }
         const ffn_wgrad_unit unit = units[seg.job];
         if (unit.kind == 1) {
             head_segment(ch, unit, seg, smem, saved, d_logits, n, num_blocks, partials);

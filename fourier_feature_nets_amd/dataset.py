@@ -272,6 +272,24 @@ class ImageDataset(RayDataset):
             rays = rays[self._subsample_mask[rays % sampler.rays_per_camera]]
         return sampler.valid_index(rays)
 
+    def epoch_ray_ids(self, order: torch.Tensor, batch_size: int):
+        """One epoch at once: what ``ray_ids`` would return for every consecutive
+        ``batch_size`` slice of ``order`` -- as one device tensor plus the host-side slice
+        boundaries.  One device-to-host sync per epoch instead of one per step; the per-step
+        sets and their order are exactly those of the per-batch filter."""
+        sampler = self.sampler
+        local = sampler._index_tensor(order)
+        index = self._mode_index()
+        rays = local if index is None else index[local]
+        keep = sampler.valid[rays] != 0
+        if self._subsample_mask is not None:
+            keep &= self._subsample_mask[rays % sampler.rays_per_camera]
+        total = int(rays.numel())
+        ends = torch.arange(batch_size, total + batch_size, batch_size, device=rays.device).clamp_(max=total)
+        csum = torch.cumsum(keep, 0, dtype=torch.int64)
+        bounds = [0] + csum[ends - 1].cpu().tolist() if total else [0]
+        return rays[keep], bounds
+
     def to_valid(self, idx: List[int]) -> List[int]:
         return self.sampler.to_valid(idx)
 

@@ -408,24 +408,29 @@ class MlpProgram:
     @staticmethod
     def _split(costs: List[int], blocks: int, workers: int):
         """Contiguous, cost-balanced split of the job-major (job, block) sequence.
-        Returns (segments as (job, blk_begin, blk_end), starts per worker)."""
+        Returns (segments as (job, blk_begin, blk_end), starts per worker).  Worker w ends
+        where the running cost crosses (w+1)/workers of the total, rounded to the nearest
+        block -- rounding errors do not pile up on the last worker."""
         total = sum(c * blocks for c in costs)
-        target = -(-total // workers) if total else 0
         segs, starts = [], [0]
-        job, blk = 0, 0
+        job, blk, cum = 0, 0, 0
         for w in range(workers):
-            budget = target
-            last = w == workers - 1
-            while job < len(costs) and (budget > 0 or last):
+            boundary = total * (w + 1) / workers
+            while job < len(costs):
                 left = blocks - blk
-                take = left if last else min(left, budget // costs[job])
+                if w == workers - 1:
+                    take = left
+                else:
+                    take = min(left, int((boundary - cum) / costs[job] + 0.5))
                 if take <= 0:
                     break
                 segs.append((job, blk, blk + take))
-                budget -= take * costs[job]
+                cum += take * costs[job]
                 blk += take
                 if blk == blocks:
                     job, blk = job + 1, 0
+                else:
+                    break
             starts.append(len(segs))
         assert job == len(costs), "work left unassigned"
         return segs, starts
@@ -512,13 +517,25 @@ class MlpProgram:
                       _dev(dst), _stream())
 
     # ------------------------------------------------------------------ launches
+    @staticmethod
+    def plan_blocks(n: int) -> int:
+        """Block count the weight-gradient plan is made for: the real count rounded up to 6
+        significant bits (<= 1.6 % more), so that batches whose valid-ray count wobbles from
+        step to step share one plan; the kernel clamps the plan to the real count."""
+        blocks = (n + 31) // 32
+        if blocks <= 64:
+            return blocks
+        unit = 1 << (blocks.bit_length() - 6)
+        return -(-blocks // unit) * unit
+
     def workspace(self, n: int) -> Workspace:
-        ws = self._workspaces.get(n)
+        key = self.plan_blocks(n)
+        ws = self._workspaces.get(key)
         if ws is None:
-            if len(self._workspaces) >= 4:
+            if len(self._workspaces) >= 8:
                 self._workspaces.clear()
-            ws = Workspace(self, n)
-            self._workspaces[n] = ws
+            ws = Workspace(self, key * 32)
+            self._workspaces[key] = ws
         return ws
 
     def saved_floats(self, n: int) -> int:

@@ -276,7 +276,9 @@ int ffn_mlp_backward_data(const ffn_mlp_chain* chain, const float* packed_wt,
  * exist (quadrant id = 2*m_half + n_half when both sides are wider than 128 channels,
  * otherwise the half index of the wide side, otherwise 0); when fewer than four exist, wave
  * w takes quadrant w % Q and the (w / Q)-th share of every block's samples.  Each wave
- * writes one partial of ffn_mlp_wgrad_partial_floats() floats into slot segment.slot + w. */
+ * writes one partial of ffn_mlp_wgrad_partial_floats() floats into slot segment.slot + w.
+ * Segments may be planned for more blocks than ceil(n/32): the kernel clamps blk_end and
+ * writes zero partials for segments that lie entirely past the end. */
 typedef struct ffn_wgrad_segment {
     int32_t job;
     int32_t slot;

@@ -312,3 +312,46 @@ def test_micro_batched_step_equals_single_launch(golden):
         results.append((loss, engine.flat.clone()))
     assert abs(results[0][0] - results[1][0]) < 1e-6
     np.testing.assert_allclose(results[0][1].cpu().numpy(), results[1][1].cpu().numpy(), rtol=0, atol=2e-6)
+
+
+def test_epoch_filter_equals_per_batch_filter():
+    """The once-per-epoch valid-ray compaction hands every step exactly the rays (and order)
+    the per-batch filter of ray_sampler.py:283-295 / image_dataset.py:364-386 would."""
+    import fourier_feature_nets_amd as ffn
+    ds = _quiet(ffn.ImageDataset.load, SCENE, "train", 8, True, False)
+    for mode in (ffn.RayDataset.Mode.Full, ffn.RayDataset.Mode.Center, ffn.RayDataset.Mode.Sparse):
+        ds.mode = mode
+        gen = torch.Generator().manual_seed(int(mode.value) + 5)
+        order = torch.randperm(len(ds), generator=gen).to(dev())
+        for batch_size in (7, 64, len(ds) + 3):
+            rays, bounds = ds.epoch_ray_ids(order, batch_size)
+            starts = list(range(0, len(ds), batch_size))
+            assert len(bounds) == len(starts) + 1 and bounds[-1] == rays.numel()
+            for bi, start in enumerate(starts):
+                exp = ds.ray_ids(order[start:start + batch_size])
+                assert torch.equal(rays[bounds[bi]:bounds[bi + 1]], exp)
+
+
+def test_wgrad_plan_reuse_across_batch_sizes(golden):
+    """One weight-gradient plan serves every sample count of its bucket: the gradients of a
+    smaller batch computed with the plan of a larger one are those of its own exact plan."""
+    from fourier_feature_nets_amd.mlp_engine import MlpProgram
+    g = golden("models")
+    from tests.test_kernels_gpu import _load_fourier
+    model, _ = _load_fourier(g, "positional")
+    torch.manual_seed(9)
+    n_big, n_small = 65 * 32 * 4, 65 * 32 * 4 - 32 * 3 - 5
+    assert MlpProgram.plan_blocks(n_big) == MlpProgram.plan_blocks(n_small) != (n_small + 31) // 32
+    x = (torch.rand(n_big, 3) * 2 - 1).to(dev())
+    probe = torch.randn(n_big, 4).to(dev()) / n_big
+    grads = []
+    for warm in (False, True):
+        model.zero_grad()
+        model._prog = None                       # fresh program: empty plan cache
+        if warm:                                 # plan made for the larger batch first
+            (model(x) * probe).sum().backward()
+            model.zero_grad()
+        (model(x[:n_small]) * probe[:n_small]).sum().backward()
+        grads.append([p.grad.clone() for p in model.parameters() if p.grad is not None])
+    for a, b in zip(*grads):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-5, atol=1e-7)
