@@ -258,7 +258,8 @@ def main():
         # HBM bytes per launch from the PMC passes committed under profiles/ (same workload)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-        symbol = {"fwd": "ffn::mlp_forward_kernel<1>", "dgrad": "ffn::mlp_backward_data_kernel",
+        symbol = {"fwd": "ffn::mlp_forward_kernel<1, false>",
+                  "dgrad": "ffn::mlp_backward_data_kernel<false>",
                   "wgrad": "ffn::wgrad_unit_kernel"}
         if os.path.exists(tpath):
             with open(tpath) as f:
