@@ -131,7 +131,7 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     group = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:      # under torch.distributed.run: RCCL even for 1 rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -198,7 +198,7 @@ def main():
         return engine.train_step(dataset, batch, step, lr)
 
     def barrier():
-        if world > 1:
+        if group is not None:
             import torch.distributed as dist
             dist.barrier(group=group)
 
@@ -232,7 +232,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     render_s = time.perf_counter() - r0
-    if world > 1:
+    if group is not None:
         import torch.distributed as dist
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=group)
@@ -310,7 +310,7 @@ def main():
         else:
             result["cpu_baseline"] = None
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if group is not None:
         import torch.distributed as dist
         dist.destroy_process_group()
 
