@@ -300,6 +300,10 @@ class Raycaster(nn.Module):
                                                         val_dataset.num_samples, False)
         engine = TrainEngine(self.model, weight_decay, self.process_group)
         self.engine = engine
+        if self.process_group is not None:
+            torch.distributed.broadcast(engine.flat, torch.distributed.get_global_rank(self.process_group, 0),
+                                        group=self.process_group)
+            self.model.invalidate_packed()
         step = 0
         start_time = time.time()
         log = []
@@ -326,6 +330,11 @@ class Raycaster(nn.Module):
                 order = torch.from_numpy(order).to(engine.device)
             else:
                 order = torch.randperm(num_rays, device=engine.device)
+            if self.process_group is not None:
+                # data parallel: every rank walks rank 0's permutation (and must hold the same
+                # initial weights: broadcast once, below)
+                torch.distributed.broadcast(order, torch.distributed.get_global_rank(self.process_group, 0),
+                                            group=self.process_group)
             # valid-ray filter of the whole epoch in one go (one sync per epoch, not per step)
             epoch_rays, bounds = train_dataset.epoch_ray_ids(order, batch_size)
             for bi, start in enumerate(range(0, num_rays, batch_size)):

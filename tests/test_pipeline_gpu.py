@@ -355,3 +355,38 @@ def test_wgrad_plan_reuse_across_batch_sizes(golden):
         grads.append([p.grad.clone() for p in model.parameters() if p.grad is not None])
     for a, b in zip(*grads):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-5, atol=1e-7)
+
+
+def test_fit_over_an_rccl_group_of_one_rank(golden):
+    """fit() with a torch.distributed (nccl = RCCL) group: permutation / weight broadcast, the
+    gradient all-reduce and the sharding code run on the GPU; with one rank the trajectory must
+    be the single-process one."""
+    import socket
+    import torch.distributed as dist
+    import fourier_feature_nets_amd as ffn
+    g = golden("training")
+    finals = []
+    for use_group in (False, True):
+        model = _small_model(g)
+        train = _quiet(ffn.ImageDataset.load, SCENE, "train", 16, True, True, anneal_start=0.2,
+                       num_anneal_steps=8)
+        val = _quiet(ffn.ImageDataset.load, SCENE, "val", 16, True, False)
+        train.sampler.noise_source = "host"
+        torch.manual_seed(4242)
+        np.random.seed(4242)
+        caster = ffn.Raycaster(model)
+        if use_group:
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                port = sock.getsockname()[1]
+            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0,
+                                    world_size=1, device_id=dev())
+            caster.process_group = dist.group.WORLD
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                caster.fit(train, val, 64, 5e-4, 6, 1000, 4, 0.1, 25000, 0.0, [])
+        finally:
+            if use_group:
+                dist.destroy_process_group()
+        finals.append(caster.engine.flat.clone())
+    assert torch.equal(finals[0], finals[1])
