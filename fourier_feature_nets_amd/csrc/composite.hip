@@ -14,14 +14,36 @@ __device__ __forceinline__ float softplus_torch(float x) {
 }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// Cross-lane scans on the DPP path (row_shr 1/2/4/8 inside each row of 16 lanes, then
+// row_bcast15 / row_bcast31 across rows): six VALU instructions with a DPP modifier instead of
+// six ds_bpermute round trips through the LDS pipeline (~100+ cycles each, serially dependent).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float old, float src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old),
+                                                                  __builtin_bit_cast(int, src), CTRL,
+                                                                  ROW_MASK, 0xf, false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_u(unsigned old, unsigned src) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, ROW_MASK, 0xf, false);
+}
+constexpr int kRowShr1 = 0x111, kRowShr2 = 0x112, kRowShr4 = 0x114, kRowShr8 = 0x118;
+constexpr int kRowBcast15 = 0x142, kRowBcast31 = 0x143, kWaveShr1 = 0x138;
+
 // inclusive multiplicative scan over the 64 lanes of a wave
-__device__ __forceinline__ float wave_scan_mul(float v, int lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const float up = __shfl_up(v, off, 64);
-        if (lane >= off) v *= up;
-    }
+__device__ __forceinline__ float wave_scan_mul(float v, int) {
+    v *= dpp_f<kRowShr1, 0xf>(1.0f, v);
+    v *= dpp_f<kRowShr2, 0xf>(1.0f, v);
+    v *= dpp_f<kRowShr4, 0xf>(1.0f, v);
+    v *= dpp_f<kRowShr8, 0xf>(1.0f, v);
+    v *= dpp_f<kRowBcast15, 0xa>(1.0f, v);
+    v *= dpp_f<kRowBcast31, 0xc>(1.0f, v);
     return v;
+}
+// value of lane i-1 (lane 0 gets `first`)
+__device__ __forceinline__ float wave_shift_up(float v, float first) { return dpp_f<kWaveShr1, 0xf>(first, v); }
+__device__ __forceinline__ float wave_last(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 // inclusive additive suffix scan (lane i gets sum over lanes >= i)
 __device__ __forceinline__ float wave_suffix_add(float v, int lane) {
@@ -33,9 +55,32 @@ __device__ __forceinline__ float wave_suffix_add(float v, int lane) {
     return v;
 }
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    v += dpp_f<kRowShr1, 0xf>(0.0f, v);
+    v += dpp_f<kRowShr2, 0xf>(0.0f, v);
+    v += dpp_f<kRowShr4, 0xf>(0.0f, v);
+    v += dpp_f<kRowShr8, 0xf>(0.0f, v);
+    v += dpp_f<kRowBcast15, 0xa>(0.0f, v);
+    v += dpp_f<kRowBcast31, 0xc>(0.0f, v);
+    return wave_last(v);
+}
+// max over the wave of the 64-bit key (hi, lo), returned in every lane
+__device__ __forceinline__ void wave_max_key(unsigned& hi, unsigned& lo) {
+#define FFN_KEY_STEP(CTRL, MASK)                                                               \
+    {                                                                                          \
+        const unsigned oh = dpp_u<CTRL, MASK>(0u, hi), ol = dpp_u<CTRL, MASK>(0u, lo);         \
+        const bool take = oh > hi || (oh == hi && ol > lo);                                    \
+        hi = take ? oh : hi;                                                                   \
+        lo = take ? ol : lo;                                                                   \
+    }
+    FFN_KEY_STEP(kRowShr1, 0xf)
+    FFN_KEY_STEP(kRowShr2, 0xf)
+    FFN_KEY_STEP(kRowShr4, 0xf)
+    FFN_KEY_STEP(kRowShr8, 0xf)
+    FFN_KEY_STEP(kRowBcast15, 0xa)
+    FFN_KEY_STEP(kRowBcast31, 0xc)
+#undef FFN_KEY_STEP
+    hi = (unsigned)__builtin_amdgcn_readlane((int)hi, 63);
+    lo = (unsigned)__builtin_amdgcn_readlane((int)lo, 63);
 }
 
 struct SampleTerms {
@@ -88,8 +133,7 @@ composite_fwd_kernel(const float4* __restrict__ logits, const float* __restrict_
             const bool active = s < S;
             const SampleTerms q = load_terms(lg, tr, s, S, active, nan_flag);
             const float incl = wave_scan_mul(q.tau, lane);
-            float excl = __shfl_up(incl, 1, 64);
-            if (lane == 0) excl = 1.0f;
+            const float excl = wave_shift_up(incl, 1.0f);
             const float T = carry * excl;
             const float w = q.alpha * T;
             cr += w * q.r; cg += w * q.g; cb += w * q.b;
@@ -98,16 +142,16 @@ composite_fwd_kernel(const float4* __restrict__ logits, const float* __restrict_
                 asum += w;
                 if (w > best_w) { best_w = w; best_s = s; }
             }
-            carry *= __shfl(incl, 63, 64);
+            carry *= wave_last(incl);
         }
         cr = wave_sum(cr); cg = wave_sum(cg); cb = wave_sum(cb); asum = wave_sum(asum);
-        // argmax with first-occurrence tie break
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const float ow = __shfl_xor(best_w, off, 64);
-            const int os = __shfl_xor(best_s, off, 64);
-            if (ow > best_w || (ow == best_w && os < best_s)) { best_w = ow; best_s = os; }
-        }
+        // argmax with first-occurrence tie break: weights are >= 0, so their bit patterns order
+        // like unsigned integers; the low word prefers the smaller sample index, 0 = "none"
+        unsigned key_hi = best_w < 0.0f ? 0u : __builtin_bit_cast(unsigned, best_w);
+        unsigned key_lo = best_w < 0.0f ? 0u : 0xffffffffu - (unsigned)best_s;
+        wave_max_key(key_hi, key_lo);
+        best_w = key_lo == 0u ? -1.0f : __builtin_bit_cast(float, key_hi);
+        best_s = key_lo == 0u ? 0 : (int)(0xffffffffu - key_lo);
         if (lane == 0) {
             color[ray * 3 + 0] = cr; color[ray * 3 + 1] = cg; color[ray * 3 + 2] = cb;
             alpha_out[ray] = asum;
@@ -141,10 +185,9 @@ blend_weights_kernel(const float* __restrict__ t, const float* __restrict__ sigm
                 tau = u < 1.0f ? u : 1.0f;
             }
             const float incl = wave_scan_mul(tau, lane);
-            float excl = __shfl_up(incl, 1, 64);
-            if (lane == 0) excl = 1.0f;
+            const float excl = wave_shift_up(incl, 1.0f);
             if (s < S) weights[(int64_t)ray * S + s] = alpha * (carry * excl);
-            carry *= __shfl(incl, 63, 64);
+            carry *= wave_last(incl);
         }
     }
 }
@@ -173,10 +216,9 @@ composite_bwd_kernel(const float4* __restrict__ logits, const float* __restrict_
             const int s = row * 64 + lane;
             q[row] = load_terms(lg, tr, s, S, s < S, nullptr);
             const float incl = wave_scan_mul(q[row].tau, lane);
-            float excl = __shfl_up(incl, 1, 64);
-            if (lane == 0) excl = 1.0f;
+            const float excl = wave_shift_up(incl, 1.0f);
             T[row] = carry * excl;
-            carry *= __shfl(incl, 63, 64);
+            carry *= wave_last(incl);
         }
         float tail = 0.0f;  // sum of g*w over all later rows
 #pragma unroll

@@ -1,0 +1,66 @@
+"""HBM-bound kernels of the path at the bench shape: achieved GB/s of the ALGORITHMIC bytes
+ against the 8 TB/s peak.   python scripts/microbench_hbm.py [--rays R --samples S]"""
+import argparse
+import json
+import math
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from fourier_feature_nets_amd import ops  # noqa: E402
+from oracle import ffn_oracle as orc  # noqa: E402  (frequency table only)
+
+
+def timed(fn, iters=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rays", type=int, default=65536)
+    ap.add_argument("--samples", type=int, default=64)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    R, S = args.rays, args.samples
+    torch.manual_seed(1)
+    out = {}
+    logits = torch.randn(R, S, 4, device=dev)
+    t = torch.sort(torch.rand(R, S, device=dev) * 4 + 2, dim=-1)[0].contiguous()
+    sec = timed(lambda: ops.composite_fwd(logits, t, False))
+    out["composite_fwd"] = (R * (20 * S + 20), sec)
+    d_color = torch.randn(R, 3, device=dev)
+    d_alpha = torch.randn(R, device=dev)
+    sec = timed(lambda: ops.composite_bwd(logits, t, d_color, d_alpha))
+    out["composite_bwd"] = (R * (20 * S + 16 * S + 16), sec)
+    n = R * S
+    x = torch.rand(n, 3, device=dev) * 2 - 1
+    b = orc.positional_b_values(5.5, 256, 3).contiguous().to(dev)
+    a = torch.ones(b.shape[1], device=dev)
+    sec = timed(lambda: ops.fourier_encode(x, b, a, math.pi, False), iters=5)
+    out["fourier_encode (tiny: 2F = 510)"] = (n * (12 + 4 * 2 * b.shape[1]), sec)
+    bn = torch.zeros(3, 30)
+    for k in range(10):
+        for d in range(3):
+            bn[d, 3 * k + d] = 2.0 ** k
+    bn = bn.to(dev)
+    sec = timed(lambda: ops.fourier_encode(x, bn, None, 1.0, True), iters=5)
+    out["fourier_encode (NeRF: 63)"] = (n * (12 + 4 * 63), sec)
+    res = {k: {"algorithmic_bytes": v[0], "us": round(v[1] * 1e6, 1),
+               "GB/s": round(v[0] / v[1] / 1e9, 1), "of_8TB/s": round(v[0] / v[1] / 8e12, 3)}
+           for k, v in out.items()}
+    print(json.dumps({"rays": R, "samples": S, "kernels": res}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
