@@ -567,6 +567,8 @@ class MlpProgram:
         """Fills ``grads`` (flat, num_grad_floats) from d(loss)/d(logits) (N,4) and the
         activations ``saved`` by the matching forward call."""
         n = positions.shape[0]
+        if n == 0:                      # an empty batch contributes no gradient
+            return grads.zero_()
         ws = self.workspace(n)
         saved, masks = self._split_saved(saved, n)
         if self.bwd.num_steps > 0:

@@ -441,3 +441,16 @@ def test_models_refuse_cpu():
     model = ffn.MLP(3, 4, num_channels=32)
     with pytest.raises(RuntimeError, match="GPU"):
         model(torch.zeros(4, 3))
+
+
+def test_fused_mlp_empty_batch(golden):
+    """Zero samples: (0,4) logits forward, all-zero gradients backward (autograd of the
+    reference modules on an empty batch)."""
+    g = golden("models")
+    model, _ = _load_fourier(g, "mlp")
+    y = model(torch.zeros((0, 3), device=dev()))
+    assert y.shape == (0, 4)
+    y.sum().backward()
+    for par in model.parameters():
+        if par.requires_grad:
+            assert par.grad is not None and float(par.grad.abs().max()) == 0.0
