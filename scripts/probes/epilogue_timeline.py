@@ -1,3 +1,8 @@
+"""Cycle counts of the phases of every step of the fused forward(train) / backward-data kernels:
+init (bias -> accumulators), K loops (+ feature bursts), next-step weight prefetch, epilogue loop,
+mask store.  Build the instrumented library first:
+    python scripts/probes/make_dbg_library.py epilogue
+    FFN_HIP_LIBRARY=$PWD/scripts/probes/variants/libffn_dbg.so python scripts/probes/epilogue_timeline.py"""
 import ctypes, os, sys
 import torch
 sys.path.insert(0, os.getcwd())

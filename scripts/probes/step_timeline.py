@@ -1,6 +1,6 @@
 """One-off: cycle timestamps of one wave at every step boundary of the fused training forward
-and backward-data kernels (debug build of the library with s_memtime hooks, see DESIGN.md;
-run with FFN_HIP_LIBRARY=scripts/probes/variants/libffn_dbg.so)."""
+and backward-data kernels (instrumented build: python scripts/probes/make_dbg_library.py steps;
+run with FFN_HIP_LIBRARY=$PWD/scripts/probes/variants/libffn_dbg.so)."""
 import ctypes, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
