@@ -8,6 +8,7 @@ for that path.  There is no CPU fallback: using a model or sampler without a GPU
 from .cameras import CameraInfo, Resolution, orbit
 from .caster import LogEntry, Raycaster, TrainEngine
 from .dataset import ImageDataset, RayDataset
+from .occupancy import OccupancyGrid
 from .models import (
     BasicFourierMLP,
     FourierFeatureMLP,
@@ -31,6 +32,6 @@ __version__ = "0.1.0"
 
 __all__ = ["__version__", "BasicFourierMLP", "CameraInfo", "ETABar", "FourierFeatureMLP",
            "GaussianFourierMLP", "ImageDataset", "LogEntry", "MLP", "NeRF",
-           "PositionalFourierMLP", "RayDataset", "RaySampler", "RaySamples", "Raycaster",
+           "OccupancyGrid", "PositionalFourierMLP", "RayDataset", "RaySampler", "RaySamples", "Raycaster",
            "RenderResult", "Resolution", "TrainEngine", "Voxels", "calculate_blend_weights",
            "exponential_lr_decay", "linspace", "load_model", "orbit"]

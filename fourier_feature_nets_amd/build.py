@@ -26,6 +26,7 @@ SOURCES = {
     "optim.hip": ["-ffp-contract=off"],
     "mlp.hip": [],
     "wgrad.hip": [],
+    "occupancy.hip": [],
 }
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC,
           "-Wno-unused-result"]

@@ -190,6 +190,7 @@ class Raycaster(nn.Module):
         self._nan_flag = None
         self.shuffle_source = "numpy"     # epoch permutations from np.random like the reference
         self.process_group = None         # set to a torch.distributed group for data parallel
+        self.occupancy = None             # an OccupancyGrid switches on empty-space skipping (no_grad renders)
 
     # ------------------------------------------------------------------ rendering
     def _flag(self, device):
@@ -206,8 +207,18 @@ class Raycaster(nn.Module):
         (ray_caster.py:48-93)."""
         num_rays, num_samples = ray_samples.positions.shape[:2]
         positions = ray_samples.positions.reshape(-1, 3)
-        if self.model.use_view:
-            logits = self.model(positions, ray_samples.view_directions.reshape(-1, 3))
+        views = ray_samples.view_directions.reshape(-1, 3) if self.model.use_view else None
+        if self.occupancy is not None and not torch.is_grad_enabled() and positions.shape[0] > 0:
+            # opt-in empty-space skipping (inference only): the MLP sees the occupied samples
+            pos_c, view_c, index = self.occupancy.compact(positions.contiguous(),
+                                                          None if views is None else views.contiguous())
+            if pos_c.shape[0] > 0:
+                packed = self.model(pos_c, view_c) if views is not None else self.model(pos_c)
+            else:
+                packed = torch.empty((0, 4), dtype=torch.float32, device=positions.device)
+            logits = ops.scatter_logits(packed.contiguous(), index, positions.shape[0])
+        elif views is not None:
+            logits = self.model(positions, views)
         else:
             logits = self.model(positions)
         logits = logits.reshape(num_rays, num_samples, 4)

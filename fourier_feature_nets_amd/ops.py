@@ -176,3 +176,47 @@ def clip_adam(params, grads, exp_avg, exp_avg_sq, step: int, lr: float, weight_d
               c_i64(n), c_f(clip_value), c_f(max_norm), c_f(step_size), c_f(inv_sqrt_bc2),
               c_f(beta1), c_f(beta2), c_f(eps), c_f(weight_decay), _dev(scratch),
               _dev(norm_out), _stream())
+
+
+# --------------------------------------------------------------------------------- occupancy
+def occupancy_build(logits: torch.Tensor, resolution: int, sigma_threshold: float,
+                    dilate: bool) -> torch.Tensor:
+    """K9a/b.  logits (G^3,4) at the cell centres -> bit mask (ceil(G^3/32),) int32."""
+    words = (resolution ** 3 + 31) // 32
+    bits = torch.empty((words,), dtype=torch.int32, device=logits.device)
+    scratch = torch.empty_like(bits) if dilate else None
+    _lib.call("ffn_occupancy_build", _dev(logits), c_i(resolution), c_f(sigma_threshold),
+              c_i(1 if dilate else 0), _dev(scratch, torch.int32), _dev(bits, torch.int32), _stream())
+    return bits
+
+
+def occupancy_compact(positions: torch.Tensor, views: Optional[torch.Tensor], box_min, box_size,
+                      resolution: int, bits: torch.Tensor):
+    """K9c-e.  (N,3) samples -> packed positions / views of the samples in occupied cells and
+    their int32 source index.  One device-to-host sync (the packed count sizes the outputs)."""
+    n = positions.shape[0]
+    dev = positions.device
+    blocks = (n + 255) // 256
+    offsets = torch.empty((blocks,), dtype=torch.int32, device=dev)
+    total = torch.empty((1,), dtype=torch.int64, device=dev)
+    lo, size = _host3(box_min), _host3(box_size)
+    _lib.call("ffn_occupancy_count", _dev(positions), c_i64(n), lo, size, c_i(resolution),
+              _dev(bits, torch.int32), _dev(offsets, torch.int32), _dev(total, torch.int64), _stream())
+    m = int(total.item())
+    out_pos = torch.empty((m, 3), dtype=torch.float32, device=dev)
+    out_view = torch.empty((m, 3), dtype=torch.float32, device=dev) if views is not None else None
+    index = torch.empty((m,), dtype=torch.int32, device=dev)
+    if m > 0:
+        _lib.call("ffn_occupancy_compact", _dev(positions), _dev(views), c_i64(n), lo, size,
+                  c_i(resolution), _dev(bits, torch.int32), _dev(offsets, torch.int32),
+                  _dev(out_pos), _dev(out_view), _dev(index, torch.int32), _stream())
+    return out_pos, out_view, index
+
+
+def scatter_logits(packed: torch.Tensor, index: torch.Tensor, n: int,
+                   empty_sigma_logit: float = -100.0) -> torch.Tensor:
+    """K9f.  (M,4) logits of the evaluated samples -> (N,4), the rest (0,0,0,empty_sigma_logit)."""
+    out = torch.empty((n, 4), dtype=torch.float32, device=index.device)
+    _lib.call("ffn_scatter_logits", _dev(packed), _dev(index, torch.int32), c_i64(packed.shape[0]),
+              c_i64(n), c_f(empty_sigma_logit), _dev(out), _stream())
+    return out

@@ -328,6 +328,35 @@ int ffn_mlp_wgrad_reduce(const ffn_reduce_job* jobs, int num_jobs, const float* 
 
 int64_t ffn_mlp_wgrad_partial_floats(void);
 
+/* ---- K9: empty-space skipping for inference (opt-in).  The reference has no
+ * counterpart on its render path (its octree ray walker, octree.py:418-501, serves only the
+ * lecture visualisations), so parity here is PSNR-level, not sample-level.
+ *
+ * An occupancy grid is resolution^3 bits (cell (ix,iy,iz) = bit ((iz*G + iy)*G + ix), x fastest)
+ * over the box [box_min, box_min + box_size); box_min / box_size are HOST pointers to 3 floats.
+ *
+ * ffn_occupancy_build: logits (G^3,4) = the model evaluated at the cell centres; a cell is
+ *   occupied when softplus(sigma logit) > sigma_threshold; dilate != 0 also marks the 26
+ *   neighbours (needs scratch_bits of the same size).
+ * ffn_occupancy_count: block_offsets (ceil(n/256) int32) <- exclusive scan of the number of
+ *   occupied samples per 256-sample block; *total (device int64) <- their sum.  Samples outside
+ *   the box count as occupied.
+ * ffn_occupancy_compact: packs the occupied samples (order preserved): out_positions /
+ *   out_views (total,3), out_index (total) = their position in the input.
+ * ffn_scatter_logits: out (n,4) <- (0,0,0,empty_sigma_logit) everywhere, then
+ *   out[index[i]] = packed[i]. */
+int ffn_occupancy_build(const float* logits, int resolution, float sigma_threshold, int dilate,
+                        uint32_t* scratch_bits, uint32_t* bits, void* stream);
+int ffn_occupancy_count(const float* positions, int64_t n, const float* box_min,
+                        const float* box_size, int resolution, const uint32_t* bits,
+                        int32_t* block_offsets, int64_t* total, void* stream);
+int ffn_occupancy_compact(const float* positions, const float* views, int64_t n,
+                          const float* box_min, const float* box_size, int resolution,
+                          const uint32_t* bits, const int32_t* block_offsets,
+                          float* out_positions, float* out_views, int32_t* out_index, void* stream);
+int ffn_scatter_logits(const float* packed, const int32_t* index, int64_t m, int64_t n,
+                       float empty_sigma_logit, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -390,3 +390,101 @@ def test_fit_over_an_rccl_group_of_one_rank(golden):
                 dist.destroy_process_group()
         finals.append(caster.engine.flat.clone())
     assert torch.equal(finals[0], finals[1])
+
+
+def _octahedron_model():
+    """A ReLU MLP with hand-set weights: sigma logit = 12 - 60 |x|_1 (dense inside the octahedron
+    |x|_1 < 0.2, empty elsewhere), colour logits vary with |x|_1."""
+    import fourier_feature_nets_amd as ffn
+    model = ffn.MLP(3, 4, num_channels=64)
+    with torch.no_grad():
+        for layer in model.layers:
+            layer.weight.zero_()
+            layer.bias.zero_()
+        for d in range(3):
+            model.layers[0].weight[2 * d, d] = 1.0
+            model.layers[0].weight[2 * d + 1, d] = -1.0
+        model.layers[1].weight[0, :6] = 1.0
+        model.layers[2].weight[0, 0] = 1.0
+        out = model.layers[3]
+        out.weight[3, 0] = -60.0
+        out.bias[3] = 12.0
+        out.weight[0, 0] = 4.0
+        out.bias[0] = -0.5
+        out.weight[1, 0] = -3.0
+        out.bias[1] = 0.7
+        out.bias[2] = 0.3
+    return model.to(dev())
+
+
+def test_occupancy_kernels_against_torch():
+    from fourier_feature_nets_amd import ops
+    torch.manual_seed(3)
+    g = 16
+    logits = torch.randn(g ** 3, 4, device=dev()) * 4
+    sigma = torch.nn.functional.softplus(logits[:, 3])
+    for dilate in (False, True):
+        bits = ops.occupancy_build(logits, g, 0.5, dilate)
+        occ = (sigma > 0.5).reshape(g, g, g)
+        if dilate:
+            occ = torch.nn.functional.max_pool3d(occ[None, None].float(), 3, 1, 1)[0, 0] > 0
+        words = bits.to(torch.int64) & 0xffffffff
+        got = ((words[:, None] >> torch.arange(32, device=dev())) & 1).reshape(-1)[:g ** 3].bool()
+        assert torch.equal(got, occ.reshape(-1))
+    # compaction: order-preserving, samples outside the box are kept
+    n = 70001
+    pos = (torch.rand(n, 3, device=dev()) * 2.4 - 1.2).contiguous()
+    view = torch.randn(n, 3, device=dev())
+    lo, size = [-1.0, -1.0, -1.0], [2.0, 2.0, 2.0]
+    cell = ((pos + 1.0) * (g / 2.0))
+    inside = ((cell >= 0) & (cell < g)).all(dim=1)
+    ci = cell.long().clamp_(0, g - 1)
+    flat = (ci[:, 2] * g + ci[:, 1]) * g + ci[:, 0]
+    keep = ~inside | occ.reshape(-1)[flat]
+    pc, vc, index = ops.occupancy_compact(pos, view, lo, size, g, bits)
+    exp_index = keep.nonzero().reshape(-1)
+    assert torch.equal(index.long(), exp_index)
+    assert torch.equal(pc, pos[exp_index]) and torch.equal(vc, view[exp_index])
+    packed = torch.randn(index.numel(), 4, device=dev())
+    full = ops.scatter_logits(packed, index, n)
+    exp = torch.zeros(n, 4, device=dev())
+    exp[:, 3] = -100.0
+    exp[exp_index] = packed
+    assert torch.equal(full, exp)
+
+
+def test_render_with_empty_space_skipping():
+    """Opt-in occupancy-grid skipping: the MLP runs on a fraction of the samples and the frame
+    is the full render's to PSNR level (new behaviour)."""
+    import fourier_feature_nets_amd as ffn
+    from tests.helpers import look_at_camera
+    model = _octahedron_model()
+    cams = []
+    for k, eye in enumerate([(0.0, 0.3, -3.0), (2.0, 1.0, 2.0)]):
+        intr, pose = look_at_camera(np.array(eye), 48, 48)
+        cams.append(ffn.CameraInfo.create("c%d" % k, ffn.Resolution(48, 48), intr, pose))
+    bounds = np.diag([2, 2, 2, 1]).astype(np.float32)
+    sampler = _quiet(ffn.RaySampler, bounds, cams, 96, device=dev())
+    caster = ffn.Raycaster(model)
+    full = [caster.render_image(sampler, c, 4096) for c in range(2)]
+    grid = ffn.OccupancyGrid.from_model(model, bounds, resolution=64, sigma_threshold=1e-3)
+    assert 0.0 < grid.fraction_occupied() < 0.05       # the octahedron fills 0.13 % of the box
+    calls = []
+    fwd = model.forward
+    model.forward = lambda x: (calls.append(x.shape[0]), fwd(x))[1]
+    caster.occupancy = grid
+    skipped = [caster.render_image(sampler, c, 4096) for c in range(2)]
+    model.forward = fwd
+    total = sum(int(sampler._valid_for_camera(c).numel()) * 96 for c in range(2))
+    assert sum(calls) < 0.05 * total
+    for a, b in zip(full, skipped):
+        assert a.max() > 100                     # the object is in view
+        mse = np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)
+        assert 10 * np.log10(255.0 ** 2 / max(mse, 1e-12)) > 45.0
+    # training renders ignore the grid
+    samples = sampler.sample(sampler._valid_for_camera(0)[:64].contiguous(), None)
+    calls.clear()
+    model.forward = lambda x: (calls.append(x.shape[0]), fwd(x))[1]
+    caster.render(samples).color.sum().backward()
+    model.forward = fwd
+    assert calls == [64 * 96]
