@@ -41,17 +41,6 @@ __device__ __forceinline__ f32x4 zero4() { f32x4 z; z[0] = z[1] = z[2] = z[3] = 
 // 256x128 unit costs half, a 128x128 unit a quarter, of a full one).
 constexpr int kUnitBufBytes = 64 * 1024;   // A image 32 KiB + B image 32 KiB
 
-__device__ __forceinline__ void stage_slab(const f32x4* __restrict__ block_base, int quads,
-                                           char* lds_part, int tid, int wave) {
-    // chunk k = 8 quads = 4 KiB = one 16-byte piece per thread
-    for (int k = 0; k < (quads >> 3); ++k) {
-        const char* g = reinterpret_cast<const char*>(block_base) + k * 4096 + tid * 16;
-        char* l = lds_part + k * 4096 + wave * 1024;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                         (__attribute__((address_space(3))) void*)l, 16, 0, 0);
-    }
-}
-
 // LDS map of the unit kernel: [2 x (A image 32 KiB | B image 32 KiB)]
 // [512 B of zeros: the row idle lanes of a narrow window read instead of branching/selecting]
 constexpr int kUnitZeroOffset = 2 * kUnitBufBytes;
@@ -195,9 +184,10 @@ __device__ __forceinline__ void unit_segment(const ffn_mlp_chain& ch, const ffn_
 }
 
 // Logits-head rows inside the LDS-staged kernel: dW_head[j][k] = sum_s dl[s][j] * X[k][s] for
-// the <= 4 head outputs j.  X (<= 256 channels) is staged like any slab; wave w owns channel
-// half (w & 1) and sample half (w >> 1) of every block: 8 steps x 4 MFMAs -- the kernel is
-// HBM-bound (32 KiB per ~2k cycles per CU), which is the point: no scattered global reads.
+// the <= 4 head outputs j.  X (<= 256 channels) is staged like any slab (through registers,
+// two blocks ahead); wave w owns channel half (w & 1) and sample half (w >> 1) of every
+// block: 8 steps x 4 MFMAs.  The unit is bound by the stream of X (32 KiB per ~2k cycles of
+// MFMA work), which is why the copy is kept two blocks deep.
 __device__ __forceinline__ void head_segment(const ffn_mlp_chain& ch, const ffn_wgrad_unit& unit,
                                              const ffn_wgrad_segment& seg, char* smem,
                                              const float* __restrict__ saved,
@@ -213,8 +203,11 @@ __device__ __forceinline__ void head_segment(const ffn_mlp_chain& ch, const ffn_
     const bool x_ok = li < unit.n_quads - 32 * half;
     const bool col_ok = li < lg_n;
     const int col = col_ok ? lg_col + li : 0;
-    const f32x4* x_slab = reinterpret_cast<const f32x4*>(saved + ch.slot_offset[unit.n_slot] * num_blocks * 32) + unit.n_cq0 * 32;
-    const int64_t x_stride = ch.slot_channels[unit.n_slot] * 8;
+    const int64_t x_stride = (int64_t)ch.slot_channels[unit.n_slot] * 128;    // bytes per block
+    const char* x_s = reinterpret_cast<const char*>(saved + ch.slot_offset[unit.n_slot] * num_blocks * 32) +
+                      unit.n_cq0 * 512 + seg.blk_begin * x_stride;
+    const int c_last = (unit.n_quads >> 3) - 1;
+    const int t16 = tid * 16;
     f32x16 acc[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p)
@@ -232,34 +225,62 @@ __device__ __forceinline__ void head_segment(const ffn_mlp_chain& ch, const ffn_
             dst[k] = (col_ok && sample < n) ? v : 0.0f;
         }
     };
+    f32x4 R[8];      // staged chunks of X (4 KiB each; past the window: its last chunk again)
+#define FFN_REQUEST(j) R[j] = *reinterpret_cast<const f32x4*>(x_s + ((j) < c_last ? (j) : c_last) * 4096 + t16)
+#define FFN_DEPOSIT(buf, j) *reinterpret_cast<f32x4*>((buf) + (j) * 4096 + t16) = R[j]
     float dl[8], dl_next[8];
     load_dl(seg.blk_begin, dl);
-    stage_slab(x_slab + seg.blk_begin * x_stride, unit.n_quads, smem, tid, wave);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) FFN_REQUEST(j);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) FFN_DEPOSIT(smem, j);
+    x_s += x_stride;
+    if (seg.blk_begin + 1 < seg.blk_end) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) FFN_REQUEST(j);
+    }
+    x_s += x_stride;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     const int sw = li & 15;
     const f32x4* all = reinterpret_cast<const f32x4*>(smem);
     for (int64_t blk = seg.blk_begin; blk < seg.blk_end; ++blk) {
         const int cur = (int)((blk - seg.blk_begin) & 1);
         char* buf = smem + cur * kUnitBufBytes;
-        const int64_t nb = blk + 1 < seg.blk_end ? blk + 1 : blk;
-        if (blk + 1 < seg.blk_end)
-            stage_slab(x_slab + (blk + 1) * x_stride, unit.n_quads, smem + (cur ^ 1) * kUnitBufBytes, tid, wave);
-        load_dl(nb, dl_next);
+        char* nxt = smem + (cur ^ 1) * kUnitBufBytes;
+        const bool has1 = blk + 1 < seg.blk_end, has2 = blk + 2 < seg.blk_end;
+        load_dl(has1 ? blk + 1 : blk, dl_next);
         const f32x4* lx = x_ok ? reinterpret_cast<const f32x4*>(buf) + (32 * half + li) * 32 : all + kUnitZeroOffset / 16;
+        f32x4 a = lx[(2 * (8 * sh) + hh) ^ sw];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const f32x4 a = lx[(2 * (8 * sh + k) + hh) ^ sw];
+            // the next step's operand is read while this step's MFMAs run
+            const f32x4 a_next = lx[(2 * (8 * sh + (k < 7 ? k + 1 : k)) + hh) ^ sw];
             bsum += dl[k];
 #pragma unroll
             for (int p = 0; p < 4; ++p)
                 acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[p], dl[k], acc[p], 0, 0, 0);
+            if (k < 2) {
+                if (has1) {
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) FFN_DEPOSIT(nxt, k * 4 + jj);
+                }
+            } else if (k < 6) {
+                if (has2) {
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) FFN_REQUEST((k - 2) * 2 + jj);
+                }
+            }
+            a = a_next;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        x_s += x_stride;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
 #pragma unroll
         for (int k = 0; k < 8; ++k) dl[k] = dl_next[k];
     }
+#undef FFN_REQUEST
+#undef FFN_DEPOSIT
     float* out = partials + (int64_t)(seg.slot + wave) * kPartialFloats;
 #pragma unroll
     for (int p = 0; p < 4; ++p)

@@ -9,6 +9,7 @@ the whole model.
 """
 
 import ctypes
+import os
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -25,6 +26,9 @@ WGRAD_GROUPS = 256          # one persistent workgroup per CU for the LDS-staged
 # unit (HBM-bound, 32 KiB per block)
 UNIT_COST = {4: 24, 2: 13, 1: 8}
 HEAD_COST = 9
+if os.environ.get("FFN_UNIT_COST"):       # "full,half,quarter,head" -- calibration experiments
+    _c = [int(v) for v in os.environ["FFN_UNIT_COST"].split(",")]
+    UNIT_COST, HEAD_COST = {4: _c[0], 2: _c[1], 1: _c[2]}, _c[3]
 
 
 class FfnEncoding(ctypes.Structure):
