@@ -26,12 +26,13 @@ from .utils import (
     linspace,
     load_model,
 )
+from .visualizers import ActivationVisualizer, EvaluationVisualizer, OrbitVideoVisualizer, Visualizer
 from .voxels import Voxels
 
 __version__ = "0.1.0"
 
-__all__ = ["__version__", "BasicFourierMLP", "CameraInfo", "ETABar", "FourierFeatureMLP",
+__all__ = ["__version__", "ActivationVisualizer", "BasicFourierMLP", "CameraInfo", "ETABar", "EvaluationVisualizer", "FourierFeatureMLP",
            "GaussianFourierMLP", "ImageDataset", "LogEntry", "MLP", "NeRF",
-           "OccupancyGrid", "PositionalFourierMLP", "RayDataset", "RaySampler", "RaySamples", "Raycaster",
-           "RenderResult", "Resolution", "TrainEngine", "Voxels", "calculate_blend_weights",
+           "OccupancyGrid", "OrbitVideoVisualizer", "PositionalFourierMLP", "RayDataset", "RaySampler", "RaySamples", "Raycaster",
+           "RenderResult", "Resolution", "TrainEngine", "Visualizer", "Voxels", "calculate_blend_weights",
            "exponential_lr_decay", "linspace", "load_model", "orbit"]

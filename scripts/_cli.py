@@ -99,20 +99,3 @@ def write_log(path, args, log):
 def save_png(path, image):
     from PIL import Image
     Image.fromarray(image).save(path)
-
-
-class FrameDump:
-    """Training hook with the visualizer call signature (step, render_image, render_act):
-    every `interval` steps renders camera 0 of a dataset and writes a PNG."""
-
-    def __init__(self, results_dir, dataset, interval, raycaster, batch_size):
-        self.dir = os.path.join(results_dir, dataset.label)
-        os.makedirs(self.dir, exist_ok=True)
-        self.dataset, self.interval = dataset, interval
-        self.raycaster, self.batch_size = raycaster, batch_size
-
-    def visualize(self, step, render_image, render_act):
-        if step % self.interval:
-            return
-        image = self.raycaster.render_image(self.dataset.sampler, 0, max(self.batch_size, 4096))
-        save_png(os.path.join(self.dir, "{:06}.png".format(step)), image)

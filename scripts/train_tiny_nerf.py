@@ -45,8 +45,13 @@ def main():
         train.mode = ffn.RayDataset.Mode.Dilate
     os.makedirs(args.results_dir, exist_ok=True)
     caster = ffn.Raycaster(model.to(args.device))
-    hooks = [_cli.FrameDump(args.results_dir, ds, args.image_interval, caster, args.batch_size)
-             for ds in (train, val)]
+    if args.make_video:      # same choice of visualizers as the reference driver
+        hooks = [ffn.OrbitVideoVisualizer(args.results_dir, args.num_steps,
+                                          train.cameras[0].resolution, args.num_frames,
+                                          args.num_samples, args.color_space, device=args.device)]
+    else:
+        hooks = [ffn.EvaluationVisualizer(args.results_dir, ds, args.image_interval)
+                 for ds in (train, val)]
     log = caster.fit(train, val, args.batch_size, args.learning_rate, args.num_steps,
                      args.crop_steps, args.report_interval, args.decay_rate, args.decay_steps,
                      args.weight_decay, hooks)
