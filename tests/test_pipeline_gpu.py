@@ -515,3 +515,22 @@ def test_visualizers_write_the_reference_file_layout(golden, tmp_path):
     assert np.asarray(Image.open(os.path.join(out, "video", video[0]))).shape == (16, 16, 3)
     with pytest.raises(NotImplementedError):
         ffn.ActivationVisualizer(out, 4, ffn.Resolution(16, 16), 2, 8, "RGB")
+
+
+def test_training_step_is_deterministic(golden):
+    """Same weights, rays and noise -> bit-identical loss and updated weights (fixed-order
+    partial reduction, no atomics anywhere on the step path)."""
+    import fourier_feature_nets_amd as ffn
+    g = golden("training")
+    outs = []
+    for _ in range(2):
+        model = _small_model(g)
+        train = _quiet(ffn.ImageDataset.load, SCENE, "train", 16, True, True)
+        engine = ffn.TrainEngine(model)
+        torch.manual_seed(21)
+        torch.cuda.manual_seed(21)
+        batch = torch.arange(0, len(train), 2, device=dev())
+        losses = [float(engine.train_step(train, batch, s, 5e-4)) for s in range(3)]
+        outs.append((losses, engine.flat.clone()))
+    assert outs[0][0] == outs[1][0]
+    assert torch.equal(outs[0][1], outs[1][1])
