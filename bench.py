@@ -40,6 +40,8 @@ def parse_args():
     ap.add_argument("--size", type=int, default=400)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-render", action="store_true", help="skip the frames/sec leg")
+    ap.add_argument("--no-target-shape", action="store_true",
+                    help="skip the MFMA-utilisation leg at the north-star shape (NeRF, 65536 x 128)")
     ap.add_argument("--model", default="tiny", choices=["tiny", "nerf", "gaussian512"],
                     help="tiny = BASELINE configs[1] (the metric's config); nerf = configs[2]-shaped "
                          "full NeRF (8x256, skip, view branch), use with --samples 128")
@@ -119,6 +121,72 @@ def cpu_baseline(args, model_state, log):
     return {"value": rays * done / elapsed, "unit": "rays/s", "cores": cores, "kind": "port",
             "sample": "%d training steps of %d rays x %d samples (oracle: the reference's ATen op "
                       "sequence on the host CPU), %.1f s" % (done, rays, S, elapsed)}
+
+
+def target_shape_leg(device):
+    """MFMA utilisation of the fused Fourier-MLP kernels at the shape BASELINE.json's target is
+    stated on: full NeRF, one launch of 65 536 rays x 128 samples (synthetic positions / view
+    directions / d_logits; kernels only, HIP events on the launch stream)."""
+    import fourier_feature_nets_amd as ffn
+    rays, samples = 65536, 128
+    n = rays * samples
+    torch.cuda.empty_cache()
+    torch.manual_seed(20080524)
+    model = ffn.NeRF(8, 256, 9, 10, 3, 4, [4], True).to(device)
+    prog = model.program()
+    gen = torch.Generator(device=device).manual_seed(7)
+    pos = torch.rand((n, 3), generator=gen, device=device) * 2 - 1
+    view = torch.nn.functional.normalize(torch.randn((n, 3), generator=gen, device=device), dim=1)
+    d_logits = torch.randn((n, 4), generator=gen, device=device) / n
+    saved = torch.empty((prog.saved_floats(n),), dtype=torch.float32, device=device)
+    grads = torch.empty((prog.num_grad_floats,), dtype=torch.float32, device=device)
+    from fourier_feature_nets_amd import _lib as lib_mod
+    orig_call = lib_mod.call
+    spans = {}
+
+    def timed(name, *a):
+        key = {"ffn_mlp_forward": "mlp_forward_kernel<train>",
+               "ffn_mlp_backward_data": "mlp_backward_data_kernel",
+               "ffn_mlp_wgrad_units": "wgrad_unit_kernel"}.get(name)
+        if key is None:
+            return orig_call(name, *a)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        orig_call(name, *a)
+        e1.record()
+        spans.setdefault(key, []).append((e0, e1))
+
+    lib_mod.call = timed
+    try:
+        for it in range(3):
+            if it == 1:
+                spans.clear()
+            prog.forward(pos, view, saved)
+            prog.backward(d_logits, pos, view, saved, grads)
+        torch.cuda.synchronize()
+    finally:
+        lib_mod.call = orig_call
+    specs = prog.layers
+    fwd = 2 * sum(sp.out * sp.ld for sp in specs)
+    flops = {"mlp_forward_kernel<train>": fwd, "wgrad_unit_kernel": fwd,
+             "mlp_backward_data_kernel": 2 * sum(sp.out * sp.act_in for sp in specs)}
+    out = {}
+    total_ms = 0.0
+    for key, pairs in spans.items():
+        ms = sum(a.elapsed_time(b) for a, b in pairs) / len(pairs)
+        total_ms += ms
+        tf = flops[key] * n / (ms * 1e-3) / 1e12
+        out[key] = {"avg_ms": round(ms, 3), "achieved": round(tf, 2),
+                    "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4), "flop_per_sample": flops[key]}
+    all_flops = sum(flops.values()) * n
+    del saved, pos, view, d_logits
+    torch.cuda.empty_cache()
+    return {"workload": "NeRF(8,256,9,10,3,4,[4],True), one launch of 65536 rays x 128 samples "
+                        "(fused Fourier-MLP kernels only)",
+            "kernels": out, "mlp_ms": round(total_ms, 3),
+            "achieved": round(all_flops / (total_ms * 1e-3) / 1e12, 2),
+            "frac": round(all_flops / (total_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+            "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "dtype": "f32"}
 
 
 def main():
@@ -304,6 +372,8 @@ def main():
                        "samples_per_ray": args.samples, "includes": "sampling, fused MLP, "
                        "composite, u8 assembly and the D2H copy of each frame"},
         }
+        result["north_star_shape"] = None if (args.no_target_shape or args.model != "tiny") \
+            else target_shape_leg(device)
         if not args.no_cpu_baseline and world == 1 and args.model == "tiny":
             state = {k: v.detach() for k, v in model.state_dict().items()}
             result["cpu_baseline"] = cpu_baseline(args, state, None)
