@@ -11,9 +11,13 @@
 // no transposes, no inter-wave barriers, no HBM round trips between layers.
 // Weights are streamed from L2 in a pre-packed operand order (ffn_mlp_pack), 1 KiB
 // coalesced per wave-load, double buffered in registers against the 64-cycle MFMAs.
-// Fourier features are generated in registers (branch-free sincos) and interleaved with
-// the MFMAs of the previous K group.  The same interpreter runs the backward-data chain
-// (dZ_{l-1} = relu'(H_{l-1}) * W_l^T dZ_l) with transposed weight packs.
+// f32 VALU work does not overlap f32 MFMA on gfx950, so nothing but loads rides in the K
+// loops: Fourier features are generated in packed-f32 bursts into the slab between K loops
+// (and saved for the weight gradients when training), biases are the accumulators' initial
+// value, logits heads are folded into the producing layer's epilogue.  The same interpreter
+// runs the backward-data chain (dZ_{l-1} = relu'(H_{l-1}) * W_l^T dZ_l) with transposed
+// weight packs and 1-bit ReLU masks.  A "wide" variant (two waves per 32-sample block, 64 KiB
+// slab) covers 512-channel layers.
 #include "common.h"
 
 namespace ffn {

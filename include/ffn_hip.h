@@ -251,11 +251,14 @@ int ffn_mlp_pack(const float* src, int rows, int cols, int ld, int transpose,
                  float* dst, void* stream);
 
 /* Forward chain.  positions (N,3), views (N,3) or NULL, logits out (N,4).  Training: when
- * `saved` and `masks` are non-NULL, every step with save_in_slot >= 0 writes its input
- * activations into `saved` (block layout, for the weight gradients) and every ReLU step
- * writes the sign bits of its output into `masks` (num_slots * num_blocks * 256 uint32:
- * [slot][block][lane][4], bit 16*(tile&1)+r of word tile/2 = accumulator register r of
- * that lane) for the backward-data chain. */
+ * `saved` and `masks` are non-NULL, every step writes what the backward pass needs into
+ * `saved` (block layout): its input activations (save_in_slot), the encoding features it
+ * generated (save_enc_slot), its output when a fused head reads it (save_out_slot); and every
+ * ReLU step writes the sign bits of its output into `masks` (num_slots * num_blocks * W
+ * uint32, W = 256, or 512 for a wide chain: [slot][block][half][lane][4], bit 16*(tile&1)+r
+ * of word tile/2 = accumulator register r of that lane, tiles counted inside the wave's half)
+ * for the backward-data chain.  `bias` = bias_floats floats: per step its padded bias, plus
+ * the fused heads' blocks (head_off). */
 int ffn_mlp_forward(const ffn_mlp_chain* chain, const float* packed_w, const float* bias,
                     const float* positions, const float* views, int64_t n, float* logits,
                     float* saved, uint32_t* masks, void* stream);
