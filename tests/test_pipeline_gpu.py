@@ -3,6 +3,7 @@ on the HIP kernels, against the oracle and the reference-generated goldens.  Nee
 
 import contextlib
 import io
+import math
 import os
 
 import numpy as np
@@ -534,3 +535,48 @@ def test_training_step_is_deterministic(golden):
         outs.append((losses, engine.flat.clone()))
     assert outs[0][0] == outs[1][0]
     assert torch.equal(outs[0][1], outs[1][1])
+
+
+def test_psnr_after_long_training_matches_oracle(golden):
+    """BASELINE target "rendered PSNR within 0.05 dB of the reference": 150 optimisation steps
+    from the same weights, rays and noise on the HIP path and in the oracle (the reference's op
+    sequence on the CPU), then the validation PSNR (-10 log10 of the mean batch loss incl. the
+    alpha term, ray_caster.py:244-245) of both models on the same deterministic samples."""
+    import fourier_feature_nets_amd as ffn
+    g = golden("training")
+    model = _small_model(g)
+    ref = _oracle_model(g)
+    train = _quiet(ffn.ImageDataset.load, SCENE, "train", 16, True, True)
+    val = _quiet(ffn.ImageDataset.load, SCENE, "val", 16, True, False)
+    train.sampler.noise_source = "host"
+    engine = ffn.TrainEngine(model)
+    trainer = orc.OracleTrainer(ref, 5e-4)
+    state = {"starts": train.sampler.starts.cpu(), "directions": train.sampler.directions.cpu(),
+             "near_far": train.sampler.near_far.cpu()}
+    colors, alphas = train.colors.cpu(), train.alphas.cpu()
+    gen = torch.Generator().manual_seed(99)
+    steps = 150
+    for step in range(steps):
+        batch = torch.randperm(len(train), generator=gen)[:96]
+        rays = train.ray_ids(batch.to(dev()))
+        torch.manual_seed(1000 + step)
+        engine.train_step(train, batch.to(dev()), None, 5e-4, rays=rays)
+        torch.manual_seed(1000 + step)
+        noise = torch.rand((rays.numel(), 16))
+        pos, view, t, _ = orc.sample(state, rays.cpu().numpy(), None, 16, noise=noise)
+        gc, ga = orc.ground_truth(colors, alphas, rays.cpu())
+        trainer.step(pos, None, t, gc, ga, 5e-4)
+    engine.check_finite()
+    # validation: all valid rays of the val split, deterministic samples
+    vrays = val.ray_ids(torch.arange(len(val), device=dev()))
+    gpu_loss = float(engine.eval_loss(val, torch.arange(len(val), device=dev()), None))
+    vstate = {"starts": val.sampler.starts.cpu(), "directions": val.sampler.directions.cpu(),
+              "near_far": val.sampler.near_far.cpu()}
+    pos, view, t, _ = orc.sample(vstate, vrays.cpu().numpy(), None, 16)
+    gc, ga = orc.ground_truth(val.colors.cpu(), val.alphas.cpu(), vrays.cpu())
+    with torch.no_grad():
+        ref_loss = float(trainer.loss(pos, None, t, gc, ga))
+    psnr_gpu, psnr_ref = -10 * math.log10(gpu_loss), -10 * math.log10(ref_loss)
+    print("psnr after %d steps: hip %.4f dB, oracle %.4f dB" % (steps, psnr_gpu, psnr_ref))
+    assert psnr_ref > 10.0                            # far from the ~6 dB of the initial weights
+    assert abs(psnr_gpu - psnr_ref) < 0.05, (psnr_gpu, psnr_ref)
