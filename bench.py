@@ -196,6 +196,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible and there is no CPU fallback")
+    # FFN_BENCH_SHARE_GPU=1 (with FFN_BENCH_BACKEND=gloo): all ranks on cuda:0 -- a functional
+    # check of the N > 1 path on a one-GPU box, not a measurement
+    if os.environ.get("FFN_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     group = None
@@ -203,8 +207,11 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=device)
+        backend = os.environ.get("FFN_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
         group = dist.group.WORLD
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node == --gpus"
 
