@@ -193,11 +193,20 @@ __device__ __forceinline__ void pipeline_plain() {
     __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
     __builtin_amdgcn_sched_group_barrier(0x008, 8 * OT, 0);
 }
-// `wg` points at this lane's float4 of tile 0 of the wanted K group; tiles are 64 float4 apart
+// `wg` is the WAVE-UNIFORM address of tile 0 of the wanted K group; tiles are 64 float4
+// apart, lanes 16 B.  Keeping the running pointer uniform lets the loads use the scalar-base
+// addressing mode: the group walk and its end-of-panel clamp are SALU work, not VALU work
+// in the MFMA stream.
 template <int OT>
-__device__ __forceinline__ void load_group(f32x4 (&a)[OT], const f32x4* __restrict__ wg) {
+__device__ __forceinline__ void load_group(f32x4 (&a)[OT], const f32x4* __restrict__ wg, int lane) {
+    // tiles 4..7 lie past the 12-bit immediate offset: give them their own scalar base (the
+    // empty asm keeps the compiler from folding it back into per-lane 64-bit address math)
+    typedef const f32x4 __attribute__((address_space(1)))* gptr;
+    const gptr lo = (gptr)wg;
+    gptr hi = (gptr)(wg + 4 * 64);
+    if (OT > 4) asm volatile("" : "+s"(hi));
 #pragma unroll
-    for (int o = 0; o < OT; ++o) a[o] = wg[o * 64];
+    for (int o = 0; o < OT; ++o) a[o] = (o < 4 ? lo : hi)[(o & 3) * 64 + lane];
 }
 
 struct WaveCtx {
@@ -263,7 +272,7 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
             }
     }
 
-    const f32x4* wp = reinterpret_cast<const f32x4*>(packed_w + L.w_off) + half * OT * 64 + w.lane;
+    const f32x4* wp = reinterpret_cast<const f32x4*>(packed_w + L.w_off) + half * OT * 64;   // uniform
     const int GA = L.act_groups;   // multiple of 4
     const int GX = L.aux_groups;   // multiple of 4; encoding features (fwd) or d_logits (bwd)
     const int G = GA + GX;
@@ -275,8 +284,11 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
     f32x4 x0, x1, x2, x3;
 #pragma unroll
     for (int o = 0; o < OT; ++o) { wa0[o] = pre[o]; wa1[o] = pre[8 + o]; }
-    const f32x4* wnext = wp + 2 * kGroupStride;          // group 2
-    const f32x4* wlast = wp + (int64_t)(G - 2) * kGroupStride;
+    // (the group walk is kept as a uniform integer so that advancing and clamping it is
+    // SALU work; the loads address  scalar base + lane*16 + immediate)
+    int gnext = 2;                                       // next K-group pair to fetch
+    const int glast = G - 2;
+    const f32x4* wnext = wp + 2 * kGroupStride;
     // backward: the ReLU sign mask of the layer being differentiated, fetched a layer ahead
     const int64_t mask_at = (((int64_t)(L.mask_slot < 0 ? 0 : L.mask_slot) * w.num_blocks + w.block) * TW + half) * 64 + w.lane;
     uint4 mbits = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
@@ -316,8 +328,8 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
         x0 = xa[0];
         x1 = xa[64];
         for (int g = 0; g < count; g += 4) {
-            load_group<OT>(wb0, wnext);
-            load_group<OT>(wb1, wnext + kGroupStride);
+            load_group<OT>(wb0, wnext, w.lane);
+            load_group<OT>(wb1, wnext + kGroupStride, w.lane);
             x2 = xa[128];
             x3 = xa[192];
             if (save_lo) {
@@ -326,9 +338,10 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
             }
             mma_group<OT>(acc, wa0, x0);
             mma_group<OT>(acc, wa1, x1);
-            wnext = wnext + 2 * kGroupStride < wlast ? wnext + 2 * kGroupStride : wlast;  // clamp at the end
-            load_group<OT>(wa0, wnext);
-            load_group<OT>(wa1, wnext + kGroupStride);
+            gnext = gnext + 2 < glast ? gnext + 2 : glast;      // clamp at the end of the panel
+            wnext = wp + (int64_t)gnext * kGroupStride;
+            load_group<OT>(wa0, wnext, w.lane);
+            load_group<OT>(wa1, wnext + kGroupStride, w.lane);
             xa += 256;
             if (g + 4 < count) {
                 x0 = xa[0];
@@ -340,7 +353,8 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
             }
             mma_group<OT>(acc, wb0, x2);
             mma_group<OT>(acc, wb1, x3);
-            wnext = wnext + 2 * kGroupStride < wlast ? wnext + 2 * kGroupStride : wlast;
+            gnext = gnext + 2 < glast ? gnext + 2 : glast;
+            wnext = wp + (int64_t)gnext * kGroupStride;
             pipeline_plain<OT>();
             pipeline_plain<OT>();
         }
