@@ -324,6 +324,15 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
         // wide mode: each wave of the pair saves half of what both consume
         const bool save_lo = MODE != kInfer && save != nullptr && (!WIDE || half == 0);
         const bool save_hi = MODE != kInfer && save != nullptr && (!WIDE || half == 1);
+        // byte offset of this lane's float4 of K group g inside a saved block:
+        //   16 * ((2g + h) * 32 + (s ^ ((2g + h) & 15)))  =  g * 1024  +  (lane_part ^ (((2g) & 15) << 4))
+        // with lane_part = h * 512 + ((s ^ h) << 4): one v_xor with a scalar per store, the rest
+        // rides in the scalar base
+        const unsigned save_lane = (unsigned)(w.h * 512 + ((w.s ^ w.h) << 4));
+        char* save_s = reinterpret_cast<char*>(save);
+#define FFN_SAVE(g, value)                                                                     \
+    *reinterpret_cast<f32x4*>(save_s + (int64_t)(g) * 1024 +                                   \
+                              (save_lane ^ (unsigned)((((g) * 2) & 15) << 4))) = (value)
         const f32x4* xa = w.act + w.lane;
         x0 = xa[0];
         x1 = xa[64];
@@ -333,8 +342,8 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
             x2 = xa[128];
             x3 = xa[192];
             if (save_lo) {
-                save[saved_index(2 * g + w.h, w.s)] = x0;
-                save[saved_index(2 * (g + 1) + w.h, w.s)] = x1;
+                FFN_SAVE(g, x0);
+                FFN_SAVE(g + 1, x1);
             }
             mma_group<OT>(acc, wa0, x0);
             mma_group<OT>(acc, wa1, x1);
@@ -348,8 +357,8 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
                 x1 = xa[64];
             }
             if (save_hi) {
-                save[saved_index(2 * (g + 2) + w.h, w.s)] = x2;
-                save[saved_index(2 * (g + 3) + w.h, w.s)] = x3;
+                FFN_SAVE(g + 2, x2);
+                FFN_SAVE(g + 3, x3);
             }
             mma_group<OT>(acc, wb0, x2);
             mma_group<OT>(acc, wb1, x3);
@@ -358,6 +367,7 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
             pipeline_plain<OT>();
             pipeline_plain<OT>();
         }
+#undef FFN_SAVE
     }
 
     // ---- backward: the d_logits columns are one more (register) K group --------------
