@@ -580,3 +580,32 @@ def test_psnr_after_long_training_matches_oracle(golden):
     print("psnr after %d steps: hip %.4f dB, oracle %.4f dB" % (steps, psnr_gpu, psnr_ref))
     assert psnr_ref > 10.0                            # far from the ~6 dB of the initial weights
     assert abs(psnr_gpu - psnr_ref) < 0.05, (psnr_gpu, psnr_ref)
+
+
+def test_driver_scripts_end_to_end(tmp_path):
+    """scripts/train_tiny_nerf.py and scripts/orbit_video.py (the counterparts of the reference
+    drivers) run as programs: checkpoint, log.txt, evaluation grids, orbit frames."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "run")
+    res = subprocess.run([sys.executable, os.path.join(root, "scripts", "train_tiny_nerf.py"), SCENE,
+                          "positional", out, "--num-steps", "4", "--report-interval", "2",
+                          "--image-interval", "2", "--batch-size", "64", "--num-samples", "16",
+                          "--crop-steps", "0"], capture_output=True, text=True, cwd=root)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert sorted(os.listdir(out)) == ["log.txt", "tiny_nerf.pt", "train", "val"]
+    with open(os.path.join(out, "log.txt")) as f:
+        head = json.loads(f.readline())
+    assert head["num_steps"] == 4 and head["nerf_model"] == "positional"
+    assert len(os.listdir(os.path.join(out, "val"))) == 3
+    import fourier_feature_nets_amd as ffn
+    model = ffn.load_model(os.path.join(out, "tiny_nerf.pt"))
+    assert isinstance(model, ffn.FourierFeatureMLP)      # load_model rebuilds the base class (utils.py:448-503)
+    frames = str(tmp_path / "orbit")
+    res = subprocess.run([sys.executable, os.path.join(root, "scripts", "orbit_video.py"),
+                          os.path.join(out, "tiny_nerf.pt"), "24", frames, "--num-frames", "2",
+                          "--num-samples", "16"], capture_output=True, text=True, cwd=root)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert sorted(os.listdir(frames)) == ["frame_00000.png", "frame_00001.png"]
