@@ -482,3 +482,33 @@ def test_fused_mlp_full_size_properties(golden):
     for a, b in zip(whole, parts):
         scale = float(a.abs().max())
         assert float((a - b).abs().max()) <= 2e-5 * max(scale, 1e-6)
+
+
+def test_abi_rejects_bad_arguments_with_a_message():
+    """Entry points validate shapes / chains and return an error code + message instead of
+    launching (the Python layer turns it into FfnError)."""
+    import ctypes
+    from fourier_feature_nets_amd import _lib
+    from fourier_feature_nets_amd._lib import c_i, c_i64, c_p, FfnError
+    from fourier_feature_nets_amd.mlp_engine import FfnMlpChain
+    stream = c_p(torch.cuda.current_stream().cuda_stream)
+    buf = torch.zeros(64, device=dev())
+    ptr = c_p(buf.data_ptr())
+    with pytest.raises(FfnError, match="ffn_composite_fwd"):
+        _lib.call("ffn_composite_fwd", ptr, ptr, c_i(4), c_i(0), ptr, ptr, c_p(0), c_p(0), stream)
+    with pytest.raises(FfnError, match="ffn_mlp_pack"):
+        _lib.call("ffn_mlp_pack", ptr, c_i(4), c_i(4), c_i(4), c_i(0), c_p(0), c_p(0), c_i(0), c_i(1),
+                  ptr, stream)
+    chain = FfnMlpChain()                 # num_steps == 0: not a chain
+    with pytest.raises(FfnError, match="bad chain"):
+        _lib.call("ffn_mlp_forward", ctypes.byref(chain), ptr, ptr, ptr, c_p(0), c_i64(8), ptr,
+                  c_p(0), c_p(0), stream)
+    chain.num_steps = 1
+    chain.step[0].out_tiles = 3           # not a supported tile count
+    chain.step[0].act_groups = 4
+    with pytest.raises(FfnError, match="bad chain"):
+        _lib.call("ffn_mlp_backward_data", ctypes.byref(chain), ptr, ptr, c_i64(8), ptr, ptr, stream)
+    with pytest.raises(FfnError, match="ffn_occupancy_build"):
+        _lib.call("ffn_occupancy_build", ptr, c_i(0), ctypes.c_float(0.1), c_i(0), c_p(0), ptr, stream)
+    torch.cuda.synchronize()              # nothing was launched, nothing is poisoned
+    assert float(buf.abs().max()) == 0.0
