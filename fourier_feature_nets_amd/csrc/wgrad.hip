@@ -23,6 +23,16 @@ constexpr int kPartialFloats = 16 * 16 * 64 + 256;  // 16 tiles + bias strip
 
 __device__ __forceinline__ f32x4 zero4() { f32x4 z; z[0] = z[1] = z[2] = z[3] = 0.0f; return z; }
 
+// tells the compiler a pointer is wave-uniform (so that it lives in SGPRs and loads through it
+// use scalar-base addressing)
+template <typename T>
+__device__ __forceinline__ T* uniform_ptr(T* p) {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<T*>(((uint64_t)hi << 32) | lo);
+}
+
 // ---------------------------------------------------------------------------------- units
 // A 256-thread workgroup owns one unit (dZ slab window of <=256 channels  x  input slab
 // window of <=256 channels) over a range of sample blocks.  Per block the two operand images
@@ -76,6 +86,8 @@ __device__ __forceinline__ void unit_segment(const ffn_mlp_chain& ch, const ffn_
                       unit.m_cq0 * 512 + seg.blk_begin * a_stride;
     const char* b_s = reinterpret_cast<const char*>(saved + ch.slot_offset[unit.n_slot] * num_blocks * 32) +
                       unit.n_cq0 * 512 + seg.blk_begin * b_stride;
+    a_s = uniform_ptr(a_s);
+    b_s = uniform_ptr(b_s);
     const int ca_last = (unit.m_quads >> 3) - 1, cb_last = (unit.n_quads >> 3) - 1;
     const int t16 = tid * 16;
 
@@ -92,9 +104,16 @@ __device__ __forceinline__ void unit_segment(const ffn_mlp_chain& ch, const ffn_
     // Chunks past the end of a window re-read its last chunk (never consumed: the lanes that
     // would are pointed at the zero row), which keeps the loop free of branches.
     f32x4 R[NCH];
+    // uniform chunk pointer indexed by the thread: scalar base + lane offset addressing, the
+    // chunk select and the block walk stay on the SALU
+    typedef const f32x4 __attribute__((address_space(1)))* gptr;
 #define FFN_REQUEST(j)                                                                         \
-    R[j] = (j) < CA ? *reinterpret_cast<const f32x4*>(a_s + ((j) < ca_last ? (j) : ca_last) * 4096 + t16) \
-                    : *reinterpret_cast<const f32x4*>(b_s + ((j) - CA < cb_last ? (j) - CA : cb_last) * 4096 + t16)
+    do {                                                                                       \
+        gptr chunk = (j) < CA ? (gptr)(a_s + ((j) < ca_last ? (j) : ca_last) * 4096)           \
+                              : (gptr)(b_s + ((j) - CA < cb_last ? (j) - CA : cb_last) * 4096);  \
+        asm volatile("" : "+s"(chunk));    /* its own scalar base: no per-lane 64-bit adds */  \
+        R[j] = chunk[tid];                                                                     \
+    } while (0)
 #define FFN_DEPOSIT(buf, j)                                                                    \
     *reinterpret_cast<f32x4*>((buf) + ((j) < CA ? (j) * 4096 : 32 * 1024 + ((j) - CA) * 4096) + t16) = R[j]
 
@@ -206,6 +225,7 @@ __device__ __forceinline__ void head_segment(const ffn_mlp_chain& ch, const ffn_
     const int64_t x_stride = (int64_t)ch.slot_channels[unit.n_slot] * 128;    // bytes per block
     const char* x_s = reinterpret_cast<const char*>(saved + ch.slot_offset[unit.n_slot] * num_blocks * 32) +
                       unit.n_cq0 * 512 + seg.blk_begin * x_stride;
+    x_s = uniform_ptr(x_s);
     const int c_last = (unit.n_quads >> 3) - 1;
     const int t16 = tid * 16;
     f32x16 acc[4];
@@ -226,7 +246,13 @@ __device__ __forceinline__ void head_segment(const ffn_mlp_chain& ch, const ffn_
         }
     };
     f32x4 R[8];      // staged chunks of X (4 KiB each; past the window: its last chunk again)
-#define FFN_REQUEST(j) R[j] = *reinterpret_cast<const f32x4*>(x_s + ((j) < c_last ? (j) : c_last) * 4096 + t16)
+    typedef const f32x4 __attribute__((address_space(1)))* gptr;
+#define FFN_REQUEST(j)                                                                         \
+    do {                                                                                       \
+        gptr chunk = (gptr)(x_s + ((j) < c_last ? (j) : c_last) * 4096);                       \
+        asm volatile("" : "+s"(chunk));                                                        \
+        R[j] = chunk[tid];                                                                     \
+    } while (0)
 #define FFN_DEPOSIT(buf, j) *reinterpret_cast<f32x4*>((buf) + (j) * 4096 + t16) = R[j]
     float dl[8], dl_next[8];
     load_dl(seg.blk_begin, dl);
