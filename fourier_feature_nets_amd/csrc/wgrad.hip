@@ -12,6 +12,8 @@
 // (unit, sample-block range) segments, keep a 128x128 patch per wave in 256 accumulator
 // registers, and dump one partial per wave and segment; a second kernel sums the partials in
 // a fixed order (deterministic) and scatters into the natural nn.Linear gradient layout.
+#include <type_traits>
+
 #include "common.h"
 
 namespace ffn {
@@ -49,12 +51,16 @@ __device__ __forceinline__ T* uniform_ptr(T* p) {
 // A window of <=128 channels has only one quadrant along that side; the waves that would own
 // the missing quadrants split the block's 16 sample pairs with their siblings instead (so a
 // 256x128 unit costs half, a 128x128 unit a quarter, of a full one).
-constexpr int kUnitBufBytes = 64 * 1024;   // A image 32 KiB + B image 32 KiB
-
-// LDS map of the unit kernel: [2 x (A image 32 KiB | B image 32 KiB)]
-// [512 B of zeros: the row idle lanes of a narrow window read instead of branching/selecting]
-constexpr int kUnitZeroOffset = 2 * kUnitBufBytes;
-constexpr int kUnitLdsBytes = kUnitZeroOffset + 512;
+// LDS map of the unit kernel: four operand images, each followed by a 512-B row of zeros --
+//   [A even | 0][A odd | 0][B even | 0][B odd | 0],  kImageStride = 32 KiB + 512 B apart.
+// Idle lanes of a narrow window read "their" image's zero row instead of branching or
+// selecting; and because the even / odd block buffers of an operand are one constant apart,
+// the buffer toggle of the double buffering rides in the ds_read immediate offset.
+constexpr int kImageBytes = 32 * 1024;
+constexpr int kImageStride = kImageBytes + 512;
+constexpr int kUnitLdsBytes = 4 * kImageStride;
+__device__ __forceinline__ constexpr int image_a(int cur) { return cur * kImageStride; }
+__device__ __forceinline__ constexpr int image_b(int cur) { return (2 + cur) * kImageStride; }
 
 // CA / CB = 4 KiB chunks staged per block for the A / B image: 8 for a window wider than 128
 // channels (two quadrants along that side), 4 otherwise; BIAS = this wave also sums dZ.
@@ -114,14 +120,15 @@ __device__ __forceinline__ void unit_segment(const ffn_mlp_chain& ch, const ffn_
         asm volatile("" : "+s"(chunk));    /* its own scalar base: no per-lane 64-bit adds */  \
         R[j] = chunk[tid];                                                                     \
     } while (0)
-#define FFN_DEPOSIT(buf, j)                                                                    \
-    *reinterpret_cast<f32x4*>((buf) + ((j) < CA ? (j) * 4096 : 32 * 1024 + ((j) - CA) * 4096) + t16) = R[j]
+#define FFN_DEPOSIT(cur, j)                                                                    \
+    *reinterpret_cast<f32x4*>(smem + ((j) < CA ? image_a(cur) + (j) * 4096                     \
+                                               : image_b(cur) + ((j) - CA) * 4096) + t16) = R[j]
 
     // ---- prologue: first block -> LDS buffer 0, second block -> registers
 #pragma unroll
     for (int j = 0; j < NCH; ++j) FFN_REQUEST(j);
 #pragma unroll
-    for (int j = 0; j < NCH; ++j) FFN_DEPOSIT(smem, j);
+    for (int j = 0; j < NCH; ++j) FFN_DEPOSIT(0, j);
     a_s += a_stride;
     b_s += b_stride;
     if (seg.blk_begin + 1 < seg.blk_end) {
@@ -133,28 +140,37 @@ __device__ __forceinline__ void unit_segment(const ffn_mlp_chain& ch, const ffn_
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    // LDS byte offset of sample pair u inside a quad row: ((2u + hh) ^ (li & 15)) * 16
-    //   = x0 ^ (i << 5)  for u = part*S + i, x0 = ((hh ^ (li & 15)) << 4) ^ (part*S << 5)
+    // LDS addresses of this lane's operand float4 for each of its S steps, in the EVEN
+    // buffers (the odd ones are +kImageStride, an immediate).  Sample pair u of a quad row
+    // sits at byte ((2u + hh) ^ (li & 15)) * 16 = x0 ^ (i << 5) for u = part*S + i.
+    // Idle lanes of a narrow window point into the image's zero row.
     const unsigned x0 = (unsigned)(((hh ^ (li & 15)) << 4) ^ ((part * S) << 5));
     const unsigned lds0 = (unsigned)(size_t)smem;
-    for (int64_t blk = seg.blk_begin; blk < seg.blk_end; ++blk) {
-        const int cur = (int)((blk - seg.blk_begin) & 1);
-        char* nxt = smem + (cur ^ 1) * kUnitBufBytes;
-        const bool has1 = blk + 1 < seg.blk_end, has2 = blk + 2 < seg.blk_end;
-        // idle lanes of a narrow window read the zero row: no select in the MFMA stream.
-        // Operand reads are hand-issued (inline asm, so hipcc's waitcnt pass does not see
-        // them) right behind the step's MFMAs have started, and waited for by hand at the end
-        // of the step: a full ~1000 cycles of matrix work covers the LDS latency.
-        const unsigned a_base = a_ok ? lds0 + cur * kUnitBufBytes + (32 * mp + li) * 512 : lds0 + kUnitZeroOffset;
-        const unsigned b_base = b_ok ? lds0 + cur * kUnitBufBytes + 32 * 1024 + (32 * np + li) * 512 : lds0 + kUnitZeroOffset;
+    const unsigned a_row = lds0 + image_a(0) + (a_ok ? (32 * mp + li) * 512 : kImageBytes);
+    const unsigned b_row = lds0 + image_b(0) + (b_ok ? (32 * np + li) * 512 : kImageBytes);
+    unsigned a_at[S], b_at[S];
+#pragma unroll
+    for (int i = 0; i < S; ++i) {
+        a_at[i] = a_row + (x0 ^ (unsigned)(i << 5));
+        b_at[i] = b_row + (x0 ^ (unsigned)(i << 5));
+    }
+
+    // one block out of the buffers of parity CUR (compile-time: the toggle is an immediate).
+    // Operand reads are hand-issued (inline asm, so hipcc's waitcnt pass does not see them)
+    // right behind the step's MFMAs have started, and waited for by hand at the end of the
+    // step: a full ~1000 cycles of matrix work covers the LDS latency.
+    auto block_body = [&](auto cur_tag, bool has1, bool has2) {
+        constexpr int CUR = decltype(cur_tag)::value;
+        constexpr int kToggle = CUR * kImageStride;
         f32x4 a, b, a_n, b_n;
-        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(a), "=&v"(b) : "v"(a_base + x0), "v"(b_base + x0) : "memory");
+        asm volatile("ds_read_b128 %0, %2 offset:%4\n\tds_read_b128 %1, %3 offset:%4\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(a), "=&v"(b) : "v"(a_at[0]), "v"(b_at[0]), "i"(kToggle) : "memory");
 #pragma unroll
         for (int i = 0; i < S; ++i) {
-            const unsigned off_n = x0 ^ (unsigned)((i + 1 < S ? i + 1 : i) << 5);
-            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3"
-                         : "=&v"(a_n), "=&v"(b_n) : "v"(a_base + off_n), "v"(b_base + off_n) : "memory");
+            constexpr int kLast = S - 1;
+            const int in = i + 1 < S ? i + 1 : kLast;
+            asm volatile("ds_read_b128 %0, %2 offset:%4\n\tds_read_b128 %1, %3 offset:%4"
+                         : "=&v"(a_n), "=&v"(b_n) : "v"(a_at[in]), "v"(b_at[in]), "i"(kToggle) : "memory");
             __builtin_amdgcn_sched_barrier(0);
             if (BIAS) bsum += a;
 #pragma unroll
@@ -166,7 +182,7 @@ __device__ __forceinline__ void unit_segment(const ffn_mlp_chain& ch, const ffn_
                     if (i < S / 4) {
                         if (has1) {
 #pragma unroll
-                            for (int jj = 0; jj < WPS; ++jj) FFN_DEPOSIT(nxt, i * WPS + jj);
+                            for (int jj = 0; jj < WPS; ++jj) FFN_DEPOSIT(1 - CUR, i * WPS + jj);
                         }
                     } else if (i < 3 * S / 4) {
                         if (has2) {
@@ -185,6 +201,12 @@ __device__ __forceinline__ void unit_segment(const ffn_mlp_chain& ch, const ffn_
         a_s += a_stride;
         b_s += b_stride;
         __builtin_amdgcn_s_barrier();     // LDS traffic of this block is complete (lgkmcnt(0) above)
+    };
+
+    for (int64_t blk = seg.blk_begin; blk < seg.blk_end; blk += 2) {
+        block_body(std::integral_constant<int, 0>{}, blk + 1 < seg.blk_end, blk + 2 < seg.blk_end);
+        if (blk + 1 < seg.blk_end)
+            block_body(std::integral_constant<int, 1>{}, blk + 2 < seg.blk_end, blk + 3 < seg.blk_end);
     }
 #undef FFN_REQUEST
 #undef FFN_DEPOSIT
@@ -253,13 +275,13 @@ __device__ __forceinline__ void head_segment(const ffn_mlp_chain& ch, const ffn_
         asm volatile("" : "+s"(chunk));                                                        \
         R[j] = chunk[tid];                                                                     \
     } while (0)
-#define FFN_DEPOSIT(buf, j) *reinterpret_cast<f32x4*>((buf) + (j) * 4096 + t16) = R[j]
+#define FFN_DEPOSIT(cur, j) *reinterpret_cast<f32x4*>(smem + image_a(cur) + (j) * 4096 + t16) = R[j]
     float dl[8], dl_next[8];
     load_dl(seg.blk_begin, dl);
 #pragma unroll
     for (int j = 0; j < 8; ++j) FFN_REQUEST(j);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) FFN_DEPOSIT(smem, j);
+    for (int j = 0; j < 8; ++j) FFN_DEPOSIT(0, j);
     x_s += x_stride;
     if (seg.blk_begin + 1 < seg.blk_end) {
 #pragma unroll
@@ -269,14 +291,12 @@ __device__ __forceinline__ void head_segment(const ffn_mlp_chain& ch, const ffn_
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     const int sw = li & 15;
-    const f32x4* all = reinterpret_cast<const f32x4*>(smem);
     for (int64_t blk = seg.blk_begin; blk < seg.blk_end; ++blk) {
         const int cur = (int)((blk - seg.blk_begin) & 1);
-        char* buf = smem + cur * kUnitBufBytes;
-        char* nxt = smem + (cur ^ 1) * kUnitBufBytes;
         const bool has1 = blk + 1 < seg.blk_end, has2 = blk + 2 < seg.blk_end;
         load_dl(has1 ? blk + 1 : blk, dl_next);
-        const f32x4* lx = x_ok ? reinterpret_cast<const f32x4*>(buf) + (32 * half + li) * 32 : all + kUnitZeroOffset / 16;
+        const f32x4* lx = reinterpret_cast<const f32x4*>(smem + image_a(cur)) +
+                          (x_ok ? (32 * half + li) * 32 : kImageBytes / 16);
         f32x4 a = lx[(2 * (8 * sh) + hh) ^ sw];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -289,7 +309,7 @@ __device__ __forceinline__ void head_segment(const ffn_mlp_chain& ch, const ffn_
             if (k < 2) {
                 if (has1) {
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) FFN_DEPOSIT(nxt, k * 4 + jj);
+                    for (int jj = 0; jj < 4; ++jj) FFN_DEPOSIT(cur ^ 1, k * 4 + jj);
                 }
             } else if (k < 6) {
                 if (has2) {
@@ -322,7 +342,8 @@ wgrad_unit_kernel(const ffn_mlp_chain ch, const ffn_wgrad_unit* __restrict__ uni
                   const float* __restrict__ dz, const float* __restrict__ d_logits, int64_t n,
                   float* __restrict__ partials) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (threadIdx.x < 128) reinterpret_cast<float*>(smem + kUnitZeroOffset)[threadIdx.x] = 0.0f;
+    for (int k = threadIdx.x; k < 4 * 128; k += 256)      // the zero row behind each image
+        reinterpret_cast<float*>(smem + (k >> 7) * kImageStride + kImageBytes)[k & 127] = 0.0f;
     __syncthreads();
     const int64_t num_blocks = (n + 31) / 32;
     const int seg_lo = seg_start[blockIdx.x], seg_hi = seg_start[blockIdx.x + 1];
