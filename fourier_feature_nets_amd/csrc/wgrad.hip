@@ -258,13 +258,26 @@ __device__ __forceinline__ void head_segment(const ffn_mlp_chain& ch, const ffn_
     float bsum = 0.0f;
     // this wave's 8 sample pairs of a block; d_logits straight from HBM (512 B / block),
     // fetched one block ahead so that their latency hides behind the previous block
+    // a block's d_logits are 32 consecutive float4: uniform block base + a per-lane constant
+    // + 32 B per step (immediate); only a ragged last block needs per-sample clamping
+    const int dl_lane = (2 * (8 * sh) + hh) * 4 + col;
     auto load_dl = [&](int64_t blk, float (&dst)[8]) {
+        typedef const float __attribute__((address_space(1)))* gfloat;
+        if ((blk + 1) * 32 <= n) {
+            gfloat base = (gfloat)uniform_ptr(d_logits + blk * 128);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int64_t sample = blk * 32 + 2 * (8 * sh + k) + hh;
-            const int64_t sc = sample < n ? sample : n - 1;
-            const float v = d_logits[sc * 4 + col];
-            dst[k] = (col_ok && sample < n) ? v : 0.0f;
+            for (int k = 0; k < 8; ++k) {
+                const float v = base[dl_lane + 8 * k];
+                dst[k] = col_ok ? v : 0.0f;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int64_t sample = blk * 32 + 2 * (8 * sh + k) + hh;
+                const int64_t sc = sample < n ? sample : n - 1;
+                const float v = d_logits[sc * 4 + col];
+                dst[k] = (col_ok && sample < n) ? v : 0.0f;
+            }
         }
     };
     f32x4 R[8];      // staged chunks of X (4 KiB each; past the window: its last chunk again)

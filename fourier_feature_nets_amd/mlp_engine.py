@@ -22,10 +22,10 @@ from .ops import _dev, _stream
 MAX_STEPS = 16
 WGRAD_GROUPS = 256          # one persistent workgroup per CU for the LDS-staged units
 # relative cost of one 32-sample block of a unit, by the number of 128x128 quadrants it has
-# (measured on MI355X: ~19.7k cycles for a full unit, of which ~16.4k are MFMA), and of a head
-# unit (HBM-bound, 32 KiB per block)
+# (calibrated on MI355X with FFN_UNIT_COST sweeps: a full unit is ~18k cycles per block, of which
+# 16.4k are MFMA issue), and of a head unit (32 MFMAs per wave, bound by its memory instructions)
 UNIT_COST = {4: 24, 2: 13, 1: 8}
-HEAD_COST = 9
+HEAD_COST = 6
 if os.environ.get("FFN_UNIT_COST"):       # "full,half,quarter,head" -- calibration experiments
     _c = [int(v) for v in os.environ["FFN_UNIT_COST"].split(",")]
     UNIT_COST, HEAD_COST = {4: _c[0], 2: _c[1], 1: _c[2]}, _c[3]
