@@ -389,6 +389,7 @@ def main():
         print(json.dumps(result), flush=True)
     if group is not None:
         import torch.distributed as dist
+        dist.barrier(group=group)        # rank 0 may still be in its reporting-only legs
         dist.destroy_process_group()
 
 
