@@ -261,3 +261,32 @@ def test_driver_scripts_keep_the_reference_flags_and_defaults():
     }
     for name in ref:
         assert mine[name] == ref[name], name
+
+
+def test_wgrad_split_is_balanced_and_plan_buckets_are_tight():
+    """Segments of the weight-gradient plan: every worker's cost stays within one block of the
+    mean (the first version let rounding leftovers pile up on the last worker), and the block
+    count a plan is made for exceeds the real one by at most 1/32."""
+    from fourier_feature_nets_amd.mlp_engine import MlpProgram
+    costs = [24, 24, 13, 8, 6]
+    for blocks in (1, 5, 97, 2813, 131072):
+        for workers in (4, 256):
+            segs, starts = MlpProgram._split(costs, blocks, workers)
+            assert len(starts) == workers + 1 and starts[-1] == len(segs)
+            loads = [sum((b1 - b0) * costs[j] for j, b0, b1 in segs[starts[w]:starts[w + 1]])
+                     for w in range(workers)]
+            total = sum(costs) * blocks
+            assert sum(loads) == total
+            assert max(loads) <= total / workers + max(costs)
+            # contiguous, complete coverage of every job
+            cover = {}
+            for j, b0, b1 in segs:
+                assert b0 < b1
+                assert cover.get(j, 0) == b0
+                cover[j] = b1
+            assert cover == {j: blocks for j in range(len(costs))}
+    for n in (1, 31, 32, 33, 2048, 2049, 90001, 4194304, 8388608 - 17):
+        blocks = (n + 31) // 32
+        planned = MlpProgram.plan_blocks(n)
+        assert blocks <= planned <= blocks + max(0, blocks // 32)
+        assert MlpProgram.plan_blocks(planned * 32) == planned          # idempotent
