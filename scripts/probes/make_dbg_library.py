@@ -37,7 +37,7 @@ def instrument(mode):
         s = sub(s, seg, "        " + STAMP % "-" + "\n" + seg)      # negative = a K loop starts
         s = sub(s, end, "    " + STAMP % "" + "\n}")
     else:
-        init_done = "    const f32x4* wp = reinterpret_cast<const f32x4*>(packed_w + L.w_off) + half * OT * 64 + w.lane;"
+        init_done = "    const f32x4* wp = reinterpret_cast<const f32x4*>(packed_w + L.w_off) + half * OT * 64;   // uniform"
         s = sub(s, init_done, "    " + STAMP % "" + "\n" + init_done)
         oloop = "    if (WIDE) team_barrier();        // every K loop of this step has finished reading the slab"
         s = sub(s, oloop, "    " + STAMP % "" + "\n" + oloop)
