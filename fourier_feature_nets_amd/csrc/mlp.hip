@@ -385,17 +385,13 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
         mma_group<OT>(acc, wa0, sel);   // group GA; the padding groups are all zero
     }
 
-    // ---- next step's first weight group rides under this step's epilogue -----------
-    if (next != nullptr) {
-        const int ot_next = next->out_tiles / TW;
-        const f32x4* wn = reinterpret_cast<const f32x4*>(packed_w + next->w_off) + half * ot_next * 64 + w.lane;
-#pragma unroll
-        for (int o = 0; o < 8; ++o)
-            if (o < ot_next) {
-                pre[o] = wn[o * 64];
-                pre[8 + o] = wn[(int64_t)(TW * ot_next + o) * 64];
-            }
-    }
+    // ---- next step's first K pair is fetched from inside the epilogue loop (two loads per
+    // output tile), so that their issue slots sit between the epilogue's VALU work instead of
+    // in front of it (a lone wave pays ~64 cycles per L2 load it cannot overlap)
+    const int ot_next = next != nullptr ? next->out_tiles / TW : 0;
+    const f32x4* wn = next != nullptr
+        ? reinterpret_cast<const f32x4*>(packed_w + next->w_off) + half * ot_next * 64 + w.lane
+        : nullptr;
 
     // ---- epilogue: bias / activation / mask, hand-off -------------------------------
     f32x4* save_out = nullptr;
@@ -412,7 +408,12 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
     if (WIDE) team_barrier();        // every K loop of this step has finished reading the slab
     unsigned sign_bits[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int o = 0; o < OT; ++o) {
+    for (int o = 0; o < 8; ++o) {
+        if (o < ot_next) {               // (uniform) the next step may have more tiles than this one
+            pre[o] = wn[o * 64];
+            pre[8 + o] = wn[(int64_t)(TW * ot_next + o) * 64];
+        }
+        if (o >= OT) continue;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int group = 4 * (OT * half + o) + q;   // K group of the next step
