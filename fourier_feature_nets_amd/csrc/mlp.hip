@@ -541,6 +541,19 @@ mlp_forward_kernel(const ffn_mlp_chain ch, const float* __restrict__ packed_w,
                                               kBiasLdsFloats * 4) + (threadIdx.x >> 7) * 64;
     const int64_t passes = WIDE ? (w.num_blocks + stride - 1) / stride : 0;
     const int64_t first = w.block;
+    // the inputs of a block are requested one block ahead: a lone wave has nothing else to
+    // cover a ~2k-cycle HBM latency in front of the first feature burst
+    float in_next[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto request_inputs = [&](int64_t block) {
+        block = block < w.num_blocks ? block : w.num_blocks - 1;
+        const int64_t sample = block * kSamplesPerWave + w.s;
+        const int64_t src = sample < n ? sample : n - 1;  // tail lanes recompute the last sample
+        in_next[0] = positions[src * 3 + 0]; in_next[1] = positions[src * 3 + 1]; in_next[2] = positions[src * 3 + 2];
+        if (views != nullptr) {
+            in_next[3] = views[src * 3 + 0]; in_next[4] = views[src * 3 + 1]; in_next[5] = views[src * 3 + 2];
+        }
+    };
+    request_inputs(first);
     for (int64_t pass = 0; WIDE ? pass < passes : w.block < w.num_blocks; ++pass) {
         if (WIDE) {
             w.block = first + pass * stride;
@@ -548,13 +561,9 @@ mlp_forward_kernel(const ffn_mlp_chain ch, const float* __restrict__ packed_w,
             if (!w.active) w.block = w.num_blocks - 1;
         }
         const int64_t sample = w.block * kSamplesPerWave + w.s;
-        const int64_t src = sample < n ? sample : n - 1;  // tail lanes recompute the last sample
-        w.x0 = positions[src * 3 + 0]; w.x1 = positions[src * 3 + 1]; w.x2 = positions[src * 3 + 2];
-        if (views != nullptr) {
-            w.v0 = views[src * 3 + 0]; w.v1 = views[src * 3 + 1]; w.v2 = views[src * 3 + 2];
-        } else {
-            w.v0 = w.v1 = w.v2 = 0.0f;
-        }
+        w.x0 = in_next[0]; w.x1 = in_next[1]; w.x2 = in_next[2];
+        w.v0 = in_next[3]; w.v1 = in_next[4]; w.v2 = in_next[5];
+        request_inputs(first + (pass + 1) * stride);
         w.logit[0] = w.logit[1] = w.logit[2] = w.logit[3] = 0.0f;
         run_chain<MODE, WIDE>(ch, w, packed_w, saved);
         f32x4 out;
@@ -588,15 +597,24 @@ mlp_backward_data_kernel(const ffn_mlp_chain ch, const float* __restrict__ packe
     w.x0 = w.x1 = w.x2 = w.v0 = w.v1 = w.v2 = 0.0f;
     const int64_t passes = WIDE ? (w.num_blocks + stride - 1) / stride : 0;
     const int64_t first = w.block;
+    // d_logits of a block are requested one block ahead (see the forward kernel)
+    f32x4 dl_next;
+    auto request_dl = [&](int64_t block) {
+        block = block < w.num_blocks ? block : w.num_blocks - 1;
+        const int64_t sample = block * kSamplesPerWave + w.s;
+        const f32x4 v = reinterpret_cast<const f32x4*>(d_logits)[sample < n ? sample : n - 1];
+        f32x4 zero; zero[0] = zero[1] = zero[2] = zero[3] = 0.0f;
+        dl_next = sample < n ? v : zero;
+    };
+    request_dl(first);
     for (int64_t pass = 0; WIDE ? pass < passes : w.block < w.num_blocks; ++pass) {
         if (WIDE) {
             w.block = first + pass * stride;
             w.active = w.block < w.num_blocks;
             if (!w.active) w.block = w.num_blocks - 1;
         }
-        const int64_t sample = w.block * kSamplesPerWave + w.s;
-        f32x4 zero; zero[0] = zero[1] = zero[2] = zero[3] = 0.0f;
-        w.dl = sample < n ? reinterpret_cast<const f32x4*>(d_logits)[sample] : zero;
+        w.dl = dl_next;
+        request_dl(first + (pass + 1) * stride);
         run_chain<kBackward, WIDE>(ch, w, packed_wt, dz);
         if (!WIDE) w.block += stride;
     }
