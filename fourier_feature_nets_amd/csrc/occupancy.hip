@@ -242,3 +242,62 @@ extern "C" int ffn_scatter_logits(const float* packed, const int32_t* index, int
                            (const float4*)packed, index, m, (float4*)out);
     return check_launch("ffn_scatter_logits");
 }
+
+// ---------------------------------------------------------------------------------- K10
+// Dense voxel radiance field lookup (voxels_model.py:35-45 of the reference: grid_sample of a
+// (1,4,S,S,S) volume, trilinear, padding_mode="border", align_corners=False, plus a bias).
+// Used as the opacity model of the focus sampler.  A position p maps to the continuous voxel
+// coordinate ((p/scale + 1) * S - 1) / 2 per axis, clamped to [0, S-1]; x indexes the last
+// (fastest) volume axis.  One thread per sample, four channels each; HBM/L2-gather bound.
+namespace ffn {
+__global__ void __launch_bounds__(256)
+voxels_forward_kernel(const float* __restrict__ volume, const float* __restrict__ bias,
+                      const float* __restrict__ positions, int64_t n, int side, float inv_scale,
+                      float4* __restrict__ out) {
+    const int64_t plane = (int64_t)side * side, chan = plane * side;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        int lo[3];
+        float frac[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            float c = ((positions[i * 3 + d] * inv_scale + 1.0f) * (float)side - 1.0f) * 0.5f;
+            c = fminf(fmaxf(c, 0.0f), (float)(side - 1));          // border padding
+            const float f = floorf(c);
+            lo[d] = (int)f;
+            frac[d] = c - f;
+        }
+        const int hi0 = min(lo[0] + 1, side - 1), hi1 = min(lo[1] + 1, side - 1), hi2 = min(lo[2] + 1, side - 1);
+        float acc[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float* v = volume + c * chan;
+            auto at = [&](int z, int y, int x) { return v[(int64_t)z * plane + (int64_t)y * side + x]; };
+            // same association as ATen's trilinear kernel: eight corner weights, summed
+            const float wx1 = frac[0], wx0 = 1.0f - frac[0];
+            const float wy1 = frac[1], wy0 = 1.0f - frac[1];
+            const float wz1 = frac[2], wz0 = 1.0f - frac[2];
+            float s = at(lo[2], lo[1], lo[0]) * (wx0 * wy0 * wz0);
+            s += at(lo[2], lo[1], hi0) * (wx1 * wy0 * wz0);
+            s += at(lo[2], hi1, lo[0]) * (wx0 * wy1 * wz0);
+            s += at(lo[2], hi1, hi0) * (wx1 * wy1 * wz0);
+            s += at(hi2, lo[1], lo[0]) * (wx0 * wy0 * wz1);
+            s += at(hi2, lo[1], hi0) * (wx1 * wy0 * wz1);
+            s += at(hi2, hi1, lo[0]) * (wx0 * wy1 * wz1);
+            s += at(hi2, hi1, hi0) * (wx1 * wy1 * wz1);
+            acc[c] = s + bias[c];
+        }
+        out[i] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+}
+}  // namespace ffn
+
+extern "C" int ffn_voxels_forward(const float* volume, const float* bias, const float* positions,
+                                  int64_t n, int side, float scale, float* out, void* stream) {
+    if (n == 0) return 0;
+    if (n < 0 || side < 1 || !(scale > 0.0f)) return fail_arg("ffn_voxels_forward: shape");
+    hipLaunchKernelGGL(ffn::voxels_forward_kernel, dim3(stream_grid(n)), dim3(256), 0,
+                       (hipStream_t)stream, volume, bias, positions, n, side, 1.0f / scale,
+                       (float4*)out);
+    return check_launch("ffn_voxels_forward");
+}

@@ -220,3 +220,14 @@ def scatter_logits(packed: torch.Tensor, index: torch.Tensor, n: int,
     _lib.call("ffn_scatter_logits", _dev(packed), _dev(index, torch.int32), c_i64(packed.shape[0]),
               c_i64(n), c_f(empty_sigma_logit), _dev(out), _stream())
     return out
+
+
+# --------------------------------------------------------------------------------- voxels
+def voxels_forward(volume: torch.Tensor, bias: torch.Tensor, positions: torch.Tensor, side: int,
+                   scale: float) -> torch.Tensor:
+    """K10.  volume (4,S,S,S), bias (4), positions (N,3) -> logits (N,4)."""
+    n = positions.shape[0]
+    out = torch.empty((n, 4), dtype=torch.float32, device=positions.device)
+    _lib.call("ffn_voxels_forward", _dev(volume), _dev(bias), _dev(positions, name="positions"),
+              c_i64(n), c_i(side), c_f(scale), _dev(out), _stream())
+    return out

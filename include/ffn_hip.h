@@ -360,6 +360,13 @@ int ffn_occupancy_compact(const float* positions, const float* views, int64_t n,
 int ffn_scatter_logits(const float* packed, const int32_t* index, int64_t m, int64_t n,
                        float empty_sigma_logit, float* out, void* stream);
 
+/* ---- K10: dense voxel radiance field (voxels_model.py:35-45): trilinear lookup of a
+ * (4,S,S,S) volume at positions/scale in [-1,1]^3 (grid_sample semantics: x = fastest axis,
+ * border padding, align_corners = false) + bias (4) -> logits (N,4).  Inference only; it is
+ * the opacity model the README workflows hand to the focus sampler. */
+int ffn_voxels_forward(const float* volume, const float* bias, const float* positions, int64_t n,
+                       int side, float scale, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

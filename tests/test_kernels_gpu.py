@@ -512,3 +512,28 @@ def test_abi_rejects_bad_arguments_with_a_message():
         _lib.call("ffn_occupancy_build", ptr, c_i(0), ctypes.c_float(0.1), c_i(0), c_p(0), ptr, stream)
     torch.cuda.synchronize()              # nothing was launched, nothing is poisoned
     assert float(buf.abs().max()) == 0.0
+
+
+def test_voxels_lookup_against_grid_sample():
+    """K10 == F.grid_sample(volume, p/scale, padding_mode="border", align_corners=False) + bias
+    (voxels_model.py:35-45), including positions outside the cube."""
+    import fourier_feature_nets_amd as ffn
+    torch.manual_seed(8)
+    for side, scale in ((8, 1.0), (5, 1.5), (32, 0.7)):
+        vox = ffn.Voxels(side, scale)
+        with torch.no_grad():
+            vox.voxels.copy_(torch.randn_like(vox.voxels))
+            vox.bias.copy_(torch.randn(1, 4))
+        pos = (torch.rand(4099, 3) * 2 - 1) * scale * 1.3
+        pos[0] = torch.tensor([scale, -scale, 0.0])
+        grid = (pos / scale).reshape(1, -1, 1, 1, 3)
+        exp = torch.nn.functional.grid_sample(vox.voxels.detach(), grid, padding_mode="border",
+                                              align_corners=False)
+        exp = exp.transpose(1, 2).reshape(-1, 4) + vox.bias.detach()
+        vox = vox.to(dev())
+        with torch.no_grad():
+            got = vox(pos.to(dev()))
+        # fp32 rounding of the voxel coordinate differs from ATen's by a few ulp of the weights
+        np.testing.assert_allclose(got.cpu().numpy(), exp.numpy(), rtol=1e-5, atol=2e-5)
+        with pytest.raises(NotImplementedError):
+            vox(pos.to(dev()))                      # gradients through the volume: out of scope
