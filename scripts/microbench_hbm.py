@@ -10,7 +10,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from fourier_feature_nets_amd import ops  # noqa: E402
-from oracle import ffn_oracle as orc  # noqa: E402  (frequency table only)
+import fourier_feature_nets_amd as ffn  # noqa: E402
 
 
 def timed(fn, iters=20):
@@ -45,7 +45,7 @@ def main():
     out["composite_bwd"] = (R * (20 * S + 16 * S + 16), sec)
     n = R * S
     x = torch.rand(n, 3, device=dev) * 2 - 1
-    b = orc.positional_b_values(5.5, 256, 3).contiguous().to(dev)
+    b = ffn.PositionalFourierMLP(3, 4, 5.5).b_values.data.clone().contiguous().to(dev)
     a = torch.ones(b.shape[1], device=dev)
     sec = timed(lambda: ops.fourier_encode(x, b, a, math.pi, False), iters=5)
     out["fourier_encode (tiny: 2F = 510)"] = (n * (12 + 4 * 2 * b.shape[1]), sec)

@@ -24,13 +24,13 @@ def main():
     ap.add_argument("--model", default="positional", choices=["positional", "raw"])
     ap.add_argument("--hidden", type=int, default=3)
     args = ap.parse_args()
-    from oracle import ffn_oracle as orc
+    import fourier_feature_nets_amd as ffn
     from fourier_feature_nets_amd.mlp_engine import DenseSpec, EncodingSpec, MlpProgram
     dev = torch.device("cuda:0")
     torch.manual_seed(20080524)
     C = args.channels
     if args.model == "positional":
-        b = orc.positional_b_values(5.5, 256, 3).to(dev)
+        b = ffn.PositionalFourierMLP(3, 4, 5.5).b_values.data.clone().to(dev)
         a = torch.ones(b.shape[1], device=dev)
         first = 2 * b.shape[1]
     else:
