@@ -422,7 +422,9 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
                 const unsigned word = o < 2 ? mbits.x : (o < 4 ? mbits.y : (o < 6 ? mbits.z : mbits.w));
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
-                    const int bit = 16 * (o & 1) + 4 * q + p;
+                    // (a word that received a single tile -- OT == 1 -- was shifted 16 times only)
+                    const int filled = ((OT & 1) && o == OT - 1) ? 16 : 32;
+                    const int bit = filled - 1 - (16 * (o & 1) + 4 * q + p);
                     y[p] = ((word >> bit) & 1u) ? acc[o][4 * q + p] : 0.0f;
                 }
                 w.act[group * 64 + w.lane] = y;
@@ -431,7 +433,11 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
                     float t = acc[o][4 * q + p];
-                    if (MODE == kTrainFwd) sign_bits[o >> 1] |= (t > 0.0f ? 1u : 0u) << (16 * (o & 1) + 4 * q + p);
+                    // sign bit of (0 - t) is set exactly when t > 0 (0 - (+-0) = +0); shifting it in
+                    // from the right is one v_alignbit: value (o&1, q, p) ends at bit 31 - (16(o&1)+4q+p)
+                    if (MODE == kTrainFwd)
+                        sign_bits[o >> 1] = __builtin_amdgcn_alignbit(sign_bits[o >> 1],
+                                                                      __builtin_bit_cast(unsigned, 0.0f - t), 31);
                     if (L.relu) t = __builtin_fmaxf(t, 0.0f);
                     y[p] = t;
                 }

@@ -255,8 +255,9 @@ int ffn_mlp_pack(const float* src, int rows, int cols, int ld, int transpose,
  * `saved` (block layout): its input activations (save_in_slot), the encoding features it
  * generated (save_enc_slot), its output when a fused head reads it (save_out_slot); and every
  * ReLU step writes the sign bits of its output into `masks` (num_slots * num_blocks * W
- * uint32, W = 256, or 512 for a wide chain: [slot][block][half][lane][4], bit 16*(tile&1)+r
- * of word tile/2 = accumulator register r of that lane, tiles counted inside the wave's half)
+ * uint32, W = 256, or 512 for a wide chain: [slot][block][half][lane][4], bit 31-(16*(tile&1)+r)
+ * of word tile/2 = accumulator register r of that lane, tiles counted inside the wave's half;
+ * an odd tile count leaves the last word's bits shifted down by 16)
  * for the backward-data chain.  `bias` = bias_floats floats: per step its padded bias, plus
  * the fused heads' blocks (head_off). */
 int ffn_mlp_forward(const ffn_mlp_chain* chain, const float* packed_w, const float* bias,
