@@ -84,13 +84,40 @@ def analytic_images(sampler, radius=0.6):
     return img.cpu().numpy()
 
 
+def physical_cores():
+    """(physical cores, logical CPUs) of this host: distinct (package, core) pairs of
+    /proc/cpuinfo, falling back to the logical count."""
+    logical = os.cpu_count() or 1
+    try:
+        pairs, phys, core = set(), None, None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("physical id"):
+                    phys = line.split(":")[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":")[1].strip()
+                elif not line.strip():
+                    if phys is not None and core is not None:
+                        pairs.add((phys, core))
+                    phys = core = None
+        if phys is not None and core is not None:
+            pairs.add((phys, core))
+        if pairs:
+            return len(pairs), logical
+    except OSError:
+        pass
+    return logical, logical
+
+
 def cpu_baseline(args, model_state, log):
     """The oracle's training step (the reference's ATen op sequence restated) on the host
-    cores, on a bounded sample of the same workload."""
+    cores, on a bounded sample of the same workload: full training step and forward only."""
     from oracle import ffn_oracle as orc
     # torch's CPU kernels stop scaling (and then regress) far below the core count of a GPU
-    # host; use the thread count that is fastest for this op mix and report it as `cores`
-    cores = min(os.cpu_count() or 1, 32)
+    # host: `cores` = the threads actually used (the fastest count for this op mix, at most one
+    # per physical core); the host's physical / logical counts are reported next to it
+    phys, logical = physical_cores()
+    cores = min(phys, 32)
     torch.set_num_threads(cores)
     rays, S = 1024, args.samples
     rng = torch.Generator().manual_seed(1)
@@ -118,9 +145,24 @@ def cpu_baseline(args, model_state, log):
         one_step()
         done += 1
     elapsed = time.time() - t0
-    return {"value": rays * done / elapsed, "unit": "rays/s", "cores": cores, "kind": "port",
-            "sample": "%d training steps of %d rays x %d samples (oracle: the reference's ATen op "
-                      "sequence on the host CPU), %.1f s" % (done, rays, S, elapsed)}
+    # forward only (sampling + model + compositing, no autograd): the render-side baseline
+    t1 = time.time()
+    fwd_done = 0
+    with torch.no_grad():
+        while time.time() - t1 < 5.0 and fwd_done < 40 or fwd_done < 2:
+            noise = torch.rand((rays, S), generator=rng)
+            t = orc.uniform_t(near, far, S, noise)
+            pos = starts.unsqueeze(1) + t.unsqueeze(-1) * dirs.unsqueeze(1)
+            trainer.loss(pos, None, t, gt_c, gt_a)
+            fwd_done += 1
+    fwd_elapsed = time.time() - t1
+    return {"value": rays * done / elapsed, "unit": "rays/s", "cores": cores,
+            "physical_cores": phys, "logical_cpus": logical, "kind": "port",
+            "forward_only_rays_per_s": rays * fwd_done / fwd_elapsed,
+            "sample": "%d training steps (%.1f s) and %d forward passes (%.1f s) of %d rays x %d "
+                      "samples (oracle: the reference's ATen op sequence on the host CPU, "
+                      "torch.set_num_threads(%d))" % (done, elapsed, fwd_done, fwd_elapsed, rays,
+                                                      S, cores)}
 
 
 def target_shape_leg(device):
@@ -189,8 +231,34 @@ def target_shape_leg(device):
             "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "dtype": "f32"}
 
 
+def spawn_ranks(args):
+    """``python bench.py --gpus N`` without a launcher: re-executes itself under
+    ``torch.distributed.run`` with N ranks on this node (one per GPU) and passes rank 0's JSON
+    line through.  With fewer than N GPUs visible the run is refused unless
+    FFN_BENCH_SHARE_GPU=1 (all ranks on cuda:0 over gloo: a functional check of the sharding /
+    reduction / timing code on a one-GPU box, never a measurement)."""
+    import socket
+    import subprocess
+    visible = torch.cuda.device_count()
+    env = dict(os.environ)
+    if visible < args.gpus:
+        if env.get("FFN_BENCH_SHARE_GPU") != "1":
+            raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (set FFN_BENCH_SHARE_GPU=1 "
+                             "for a functional run with all ranks on cuda:0)" % (args.gpus, visible))
+        env.setdefault("FFN_BENCH_BACKEND", "gloo")
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(spawn_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -198,8 +266,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no GPU visible and there is no CPU fallback")
     # FFN_BENCH_SHARE_GPU=1 (with FFN_BENCH_BACKEND=gloo): all ranks on cuda:0 -- a functional
     # check of the N > 1 path on a one-GPU box, not a measurement
-    if os.environ.get("FFN_BENCH_SHARE_GPU") == "1":
+    shared_gpu = os.environ.get("FFN_BENCH_SHARE_GPU") == "1"
+    if shared_gpu:
         local_rank = 0
+        os.environ.setdefault("FFN_BENCH_BACKEND", "gloo")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     group = None
@@ -213,7 +283,10 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
         group = dist.group.WORLD
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d (launch with "
+                         "torch.distributed.run --nproc-per-node == --gpus, or without a launcher)"
+                         % (args.gpus, world))
 
     import contextlib
     import io
@@ -239,6 +312,8 @@ def main():
         dataset = ffn.ImageDataset("train", images, bounds, cams, args.samples, True, True,
                                    anneal_start=0.2, num_anneal_steps=2000, device=device)
     engine = ffn.TrainEngine(model, 0.0, group)
+    if group is not None:
+        engine.collective_events = []
     # batches are drawn from the rays that hit the volume, so every step traces exactly
     # rays*world rays (the validity filter of get_rays then keeps all of them)
     valid_ids = torch.nonzero(dataset.sampler.valid != 0).flatten()
@@ -283,6 +358,8 @@ def main():
     barrier()
     torch.cuda.synchronize()
     timed_call.on = True
+    if engine.collective_events is not None:
+        engine.collective_events.clear()
     t0 = time.perf_counter()
     loss = None
     for step in range(args.warmup, args.warmup + args.steps):
@@ -379,6 +456,18 @@ def main():
                        "samples_per_ray": args.samples, "includes": "sampling, fused MLP, "
                        "composite, u8 assembly and the D2H copy of each frame"},
         }
+        if engine.collective_events:
+            us = [1e3 * a.elapsed_time(b) for a, b in engine.collective_events]
+            backend = os.environ.get("FFN_BENCH_BACKEND", "nccl")
+            result["collective"] = {
+                "op": "all_reduce(sum) of [flat gradients | 2 loss sums], one per step",
+                "backend": "rccl" if backend == "nccl" else backend + " (host-staged)",
+                "ranks": world, "bytes": int(engine.reduce_buf.numel()) * 4,
+                "avg_us": round(sum(us) / len(us), 1), "max_us": round(max(us), 1),
+                "frac_of_step": round(sum(us) / len(us) * 1e-3 / (1e3 * elapsed / args.steps), 4),
+                "shared_gpu": shared_gpu}
+        else:
+            result["collective"] = None
         result["north_star_shape"] = None if (args.no_target_shape or args.model != "tiny") \
             else target_shape_leg(device)
         if not args.no_cpu_baseline and world == 1 and args.model == "tiny":

@@ -72,7 +72,11 @@ class TrainEngine:
             p.data = flat[offset:offset + n].view(p.shape)
             offset += n
         self.flat = flat
-        self.grads = torch.zeros_like(flat)
+        # gradients + the two loss sums travel as ONE buffer, so that data parallel costs one
+        # collective per step (the all-reduce of ~1-2.4 MB is latency-bound)
+        self.reduce_buf = torch.zeros((total + 2,), dtype=torch.float32, device=device)
+        self.grads = self.reduce_buf[:total]
+        self.loss_sums = self.reduce_buf[total:]
         self.exp_avg = torch.zeros_like(flat)
         self.exp_avg_sq = torch.zeros_like(flat)
         self.scratch = torch.empty(((total + 1023) // 1024,), dtype=torch.float32, device=device)
@@ -82,6 +86,12 @@ class TrainEngine:
         self.count = 0
         self.device = device
         self.group = process_group
+        self._host_staged = False
+        if process_group is not None:
+            import torch.distributed as dist
+            # a gloo group (CPU tests, several ranks sharing one GPU) reduces through the host
+            self._host_staged = dist.get_backend(process_group) == "gloo"
+        self.collective_events = None     # set to [] to record (start, end) events per all-reduce
         self._saved = {}
         self.loss_history = None          # set to [] to record every step's loss (device scalars)
         model.invalidate_packed()
@@ -126,10 +136,10 @@ class TrainEngine:
         alphas = dataset._gt_alphas()
         aw = float(dataset.alpha_weight) if alphas is not None else 0.0
         prog = self.model.program()
-        sums = torch.zeros((2,), dtype=torch.float32, device=self.device)
+        sums = self.loss_sums
         per_launch = max(1, self.max_samples // sampler.num_samples)
         if count == 0:
-            self.grads.zero_()
+            self.reduce_buf.zero_()
         for lo in range(0, count, per_launch):
             chunk = rays[lo:lo + per_launch]
             first = lo == 0
@@ -138,7 +148,8 @@ class TrainEngine:
             logits = prog.forward(pos, views, saved)
             color, alpha, _ = ops.composite_fwd(logits, t, False, self.nan_flag)
             part, d_color, d_alpha = ops.mse_loss(color, alpha, dataset.colors, alphas, chunk,
-                                                  1.0 / (3 * global_count), aw / global_count)
+                                                  1.0 / (3 * global_count), aw / global_count,
+                                                  sums_out=sums if first else None)
             d_logits = ops.composite_bwd(logits, t, d_color, d_alpha)
             if first:
                 prog.backward(d_logits.view(-1, 4), pos, views, saved, self.grads)
@@ -147,26 +158,45 @@ class TrainEngine:
                     self._grads_part = torch.empty_like(self.grads)
                 prog.backward(d_logits.view(-1, 4), pos, views, saved, self._grads_part)
                 self.grads.add_(self._grads_part)
-            sums = sums + part
+                sums.add_(part)
         if self.group is not None:
-            import torch.distributed as dist
-            dist.all_reduce(self.grads, group=self.group)      # RCCL over xGMI, one flat buffer
-            dist.all_reduce(sums, group=self.group)
+            self._all_reduce()
         self.count += 1
         ops.clip_adam(self.flat, self.grads, self.exp_avg, self.exp_avg_sq, self.count, lr,
                       weight_decay=self.weight_decay, scratch=self.scratch,
                       norm_out=self.grad_norm)
         self.model.invalidate_packed()
+        # (a fresh tensor: the reduce buffer is overwritten by the next step)
         loss = sums[0] / (3 * global_count) + aw * (sums[1] / global_count)
         if self.loss_history is not None:
             self.loss_history.append(loss)
         return loss
+
+    def _all_reduce(self):
+        """Sum of [flat gradients | 2 loss sums] over the ranks: one RCCL all-reduce over xGMI
+        (or, for a gloo group, one staged through the host)."""
+        import torch.distributed as dist
+        events = self.collective_events
+        if events is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        if self._host_staged:
+            host = self.reduce_buf.cpu()
+            dist.all_reduce(host, group=self.group)
+            self.reduce_buf.copy_(host)
+        else:
+            dist.all_reduce(self.reduce_buf, group=self.group)
+        if events is not None:
+            e1.record()
+            events.append((e0, e1))
 
     def eval_loss(self, dataset, batch, step: Optional[int]) -> torch.Tensor:
         """Forward-only loss of a batch (the body of ``_validate``)."""
         sampler = dataset.sampler
         rays = dataset.ray_ids(batch)
         count = int(rays.numel())
+        if count == 0:      # mean over an empty batch: NaN like the reference, not an error
+            return torch.full((), float("nan"), dtype=torch.float32, device=self.device)
         alphas = dataset._gt_alphas()
         aw = float(dataset.alpha_weight) if alphas is not None else 0.0
         t, pos, views = self._samples(sampler, rays, step)

@@ -192,6 +192,73 @@ blend_weights_kernel(const float* __restrict__ t, const float* __restrict__ sigm
     }
 }
 
+// K5w backward: d(loss)/d(sigma) and d(loss)/d(t) from d(loss)/d(weights) -- the autograd of
+// utils.py:72-97 (exp, minimum with its 1/2-1/2 tie rule, cumprod) in closed form:
+//   dL/dalpha_s = g_s T_s - dtau/du * Q_s / tau_s,   Q_s = sum_{k>s} g_k w_k
+//   dL/dsigma_s = dL/dalpha_s * e_s * delta_s,       dL/ddelta_s = dL/dalpha_s * e_s * sigma_s
+//   dL/dt_s     = dL/ddelta_{s-1} - dL/ddelta_s      (delta_{S-1} = 1e10 is a constant)
+template <int ROWS>
+__global__ void __launch_bounds__(256)
+blend_weights_bwd_kernel(const float* __restrict__ t, const float* __restrict__ sigma,
+                         const float* __restrict__ d_weights, int R, int S,
+                         float* __restrict__ d_sigma, float* __restrict__ d_t) {
+    const int lane = lane_id();
+    const int wave = (int)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6);
+    const int waves = (int)((gridDim.x * (int64_t)blockDim.x) >> 6);
+    for (int ray = wave; ray < R; ray += waves) {
+        const float* tr = t + (int64_t)ray * S;
+        const float* sg = sigma + (int64_t)ray * S;
+        const float* gw = d_weights + (int64_t)ray * S;
+        float sig[ROWS], delta[ROWS], e[ROWS], alpha[ROWS], u[ROWS], tau[ROWS], T[ROWS], dd[ROWS];
+        float carry = 1.0f;
+#pragma unroll
+        for (int row = 0; row < ROWS; ++row) {
+            const int s = row * 64 + lane;
+            sig[row] = 0.0f; delta[row] = 0.0f; e[row] = 1.0f; alpha[row] = 0.0f; u[row] = 1.0f; tau[row] = 1.0f;
+            if (s < S) {
+                sig[row] = sg[s];
+                delta[row] = (s == S - 1) ? 1e10f : tr[s + 1] - tr[s];
+                e[row] = expf(-(sig[row] * delta[row]));
+                alpha[row] = 1.0f - e[row];
+                u[row] = (1.0f - alpha[row]) + 1e-10f;
+                tau[row] = u[row] < 1.0f ? u[row] : 1.0f;
+            }
+            const float incl = wave_scan_mul(tau[row], lane);
+            const float excl = wave_shift_up(incl, 1.0f);
+            T[row] = carry * excl;
+            carry *= wave_last(incl);
+        }
+        float tail = 0.0f;
+#pragma unroll
+        for (int row = ROWS - 1; row >= 0; --row) {
+            const int s = row * 64 + lane;
+            const bool active = s < S;
+            const float g = active ? gw[s] : 0.0f;
+            const float gwv = g * (alpha[row] * T[row]);
+            const float incl = wave_suffix_add(gwv, lane);
+            const float Q = (incl - gwv) + tail;
+            tail += __shfl(incl, 0, 64);
+            dd[row] = 0.0f;
+            if (active) {
+                const float dtau_du = u[row] < 1.0f ? 1.0f : (u[row] == 1.0f ? 0.5f : 0.0f);
+                const float dL_dtau = (s < S - 1) ? Q / tau[row] : 0.0f;
+                const float dL_dalpha = g * T[row] - dtau_du * dL_dtau;
+                d_sigma[(int64_t)ray * S + s] = dL_dalpha * e[row] * delta[row];
+                dd[row] = (s < S - 1) ? dL_dalpha * e[row] * sig[row] : 0.0f;
+            }
+        }
+        if (d_t != nullptr) {
+#pragma unroll
+            for (int row = 0; row < ROWS; ++row) {
+                const int s = row * 64 + lane;
+                const float first = row > 0 ? wave_last(dd[row > 0 ? row - 1 : 0]) : 0.0f;
+                const float prev = wave_shift_up(dd[row], first);
+                if (s < S) d_t[(int64_t)ray * S + s] = prev - dd[row];
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------- K5b
 // Recomputes the forward terms (cheaper than storing 12 B/sample) and walks the rows in
 // reverse to form Q_s = sum_{j>s} g_j w_j, the quantity cumprod's backward needs.
@@ -329,6 +396,27 @@ extern "C" int ffn_blend_weights(const float* t, const float* sigma, int num_ray
     hipLaunchKernelGGL(blend_weights_kernel, dim3(ray_grid(num_rays)), dim3(256), 0,
                        (hipStream_t)stream, t, sigma, num_rays, num_samples, weights);
     return check_launch("ffn_blend_weights");
+}
+
+extern "C" int ffn_blend_weights_bwd(const float* t, const float* sigma, const float* d_weights,
+                                     int num_rays, int num_samples, float* d_sigma, float* d_t,
+                                     void* stream) {
+    if (num_rays == 0) return 0;
+    if (num_rays < 0 || num_samples < 1) return fail_arg("ffn_blend_weights_bwd: shape");
+    const int rows = (num_samples + 63) / 64;
+    const dim3 grid(ray_grid(num_rays)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define FFN_BWB(ROWS)                                                                          \
+    hipLaunchKernelGGL(blend_weights_bwd_kernel<ROWS>, grid, block, 0, st, t, sigma, d_weights, \
+                       num_rays, num_samples, d_sigma, d_t)
+    switch (rows) {
+        case 1: FFN_BWB(1); break;
+        case 2: FFN_BWB(2); break;
+        case 3: case 4: FFN_BWB(4); break;
+        default: return fail_arg("ffn_blend_weights_bwd: num_samples > 256");
+    }
+#undef FFN_BWB
+    return check_launch("ffn_blend_weights_bwd");
 }
 
 extern "C" int ffn_composite_bwd(const float* logits, const float* t, const float* d_color,

@@ -170,8 +170,10 @@ class ImageDataset(RayDataset):
             element = torch.from_numpy(_ellipse(2 * radius + 1)).float().to(dev)
             for cam in range(len(self._images)):
                 mask = torch.from_numpy((self._images[cam, ..., 3] > 0).astype(np.float32)).to(dev)
+                # (counts of 0/1 products: exact in fp32 for a direct convolution; the 0.5
+                # threshold also absorbs the rounding noise of an FFT / Winograd algorithm)
                 grown = torch.nn.functional.conv2d(mask[None, None], element[None, None],
-                                                   padding=radius) > 0
+                                                   padding=radius) > 0.5
                 ids = torch.nonzero(grown.reshape(-1)).flatten() + cam * per_cam
                 ranges.append((total, total + int(ids.numel())))
                 total += int(ids.numel())
@@ -345,7 +347,7 @@ class ImageDataset(RayDataset):
                             self.include_alpha, stratified, self.sampler.opacity_model,
                             self.sampler.batch_size, self.color_space, self.sparse_size,
                             self.sampler.anneal_start, self.sampler.num_anneal_steps,
-                            self.alpha_weight if self.alpha_weight else 0.1,
+                            self.alpha_weight,      # unchanged, like image_dataset.py:349-362
                             device=self.sampler.device)
 
     @staticmethod

@@ -17,7 +17,7 @@ import torch
 
 from . import _lib
 from ._lib import c_i, c_i64, c_p
-from .ops import _dev, _stream
+from .ops import _call, _dev
 
 MAX_STEPS = 16
 WGRAD_GROUPS = 256          # one persistent workgroup per CU for the LDS-staged units
@@ -502,9 +502,9 @@ class MlpProgram:
             groups, tiles = self.fwd_shapes[i]
             w = spec.weight.detach()
             dst = self.packed_fwd[L.w_off:L.w_off + groups * tiles * 256]
-            _lib.call("ffn_mlp_pack", _dev(w), c_i(w.shape[0]), c_i(w.shape[1]), c_i(w.stride(0)),
+            _call("ffn_mlp_pack", _dev(w), c_i(w.shape[0]), c_i(w.shape[1]), c_i(w.stride(0)),
                       c_i(0), c_p(0), _dev(self.col_maps[i], torch.int32), c_i(groups), c_i(tiles),
-                      _dev(dst), _stream())
+                      _dev(dst))
             self.bias_buf[L.b_off:L.b_off + spec.out].copy_(spec.bias.detach())
         for (i, off, channels) in self.fused_heads:
             spec = self.layers[i]
@@ -516,9 +516,9 @@ class MlpProgram:
             w = self.layers[c].weight.detach()
             dst = self.packed_bwd[off:off + groups * tiles * 256]
             # operand rows = input channels (act part), operand K = output rows of layer c
-            _lib.call("ffn_mlp_pack", _dev(w), c_i(w.shape[0]), c_i(self.layers[c].act_in),
+            _call("ffn_mlp_pack", _dev(w), c_i(w.shape[0]), c_i(self.layers[c].act_in),
                       c_i(w.stride(0)), c_i(1), c_p(0), c_p(0), c_i(groups), c_i(tiles),
-                      _dev(dst), _stream())
+                      _dev(dst))
 
     # ------------------------------------------------------------------ launches
     @staticmethod
@@ -560,10 +560,9 @@ class MlpProgram:
         n = positions.shape[0]
         logits = torch.empty((n, 4), dtype=torch.float32, device=self.device)
         acts, masks = (None, None) if saved is None else self._split_saved(saved, n)
-        _lib.call("ffn_mlp_forward", ctypes.byref(self.fwd), _dev(self.packed_fwd),
+        _call("ffn_mlp_forward", ctypes.byref(self.fwd), _dev(self.packed_fwd),
                   _dev(self.bias_buf), _dev(positions, name="positions"),
-                  _dev(views, name="views"), c_i64(n), _dev(logits), _dev(acts), _dev(masks),
-                  _stream())
+                  _dev(views, name="views"), c_i64(n), _dev(logits), _dev(acts), _dev(masks))
         return logits
 
     def backward(self, d_logits: torch.Tensor, positions: torch.Tensor,
@@ -576,12 +575,12 @@ class MlpProgram:
         ws = self.workspace(n)
         saved, masks = self._split_saved(saved, n)
         if self.bwd.num_steps > 0:
-            _lib.call("ffn_mlp_backward_data", ctypes.byref(self.bwd), _dev(self.packed_bwd),
-                      _dev(d_logits), c_i64(n), _dev(masks), _dev(ws.dz), _stream())
-        _lib.call("ffn_mlp_wgrad_units", ctypes.byref(self.fwd),
+            _call("ffn_mlp_backward_data", ctypes.byref(self.bwd), _dev(self.packed_bwd),
+                      _dev(d_logits), c_i64(n), _dev(masks), _dev(ws.dz))
+        _call("ffn_mlp_wgrad_units", ctypes.byref(self.fwd),
                   _dev(self.wgrad_units_dev, torch.uint8), _dev(ws.unit_segments, torch.uint8),
                   _dev(ws.unit_seg_start, torch.int32), c_i(WGRAD_GROUPS), _dev(saved),
-                  _dev(ws.dz), _dev(d_logits), c_i64(n), _dev(ws.partials), _stream())
-        _lib.call("ffn_mlp_wgrad_reduce", _dev(ws.reduce_jobs, torch.uint8),
-                  c_i(ws.num_reduce_jobs), _dev(ws.partials), _dev(grads), _stream())
+                  _dev(ws.dz), _dev(d_logits), c_i64(n), _dev(ws.partials))
+        _call("ffn_mlp_wgrad_reduce", _dev(ws.reduce_jobs, torch.uint8),
+                  c_i(ws.num_reduce_jobs), _dev(ws.partials), _dev(grads))
         return grads

@@ -22,6 +22,10 @@ class _FusedChainFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, grad_mode, positions, views, *params):
         prog = module.program()
+        if grad_mode and (positions.requires_grad or (views is not None and views.requires_grad)):
+            raise NotImplementedError(
+                "gradients w.r.t. sample positions / view directions are not produced by the "
+                "fused kernels (the volume-rendering path never needs them); detach the inputs")
         positions = positions.contiguous()
         views = None if views is None else views.contiguous()
         # grad mode is sampled by the caller: inside Function.forward it is always off, and
@@ -40,6 +44,10 @@ class _FusedChainFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_logits):
         positions, views = ctx.saved_tensors
+        if ctx.saved_acts is None:
+            raise RuntimeError("the fused MLP frees its activation slabs in backward: a second "
+                               "backward through the same forward (retain_graph=True) is not "
+                               "supported -- run the forward again")
         prog = ctx.module.program()
         grads = torch.empty((prog.num_grad_floats,), dtype=torch.float32, device=positions.device)
         prog.backward(d_logits.contiguous(), positions, views, ctx.saved_acts, grads)
@@ -68,9 +76,21 @@ class _FusedModel(nn.Module):
         raise NotImplementedError
 
     def invalidate_packed(self):
-        """Call after the weights were changed behind autograd's back (e.g. by the fused
-        optimiser kernel) so the next forward re-derives the MFMA operand copies."""
+        """The kernels read MFMA-operand COPIES of the weights, re-derived whenever a
+        parameter's autograd version changes.  Writes that bypass the version counter --
+        ``p.data.copy_()`` / ``layer.weight.data.uniform_()``, raw-pointer updates such as the
+        fused optimiser kernel -- must be followed by this call, or the next forward uses stale
+        copies.  ``load_state_dict`` and ``train()`` / ``eval()`` switches call it themselves."""
         self._packed_key = None
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self.invalidate_packed()
+        return out
+
+    def train(self, mode: bool = True):
+        self.invalidate_packed()
+        return super().train(mode)
 
     def program(self) -> MlpProgram:
         params = self._dense_params()

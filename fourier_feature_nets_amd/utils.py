@@ -11,12 +11,28 @@ import torch
 from . import ops
 
 
-def calculate_blend_weights(t_values: torch.Tensor, opacity: torch.Tensor) -> torch.Tensor:
-    """Front-to-back alpha-compositing weights (kernel K5w; reference utils.py:72-97).
+class _BlendWeights(torch.autograd.Function):
+    """w = alpha * exclusive-cumprod(tau) (kernel K5w) with its closed-form backward (K5w-b)."""
 
-    Not differentiable on its own: gradients flow through ``Raycaster.render``'s fused
-    composite kernel instead."""
-    return ops.blend_weights(t_values.contiguous(), opacity.detach().contiguous())
+    @staticmethod
+    def forward(ctx, t_values, opacity):
+        t_values = t_values.contiguous()
+        opacity = opacity.contiguous()
+        ctx.save_for_backward(t_values, opacity)
+        return ops.blend_weights(t_values, opacity)
+
+    @staticmethod
+    def backward(ctx, d_weights):
+        t_values, opacity = ctx.saved_tensors
+        d_sigma, d_t = ops.blend_weights_bwd(t_values, opacity, d_weights.contiguous(),
+                                             want_dt=ctx.needs_input_grad[0])
+        return d_t, d_sigma
+
+
+def calculate_blend_weights(t_values: torch.Tensor, opacity: torch.Tensor) -> torch.Tensor:
+    """Front-to-back alpha-compositing weights, differentiable w.r.t. the opacities (and the
+    t-values) like the reference's (utils.py:72-97)."""
+    return _BlendWeights.apply(t_values, opacity)
 
 
 def linspace(start: torch.Tensor, stop: torch.Tensor, num_samples: int) -> torch.Tensor:

@@ -120,6 +120,12 @@ int ffn_composite_fwd(const float* logits, const float* t, int num_rays, int num
 int ffn_blend_weights(const float* t, const float* sigma, int num_rays, int num_samples,
                       float* weights, void* stream);
 
+/* K5w backward: the autograd of utils.py:72-97 in closed form.  d_weights (R,S) ->
+ * d_sigma (R,S) and, when d_t is not NULL, d_t (R,S).  S <= 256. */
+int ffn_blend_weights_bwd(const float* t, const float* sigma, const float* d_weights,
+                          int num_rays, int num_samples, float* d_sigma, float* d_t,
+                          void* stream);
+
 /* K5b backward of K5: d(loss)/d(logits) from d/d(color) (R,3) and d/d(alpha) (R). */
 int ffn_composite_bwd(const float* logits, const float* t, const float* d_color,
                       const float* d_alpha, int num_rays, int num_samples,

@@ -79,6 +79,35 @@ def build_parser(title, *tables, positional_extra=()):
     return parser
 
 
+def setup_device(requested: str, want_group: bool):
+    """Resolves --device for this process and makes it torch's current device (the C ABI
+    launches on the current device).  Under ``torch.distributed.run`` (WORLD_SIZE > 1) a plain
+    "cuda" becomes cuda:LOCAL_RANK and, if ``want_group``, the RCCL process group is created
+    (training: gradients are all-reduced; rendering is replicas-only and needs none).
+    Returns (device string, rank, world, group or None)."""
+    import torch
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    device = requested
+    if world > 1 and device == "cuda":
+        device = "cuda:%d" % int(os.environ.get("LOCAL_RANK", "0"))
+    dev = torch.device(device)
+    if dev.type == "cuda":
+        torch.cuda.set_device(dev if dev.index is not None else torch.device("cuda", 0))
+    group = None
+    if want_group and world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        backend = os.environ.get("FFN_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", torch.cuda.current_device()))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        group = dist.group.WORLD
+    return device, rank, world, group
+
+
 def axis_vector(code):
     vec = np.zeros(3, np.float32)
     vec["xyz".index(code[0])] = 1 if code[1] == "+" else -1

@@ -15,10 +15,7 @@ from scripts import _cli  # noqa: E402
 
 def main():
     args = _cli.build_parser("Orbit video (MI355X)", _cli.ORBIT).parse_args()
-    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    device = args.device
-    if world > 1 and device == "cuda":
-        device = "cuda:%d" % int(os.environ.get("LOCAL_RANK", "0"))
+    device, rank, world, _ = _cli.setup_device(args.device, False)
     cameras = ffn.orbit(_cli.axis_vector(args.up_dir), _cli.axis_vector(args.forward_dir),
                         args.num_frames, args.fov_y_degrees,
                         ffn.Resolution(args.resolution, args.resolution), args.distance)

@@ -15,6 +15,7 @@ def main():
     kinds = ("nerf_model", dict(choices=["mlp", "basic", "positional", "gaussian"]))
     args = _cli.build_parser("Tiny NeRF training (MI355X)", _cli.TRAIN_COMMON, _cli.TINY_ONLY,
                              positional_extra=[kinds]).parse_args()
+    args.device, rank, world, group = _cli.setup_device(args.device, True)
     torch.manual_seed(args.seed)
     width = dict(num_channels=args.num_channels)
     makers = {
@@ -45,7 +46,12 @@ def main():
         train.mode = ffn.RayDataset.Mode.Dilate
     os.makedirs(args.results_dir, exist_ok=True)
     caster = ffn.Raycaster(model.to(args.device))
-    if args.make_video:      # same choice of visualizers as the reference driver
+    caster.process_group = group      # data parallel under torch.distributed.run
+    if world > 1:                     # distinct jitter streams; weights are broadcast by fit
+        torch.cuda.manual_seed(args.seed + rank)
+    if rank != 0:
+        hooks = []
+    elif args.make_video:      # same choice of visualizers as the reference driver
         hooks = [ffn.OrbitVideoVisualizer(args.results_dir, args.num_steps,
                                           train.cameras[0].resolution, args.num_frames,
                                           args.num_samples, args.color_space, device=args.device)]
@@ -55,8 +61,11 @@ def main():
     log = caster.fit(train, val, args.batch_size, args.learning_rate, args.num_steps,
                      args.crop_steps, args.report_interval, args.decay_rate, args.decay_steps,
                      args.weight_decay, hooks)
-    model.save(os.path.join(args.results_dir, "tiny_nerf.pt"))
-    _cli.write_log(os.path.join(args.results_dir, "log.txt"), args, log)
+    if rank == 0:
+        model.save(os.path.join(args.results_dir, "tiny_nerf.pt"))
+        _cli.write_log(os.path.join(args.results_dir, "log.txt"), args, log)
+    if group is not None:
+        torch.distributed.destroy_process_group()
     return 0
 
 

@@ -208,10 +208,18 @@ def _dp_worker(rank, world, port, out):
     loss = ((gt_c[mine] - color).square().sum() / (3 * R)
             + 0.1 * (gt_a[mine] - alpha).square().sum() / R)
     loss.backward()
+    # the product's collective: ONE buffer [flat gradients | 2 loss sums] through
+    # TrainEngine._all_reduce (gloo groups are reduced through the host)
     flat = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
-    dist.all_reduce(flat)
-    total = torch.tensor([float(loss)])
-    dist.all_reduce(total)
+    err_c = float((gt_c[mine] - color).square().sum())
+    err_a = float((gt_a[mine] - alpha).square().sum())
+    engine.reduce_buf = torch.cat([flat, torch.tensor([err_c, err_a])])
+    engine._host_staged = True
+    engine.collective_events = None
+    engine._all_reduce()
+    flat = engine.reduce_buf[:-2]
+    sums = engine.reduce_buf[-2:]
+    total = sums[0] / (3 * R) + 0.1 * sums[1] / R
     grads = []
     offset = 0
     for p in model.parameters():
@@ -261,6 +269,25 @@ def test_driver_scripts_keep_the_reference_flags_and_defaults():
     }
     for name in ref:
         assert mine[name] == ref[name], name
+
+
+def test_ellipse_element_matches_opencv_known_answers():
+    """The Dilate-mode structuring element (image_dataset.py:92-94 calls
+    cv2.getStructuringElement(MORPH_ELLIPSE, ...); OpenCV is not in this image).  Known answers:
+    the 3x3, 5x5 and 7x7 ellipses printed in OpenCV's morphology documentation."""
+    from fourier_feature_nets_amd.dataset import _ellipse
+    assert _ellipse(1).tolist() == [[1]]
+    assert _ellipse(3).tolist() == [[0, 1, 0], [1, 1, 1], [0, 1, 0]]
+    assert _ellipse(5).tolist() == [[0, 0, 1, 0, 0], [1, 1, 1, 1, 1], [1, 1, 1, 1, 1],
+                                    [1, 1, 1, 1, 1], [0, 0, 1, 0, 0]]
+    assert _ellipse(7).tolist() == [[0, 0, 0, 1, 0, 0, 0], [0, 1, 1, 1, 1, 1, 0],
+                                    [1, 1, 1, 1, 1, 1, 1], [1, 1, 1, 1, 1, 1, 1],
+                                    [1, 1, 1, 1, 1, 1, 1], [0, 1, 1, 1, 1, 1, 0],
+                                    [0, 0, 0, 1, 0, 0, 0]]
+    for size in (9, 17, 65):         # mirror-symmetric (not transpose-symmetric, like OpenCV's)
+        e = _ellipse(size)
+        assert (e == e[::-1]).all() and (e == e[:, ::-1]).all()
+        assert e[size // 2].all() and e[:, size // 2].all()
 
 
 def test_wgrad_split_is_balanced_and_plan_buckets_are_tight():

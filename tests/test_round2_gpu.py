@@ -1,0 +1,390 @@
+"""Round-2 parity tests on the MI355X: the public blend-weights function (forward + autograd),
+Dilate mode, 800x800 ray generation, the full NeRF at the north-star launch size, a NeRF +
+focus-sampling + S=128 optimisation step against the oracle, and the data-parallel step run by
+two ranks through the product's TrainEngine."""
+
+import contextlib
+import io
+import math
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ffn_oracle as orc
+from tests.helpers import look_at_camera
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+SCENE = os.path.join(GOLDEN, "scene16.npz")
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def _quiet(fn, *args, **kwargs):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*args, **kwargs)
+
+
+# ----------------------------------------------------------------------------------- a11 / K5w
+def test_public_blend_weights_against_golden(golden):
+    """ffn.calculate_blend_weights == the reference's weights on the composite fixture
+    (utils.py:72-97; sigma = softplus of the golden logits, computed like the reference)."""
+    import fourier_feature_nets_amd as ffn
+    g = golden("composite")
+    t = _t(g["t"])
+    sigma = torch.nn.functional.softplus(_t(g["logits"])[..., 3])
+    w = ffn.calculate_blend_weights(t.to(dev()), sigma.to(dev()))
+    np.testing.assert_allclose(w.cpu().numpy(), g["weights"], rtol=1e-5, atol=1e-7)
+    assert np.allclose(orc.blend_weights(t, sigma).numpy(), g["weights"], rtol=1e-6, atol=1e-8)
+
+
+@pytest.mark.parametrize("S", [2, 16, 37, 64, 65, 130, 256])
+def test_public_blend_weights_is_differentiable(S):
+    """Gradients w.r.t. the opacities AND the t-values equal torch autograd of the reference's op
+    sequence (exp, minimum, cumprod), including saturated (alpha == 1) and empty (sigma == 0,
+    the minimum's 1/2-1/2 tie) samples."""
+    import fourier_feature_nets_amd as ffn
+    torch.manual_seed(S)
+    R = 67
+    t = torch.sort(torch.rand(R, S) * 4 + 2, -1)[0]
+    sigma = torch.nn.functional.softplus(torch.randn(R, S) * 3)
+    sigma[:5] = 0.0
+    sigma[5:9] = 200.0
+    probe = torch.randn(R, S)
+    t_ref, s_ref = t.clone().requires_grad_(True), sigma.clone().requires_grad_(True)
+    (orc.blend_weights(t_ref, s_ref) * probe).sum().backward()
+    t_gpu = t.to(dev()).requires_grad_(True)
+    s_gpu = sigma.to(dev()).requires_grad_(True)
+    w = ffn.calculate_blend_weights(t_gpu, s_gpu)
+    (w * probe.to(dev())).sum().backward()
+    # (the last column has delta = 1e10: its opacity gradient is 0 or ~1e10 -- own scale)
+    for got, ref in ((s_gpu.grad.cpu()[:, :-1], s_ref.grad[:, :-1]),
+                     (s_gpu.grad.cpu()[:, -1:], s_ref.grad[:, -1:]),
+                     (t_gpu.grad.cpu(), t_ref.grad)):
+        if ref.numel() == 0:
+            continue
+        scale = max(float(ref.abs().max()), 1e-12)
+        np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=2e-4, atol=2e-6 * scale)
+    # opacity-only gradient (t without requires_grad) takes the d_t == NULL path
+    s2 = sigma.to(dev()).requires_grad_(True)
+    (ffn.calculate_blend_weights(t.to(dev()), s2) * probe.to(dev())).sum().backward()
+    assert torch.equal(s2.grad, s_gpu.grad)
+
+
+# ----------------------------------------------------------------------------------- a15 Dilate
+def _numpy_dilate_index(images, element):
+    """image_dataset.py:92-135 restated with scipy: per camera, pixel ids of the alpha mask
+    dilated by `element`, offset by camera * W * H."""
+    from scipy.ndimage import binary_dilation
+    per_cam = images.shape[1] * images.shape[2]
+    ids, ranges, total = [], [], 0
+    for cam, image in enumerate(images):
+        grown = binary_dilation(image[..., 3] > 0, structure=element > 0)
+        found = np.nonzero(grown.reshape(-1))[0] + cam * per_cam
+        ranges.append((total, total + len(found)))
+        total += len(found)
+        ids.append(found)
+    return np.concatenate(ids), ranges
+
+
+def _blob_images(num, size, seed):
+    """RGBA uint8 images with an off-centre blob (touching one border) as the alpha mask."""
+    rng = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:size, 0:size]
+    images = np.zeros((num, size, size, 4), np.uint8)
+    for i in range(num):
+        cx, cy, r = rng.randint(0, size), rng.randint(size // 4, size), size * (0.1 + 0.1 * rng.rand())
+        mask = (xx - cx) ** 2 + (yy - cy) ** 2 <= r * r
+        images[i, ..., :3] = rng.randint(0, 255, (size, size, 3))
+        images[i, ..., 3] = mask * 255
+    return images
+
+
+@pytest.mark.parametrize("size", [16, 50, 100])
+def test_dilate_mode_index_set(size):
+    """Mode.Dilate (image_dataset.py:92-135, :264-331): the index set contains the alpha mask,
+    stays inside the image, equals a scipy restatement with the same structuring element, keeps
+    per-camera ranges, and drops the alpha term from the ground truth (:255-256)."""
+    import fourier_feature_nets_amd as ffn
+    from fourier_feature_nets_amd.dataset import _ellipse
+    num = 3
+    images = _blob_images(num, size, size)
+    cams = []
+    for i in range(num):
+        k, e = look_at_camera([4 * math.cos(i), 1.0, 4 * math.sin(i)], size, size)
+        cams.append(ffn.CameraInfo.create("c%d" % i, ffn.Resolution(size, size), k, e))
+    bounds = np.eye(4, dtype=np.float32) * 2
+    ds = _quiet(ffn.ImageDataset, "train", images, bounds, cams, 8, True, False, device=dev())
+    ds.mode = ffn.RayDataset.Mode.Dilate
+    radius = 8 * size // 100
+    exp_index, exp_ranges = _numpy_dilate_index(images, _ellipse(2 * radius + 1))
+    got = ds.dilate_index.cpu().numpy()
+    assert np.array_equal(got, exp_index)
+    assert [tuple(r) for r in ds.dilate_ranges] == exp_ranges
+    assert len(ds) == len(exp_index)
+    per_cam = size * size
+    mask_ids = np.nonzero((images[..., 3] > 0).reshape(-1))[0]
+    assert np.isin(mask_ids, got).all()                       # superset of the alpha mask
+    assert got.min() >= 0 and got.max() < num * per_cam        # subset of the image
+    assert np.all(np.diff(got) > 0)
+    for cam, (lo, hi) in enumerate(exp_ranges):                # ranges are per camera
+        assert np.all(got[lo:hi] // per_cam == cam)
+    # get_rays in this mode: dataset-local index -> dilate_index -> valid filter
+    local = torch.arange(0, len(ds), 3, device=dev())
+    rays = ds.ray_ids(local).cpu().numpy()
+    cand = exp_index[::3]
+    valid = ds.sampler.valid.cpu().numpy()
+    assert np.array_equal(rays, cand[valid[cand] != 0])
+    assert ds.index_for_camera(1) == [int(v) for v in
+                                      (exp_index[exp_ranges[1][0]:exp_ranges[1][1]] - per_cam)
+                                      if valid[v + per_cam]]
+    # ground truth: colours as they are (not zeroed by alpha), no alpha (image_dataset.py:255-256)
+    samples = ds.get_rays(local, None)
+    truth = ds.render(samples)
+    assert truth.alpha is None
+    colors = (images[..., :3].astype(np.float32) / 255).reshape(-1, 3)
+    assert np.array_equal(truth.color.cpu().numpy(), colors[rays])
+    ds.mode = ffn.RayDataset.Mode.Full
+    assert ds.render(samples).alpha is not None
+
+
+def test_dilate_mode_needs_alpha():
+    import fourier_feature_nets_amd as ffn
+    images = _blob_images(1, 16, 0)[..., :3].copy()
+    k, e = look_at_camera([4, 1, 0], 16, 16)
+    cams = [ffn.CameraInfo.create("c", ffn.Resolution(16, 16), k, e)]
+    ds = _quiet(ffn.ImageDataset, "train", images, np.eye(4, dtype=np.float32) * 2, cams, 8,
+                device=dev())
+    with pytest.raises(ValueError):
+        ds.mode = ffn.RayDataset.Mode.Dilate
+
+
+def test_train_nerf_script_in_dilate_mode(tmp_path):
+    """scripts/train_nerf.py --mode dilate end to end (2 steps): the mode is reachable from the
+    driver exactly as in the reference (train_nerf.py:132-133)."""
+    out = str(tmp_path / "run")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "train_nerf.py"), SCENE, out,
+                          "--mode", "dilate", "--num-steps", "2", "--report-interval", "2",
+                          "--image-interval", "2", "--batch-size", "64", "--num-samples", "16",
+                          "--num-layers", "3", "--num-channels", "64", "--crop-steps", "0"],
+                         capture_output=True, text=True, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert sorted(os.listdir(out)) == ["log.txt", "nerf.pt", "train", "val"]
+    with open(os.path.join(out, "log.txt")) as f:
+        lines = f.read().strip().split("\n")
+    rows = [ln.split("\t") for ln in lines[3:]]
+    assert [r[0] for r in rows] == ["0", "2"] and all(math.isfinite(float(r[2])) for r in rows)
+
+
+# ----------------------------------------------------------------------------------- a1/a2 800x800
+@pytest.mark.parametrize("size,cams", [(800, 4)])
+def test_raygen_800_properties(size, cams):
+    """BASELINE configs 4/5 use 800x800 frames: ray id layout, unit directions, origins, and the
+    slab test against a float64 recomputation from the kernel's own directions (only rays that
+    graze a face within rounding may flip)."""
+    from fourier_feature_nets_amd import ops
+    intr, ext = [], []
+    for c in range(cams):
+        ang = 2 * np.pi * c / cams + 0.3
+        k, e = look_at_camera([4 * np.cos(ang), 0.5 + 0.4 * c, 4 * np.sin(ang)], size, size)
+        intr.append(k)
+        ext.append(e)
+    bounds = np.diag([2, 2, 2, 1]).astype(np.float32)
+    unproj = np.stack([orc.unprojection(k, e) for k, e in zip(intr, ext)]).astype(np.float32)
+    pos = np.stack([e[:3, 3] for e in ext]).astype(np.float32)
+    lo, hi = orc.aabb_from_bounds(bounds)
+    starts, dirs, nf, valid = ops.raygen_nearfar(_t(unproj).to(dev()), _t(pos).to(dev()), size, size,
+                                                 lo[0], hi[0])
+    total = cams * size * size
+    assert starts.shape == (total, 3) and nf.shape == (2, total) and valid.shape == (total,)
+    d64 = dirs.double()
+    assert float((d64.norm(dim=1) - 1).abs().max()) < 3e-7
+    assert torch.equal(starts.reshape(cams, -1, 3)[:, 0], starts.reshape(cams, -1, 3)[:, -1])
+    np.testing.assert_array_equal(starts.reshape(cams, -1, 3)[:, 0].cpu().numpy(), pos)
+    # ray id = cam*W*H + y*W + x: pixel (x, y) of camera c against the oracle on a sample of pixels
+    rng = np.random.RandomState(1)
+    for c in range(cams):
+        pix = rng.randint(0, size * size, 512)
+        pts = np.stack([pix % size, pix // size], -1)
+        _, d_ref = orc.raycast(intr[c], ext[c], pts)
+        got = dirs[c * size * size + _t(pix).to(dev())].cpu().numpy()
+        np.testing.assert_allclose(got, d_ref, rtol=0, atol=3e-7)
+    # slab test in float64 from the kernel's own starts / directions
+    s64 = starts.double()
+    with np.errstate(all="ignore"):
+        t0 = (torch.tensor(lo[0], dtype=torch.float64, device=dev()) - s64) / d64
+        t1 = (torch.tensor(hi[0], dtype=torch.float64, device=dev()) - s64) / d64
+    near = torch.minimum(t0, t1).max(dim=1)[0]
+    far = torch.maximum(t0, t1).min(dim=1)[0]
+    ok = near < far
+    flips = int((ok != (valid != 0)).sum())
+    assert flips <= 8, flips
+    both = ok & (valid != 0)
+    np.testing.assert_allclose(nf[0][both].cpu().numpy(), near.clamp(min=0.1)[both].cpu().numpy(),
+                               rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(nf[1][both].cpu().numpy(), far[both].cpu().numpy(), rtol=2e-6, atol=2e-6)
+    frac = float((valid != 0).float().mean())
+    assert 0.3 < frac < 0.95
+
+
+# ----------------------------------------------------------------------------------- a9 full size
+def test_full_nerf_north_star_size_properties(golden):
+    """Full NeRF (8x256, skip, view branch) at ONE launch of 65 536 rays x 128 samples -- the
+    shape BASELINE.json states its target on; the oracle is out of reach there, so
+    size-independent properties: a sample's logits do not depend on the batch around it
+    (bit-exact), and the gradient is additive over a non-aligned split of the batch."""
+    from tests.test_kernels_gpu import _load_nerf
+    g = golden("models")
+    model, _ = _load_nerf(g, "nerf", [4], True)
+    n = 65536 * 128
+    gen = torch.Generator(device=dev()).manual_seed(21)
+    x = torch.rand((n, 3), generator=gen, device=dev()) * 2 - 1
+    v = torch.nn.functional.normalize(torch.randn((n, 3), generator=gen, device=dev()), dim=1)
+    probe = torch.randn((n, 4), generator=gen, device=dev()) / n
+    pick = torch.randint(0, n, (4096,), generator=gen, device=dev())
+    pick = torch.cat([pick, torch.tensor([0, n - 1], device=dev())])
+    with torch.no_grad():
+        y = model(x, v)
+        assert torch.equal(y[pick], model(x[pick].contiguous(), v[pick].contiguous()))
+        assert bool(torch.isfinite(y).all())
+    del y
+
+    def grads_of(lo, hi):
+        model.zero_grad()
+        (model(x[lo:hi], v[lo:hi]) * probe[lo:hi]).sum().backward()
+        out = [p.grad.clone() for p in model.parameters() if p.grad is not None]
+        model.program()._workspaces.clear()      # dZ slabs (~82 GB at this size) are per batch size
+        torch.cuda.empty_cache()
+        return out
+
+    whole = grads_of(0, n)
+    cut = n // 2 + 32 * 11 + 7
+    parts = [a + b for a, b in zip(grads_of(0, cut), grads_of(cut, n))]
+    for a, b in zip(whole, parts):
+        scale = float(a.abs().max())
+        assert float((a - b).abs().max()) <= 3e-5 * max(scale, 1e-6)
+    model.zero_grad()
+    torch.cuda.empty_cache()
+
+
+# ----------------------------------------------------------------------------------- config 3
+def test_nerf_focus_sampling_step_matches_oracle(golden):
+    """BASELINE config 3 in miniature: full NeRF(8,256, skip, view branch), S = 128 = 64 uniform +
+    64 opacity-guided samples with a coarse model, one TrainEngine step == the oracle's step on the
+    same rays, noise and weights (ray_sampler.py:359-403, ray_caster.py:319-329)."""
+    import fourier_feature_nets_amd as ffn
+    from tests.test_kernels_gpu import _load_nerf
+    from tests.test_pipeline_gpu import _oracle_model, _small_model
+    g, gt = golden("models"), golden("training")
+    model, params = _load_nerf(g, "nerf", [4], True)
+    ref = orc.OracleNeRF(params, [4], True)
+    coarse, coarse_ref = _small_model(gt), _oracle_model(gt)
+    S = 128
+    train = _quiet(ffn.ImageDataset.load, SCENE, "train", S, True, True, coarse, 64, device=dev())
+    train.sampler.noise_source = "host"
+    engine = ffn.TrainEngine(model)
+    batch = torch.arange(0, len(train), 7, device=dev())
+    torch.manual_seed(9)
+    loss = float(engine.train_step(train, batch, None, 5e-4))
+    engine.check_finite()
+    # oracle: CDFs of the coarse model from the sampler's own ray state, then the same draw order
+    rays = train.ray_ids(batch).cpu()
+    smp = train.sampler
+    n_focus = S - S // 2
+    state = {"starts": smp.starts.cpu(), "directions": smp.directions.cpu(), "near_far": smp.near_far.cpu()}
+    near, far = state["near_far"][:, rays]
+    t_probe = orc.linspace_rows(near, far, n_focus)
+    pos = state["starts"][rays].unsqueeze(1) + t_probe.unsqueeze(2) * state["directions"][rays].unsqueeze(1)
+    with torch.no_grad():
+        sigma = torch.nn.functional.softplus(coarse_ref(pos.reshape(-1, 3))[:, -1]).reshape(-1, n_focus)
+    cdf_rows = orc.determine_cdf(t_probe, sigma)
+    np.testing.assert_allclose(smp.cdfs[rays.to(dev())].cpu().numpy(), cdf_rows.numpy(), atol=2e-4)
+    cdfs = smp.cdfs.cpu()                      # the oracle consumes the device table: identical bins
+    torch.manual_seed(9)
+    noise = torch.rand((len(rays), S // 2))
+    focus_u = torch.rand((len(rays), n_focus))
+    pos, view, t, _ = orc.sample(state, rays.numpy(), None, S, noise=noise, cdfs=cdfs, focus_u=focus_u)
+    gc, ga = orc.ground_truth(train.colors.cpu(), train.alphas.cpu(), rays)
+    trainer = orc.OracleTrainer(ref, 5e-4)
+    ref_loss = trainer.step(pos, view, t, gc, ga, 5e-4)
+    assert abs(loss - ref_loss) < 5e-6 * max(1.0, abs(ref_loss)), (loss, ref_loss)
+    for key, par in model.named_parameters():
+        if par.requires_grad:
+            np.testing.assert_allclose(par.detach().cpu().numpy(), ref.p[key].detach().numpy(),
+                                       rtol=0, atol=5e-5, err_msg=key)
+
+
+# ----------------------------------------------------------------------------------- (e) multi-GPU
+def _free_port():
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+@pytest.mark.parametrize("max_samples", [None, 16 * 40])
+def test_two_rank_train_step_equals_one_rank(tmp_path, max_samples):
+    """Two processes (sharing cuda:0, gloo group) run the PRODUCT's TrainEngine.train_step --
+    contiguous ragged shards, gradients scaled by the global ray count, one collective carrying
+    [gradients | loss sums], clip + Adam after it -- for 3 steps; losses and the flat weights
+    equal the single-process run (summation order of the two partial gradients aside).
+    `max_samples` small = several forward/backward launches per rank and step."""
+    import torch.multiprocessing as mp
+    from tests import dp_worker
+    out = str(tmp_path / "dp.pt")
+    steps = 3
+    mp.spawn(dp_worker.dp_train_worker, args=(2, _free_port(), out, steps, max_samples), nprocs=2,
+             join=True)
+    blob = torch.load(out)
+    losses, flat = dp_worker.run_steps(None, steps, max_samples)
+    np.testing.assert_allclose(blob["losses"], losses, rtol=2e-6)
+    np.testing.assert_allclose(blob["flat"].numpy(), flat.numpy(), rtol=0, atol=2e-6)
+    start = torch.cat([p.detach().reshape(-1).cpu() for p in dp_worker.small_model(dev())._dense_params()])
+    assert float((blob["flat"] - start).abs().max()) > 1e-4          # the weights did move
+
+
+def test_orbit_video_two_ranks_write_the_same_frames(tmp_path):
+    """Rendering is replicas only (frame f -> rank f mod world): two ranks (sharing cuda:0)
+    together write exactly the frames one rank writes."""
+    import fourier_feature_nets_amd as ffn
+    from tests import dp_worker
+    ckpt = str(tmp_path / "m.pt")
+    dp_worker.small_model(dev()).save(ckpt)
+    script = os.path.join(ROOT, "scripts", "orbit_video.py")
+    base = [sys.executable, script, ckpt, "20", None, "--num-frames", "5", "--num-samples", "16"]
+
+    def run(out_dir, rank, world):
+        env = dict(os.environ)
+        env.pop("RANK", None)
+        if world > 1:
+            env.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+        cmd = list(base)
+        cmd[4] = out_dir
+        return subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                text=True)
+
+    one, two = str(tmp_path / "one"), str(tmp_path / "two")
+    procs = [run(one, 0, 1), run(two, 0, 2), run(two, 1, 2)]
+    for p in procs:
+        _, err = p.communicate(timeout=600)
+        assert p.returncode == 0, err[-2000:]
+    names = ["frame_%05d.png" % i for i in range(5)]
+    assert sorted(os.listdir(one)) == names and sorted(os.listdir(two)) == names
+    from PIL import Image
+    for name in names:
+        a = np.asarray(Image.open(os.path.join(one, name)))
+        b = np.asarray(Image.open(os.path.join(two, name)))
+        assert np.array_equal(a, b), name
+    assert ffn.load_model(ckpt) is not None
