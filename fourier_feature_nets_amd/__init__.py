@@ -8,6 +8,7 @@ for that path.  There is no CPU fallback: using a model or sampler without a GPU
 from .cameras import CameraInfo, Resolution, orbit
 from .caster import LogEntry, Raycaster, TrainEngine
 from .dataset import ImageDataset, RayDataset
+from .frames import FrameSink
 from .occupancy import OccupancyGrid
 from .models import (
     BasicFourierMLP,
@@ -31,7 +32,7 @@ from .voxels import Voxels
 
 __version__ = "0.1.0"
 
-__all__ = ["__version__", "ActivationVisualizer", "BasicFourierMLP", "CameraInfo", "ETABar", "EvaluationVisualizer", "FourierFeatureMLP",
+__all__ = ["__version__", "ActivationVisualizer", "BasicFourierMLP", "CameraInfo", "ETABar", "EvaluationVisualizer", "FourierFeatureMLP", "FrameSink",
            "GaussianFourierMLP", "ImageDataset", "LogEntry", "MLP", "NeRF",
            "OccupancyGrid", "OrbitVideoVisualizer", "PositionalFourierMLP", "RayDataset", "RaySampler", "RaySamples", "Raycaster",
            "RenderResult", "Resolution", "TrainEngine", "Visualizer", "Voxels", "calculate_blend_weights",

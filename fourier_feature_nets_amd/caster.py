@@ -221,6 +221,7 @@ class Raycaster(nn.Module):
         self.shuffle_source = "numpy"     # epoch permutations from np.random like the reference
         self.process_group = None         # set to a torch.distributed group for data parallel
         self.occupancy = None             # an OccupancyGrid switches on empty-space skipping (no_grad renders)
+        self.fused_render = True          # render_image / render_rays through the one-launch kernel
 
     # ------------------------------------------------------------------ rendering
     def _flag(self, device):
@@ -283,20 +284,65 @@ class Raycaster(nn.Module):
         self.check_finite()
         return out
 
-    def render_image(self, sampler: RaySampler, index: int, batch_size: int,
-                     color_space="RGB") -> np.ndarray:
-        """(H,W,3) uint8 frame of camera ``index % num_cameras`` (ray_caster.py:140-159)."""
+    def _can_fuse(self, sampler: RaySampler) -> bool:
+        model = self.model
+        return (self.fused_render and hasattr(model, "program") and sampler.num_samples <= 256
+                and not model.program().wide)
+
+    def render_rays(self, sampler: RaySampler, rays, include_depth=False,
+                    image: Optional[torch.Tensor] = None, pixel_offset: int = 0,
+                    want_color=True) -> RenderResult:
+        """Inference render of the sampler's rays ``rays`` (device int64 ids, or a
+        ``(first id, count)`` range that the kernel filters by the validity mask) in one launch
+        of the fused kernel: sampling, encoding, MLP and compositing without materialising
+        samples or logits (what ``sampler.sample`` + ``render`` do in four passes over HBM,
+        ray_caster.py:103-138).  Stratified / opacity-guided samplers contribute their
+        t-values; a plain uniform sampler needs none."""
+        needs_t = sampler.stratified or sampler.focus_sampling
+        if isinstance(rays, tuple):
+            spec = (int(rays[0]), int(rays[1]), sampler.valid)
+            index = torch.arange(spec[0], spec[0] + spec[1], dtype=torch.int64,
+                                 device=sampler.device) if needs_t else None
+        else:
+            spec = index = rays.contiguous()
+        t_values = sampler.sample_t(index, None) if needs_t else None
+        color, alpha, depth = self.model.program().render(
+            sampler.starts, sampler.directions, sampler.near_far, spec,
+            sampler.num_samples, sampler._unit(sampler.num_samples), t_values,
+            occupancy=self.occupancy, want_color=want_color, want_depth=include_depth,
+            nan_flag=self._flag(sampler.device), image=image, pixel_offset=pixel_offset)
+        return RenderResult(color, alpha, depth)
+
+    def render_image_device(self, sampler: RaySampler, index: int, batch_size: int) -> torch.Tensor:
+        """(H,W,3) uint8 frame of camera ``index % num_cameras`` as a DEVICE tensor, enqueued
+        without any host synchronisation (callers overlap the copy-out / encoding, see
+        ``frames.FrameSink``)."""
         camera = index % sampler.num_cameras
         self.model.eval()
         with torch.no_grad():
-            rays = sampler._valid_for_camera(camera)
-            colors = torch.empty((rays.numel(), 3), dtype=torch.float32, device=sampler.device)
-            for start in range(0, rays.numel(), batch_size):
-                chunk = sampler.sample(rays[start:start + batch_size].contiguous(), None)
-                colors[start:start + batch_size] = self.render(chunk, False).color
+            if self._can_fuse(sampler):
+                image = torch.zeros((sampler.image_height, sampler.image_width, 3),
+                                    dtype=torch.uint8, device=sampler.device)
+                first = camera * sampler.rays_per_camera
+                self.render_rays(sampler, (first, sampler.rays_per_camera), False, image=image,
+                                 pixel_offset=first, want_color=False)
+            else:
+                rays = sampler._valid_for_camera(camera)
+                colors = torch.empty((rays.numel(), 3), dtype=torch.float32, device=sampler.device)
+                for start in range(0, rays.numel(), batch_size):
+                    chunk = sampler.sample(rays[start:start + batch_size].contiguous(), None)
+                    colors[start:start + batch_size] = self.render(chunk, False).color
+                image = ops.to_image(colors, (rays - camera * sampler.rays_per_camera).contiguous(),
+                                     sampler.image_width, sampler.image_height)
         self.model.train()
-        image = ops.to_image(colors, (rays - camera * sampler.rays_per_camera).contiguous(),
-                             sampler.image_width, sampler.image_height)
+        return image
+
+    def render_image(self, sampler: RaySampler, index: int, batch_size: int,
+                     color_space="RGB") -> np.ndarray:
+        """(H,W,3) uint8 frame of camera ``index % num_cameras`` (ray_caster.py:140-159)."""
+        if color_space != "RGB":
+            raise NotImplementedError("only the RGB colour space is supported (YCrCb needs OpenCV)")
+        image = self.render_image_device(sampler, index, batch_size)
         self.check_finite()
         return image.cpu().numpy()
 

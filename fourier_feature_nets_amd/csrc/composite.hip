@@ -5,112 +5,9 @@
 // exclusive transmittance product is a 6-step cross-lane scan per row with a scalar
 // carry between rows.  HBM-bound: 20*S bytes read + 20 bytes written per ray forward.
 #include "common.h"
+#include "composite_terms.h"
 
 namespace ffn {
-
-__device__ __forceinline__ float softplus_torch(float x) {
-    // F.softplus, beta = 1, threshold = 20
-    return x > 20.0f ? x : log1pf(expf(x));
-}
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
-
-// Cross-lane scans on the DPP path (row_shr 1/2/4/8 inside each row of 16 lanes, then
-// row_bcast15 / row_bcast31 across rows): six VALU instructions with a DPP modifier instead of
-// six ds_bpermute round trips through the LDS pipeline (~100+ cycles each, serially dependent).
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_f(float old, float src) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old),
-                                                                  __builtin_bit_cast(int, src), CTRL,
-                                                                  ROW_MASK, 0xf, false));
-}
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ unsigned dpp_u(unsigned old, unsigned src) {
-    return (unsigned)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, ROW_MASK, 0xf, false);
-}
-constexpr int kRowShr1 = 0x111, kRowShr2 = 0x112, kRowShr4 = 0x114, kRowShr8 = 0x118;
-constexpr int kRowBcast15 = 0x142, kRowBcast31 = 0x143, kWaveShr1 = 0x138;
-
-// inclusive multiplicative scan over the 64 lanes of a wave
-__device__ __forceinline__ float wave_scan_mul(float v, int) {
-    v *= dpp_f<kRowShr1, 0xf>(1.0f, v);
-    v *= dpp_f<kRowShr2, 0xf>(1.0f, v);
-    v *= dpp_f<kRowShr4, 0xf>(1.0f, v);
-    v *= dpp_f<kRowShr8, 0xf>(1.0f, v);
-    v *= dpp_f<kRowBcast15, 0xa>(1.0f, v);
-    v *= dpp_f<kRowBcast31, 0xc>(1.0f, v);
-    return v;
-}
-// value of lane i-1 (lane 0 gets `first`)
-__device__ __forceinline__ float wave_shift_up(float v, float first) { return dpp_f<kWaveShr1, 0xf>(first, v); }
-__device__ __forceinline__ float wave_last(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
-}
-// inclusive additive suffix scan (lane i gets sum over lanes >= i)
-__device__ __forceinline__ float wave_suffix_add(float v, int lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const float dn = __shfl_down(v, off, 64);
-        if (lane + off < 64) v += dn;
-    }
-    return v;
-}
-__device__ __forceinline__ float wave_sum(float v) {
-    v += dpp_f<kRowShr1, 0xf>(0.0f, v);
-    v += dpp_f<kRowShr2, 0xf>(0.0f, v);
-    v += dpp_f<kRowShr4, 0xf>(0.0f, v);
-    v += dpp_f<kRowShr8, 0xf>(0.0f, v);
-    v += dpp_f<kRowBcast15, 0xa>(0.0f, v);
-    v += dpp_f<kRowBcast31, 0xc>(0.0f, v);
-    return wave_last(v);
-}
-// max over the wave of the 64-bit key (hi, lo), returned in every lane
-__device__ __forceinline__ void wave_max_key(unsigned& hi, unsigned& lo) {
-#define FFN_KEY_STEP(CTRL, MASK)                                                               \
-    {                                                                                          \
-        const unsigned oh = dpp_u<CTRL, MASK>(0u, hi), ol = dpp_u<CTRL, MASK>(0u, lo);         \
-        const bool take = oh > hi || (oh == hi && ol > lo);                                    \
-        hi = take ? oh : hi;                                                                   \
-        lo = take ? ol : lo;                                                                   \
-    }
-    FFN_KEY_STEP(kRowShr1, 0xf)
-    FFN_KEY_STEP(kRowShr2, 0xf)
-    FFN_KEY_STEP(kRowShr4, 0xf)
-    FFN_KEY_STEP(kRowShr8, 0xf)
-    FFN_KEY_STEP(kRowBcast15, 0xa)
-    FFN_KEY_STEP(kRowBcast31, 0xc)
-#undef FFN_KEY_STEP
-    hi = (unsigned)__builtin_amdgcn_readlane((int)hi, 63);
-    lo = (unsigned)__builtin_amdgcn_readlane((int)lo, 63);
-}
-
-struct SampleTerms {
-    float r, g, b;      // sigmoid(rgb logits)
-    float sigma_logit;  // raw
-    float delta, e, alpha, u, tau;
-};
-
-__device__ __forceinline__ SampleTerms load_terms(const float4* __restrict__ logits,
-                                                   const float* __restrict__ t, int s, int S,
-                                                   bool active, int32_t* nan_flag) {
-    SampleTerms o;
-    if (!active) {
-        o.r = o.g = o.b = 0.f; o.sigma_logit = 0.f; o.delta = 0.f; o.e = 1.f; o.alpha = 0.f;
-        o.u = 1.f; o.tau = 1.f;
-        return o;
-    }
-    const float4 l = logits[s];
-    o.r = sigmoid_f(l.x); o.g = sigmoid_f(l.y); o.b = sigmoid_f(l.z);
-    o.sigma_logit = l.w;
-    const float sigma = softplus_torch(l.w);
-    if (nan_flag != nullptr && (o.r != o.r || o.g != o.g || o.b != o.b || sigma != sigma))
-        atomicOr(nan_flag, 1);
-    o.delta = (s == S - 1) ? 1e10f : t[s + 1] - t[s];
-    o.e = expf(-(sigma * o.delta));
-    o.alpha = 1.0f - o.e;
-    o.u = (1.0f - o.alpha) + 1e-10f;
-    o.tau = o.u < 1.0f ? o.u : 1.0f;
-    return o;
-}
 
 // ---------------------------------------------------------------------------------- K5
 __global__ void __launch_bounds__(256)
@@ -124,41 +21,19 @@ composite_fwd_kernel(const float4* __restrict__ logits, const float* __restrict_
     for (int ray = wave; ray < R; ray += waves) {
         const float4* lg = logits + (int64_t)ray * S;
         const float* tr = t + (int64_t)ray * S;
-        float carry = 1.0f;       // product of tau over all previous rows
-        float cr = 0.f, cg = 0.f, cb = 0.f, asum = 0.f;
-        float best_w = -1.0f;     // weights are >= 0, so -1 means "none yet"
-        int best_s = 0;
+        RayAccum acc;
+        acc.reset();
         for (int row = 0; row < rows; ++row) {
             const int s = row * 64 + lane;
             const bool active = s < S;
             const SampleTerms q = load_terms(lg, tr, s, S, active, nan_flag);
-            const float incl = wave_scan_mul(q.tau, lane);
-            const float excl = wave_shift_up(incl, 1.0f);
-            const float T = carry * excl;
-            const float w = q.alpha * T;
-            cr += w * q.r; cg += w * q.g; cb += w * q.b;
-            const bool inner = active && s < S - 1;
-            if (inner) {
-                asum += w;
-                if (w > best_w) { best_w = w; best_s = s; }
-            }
-            carry *= wave_last(incl);
+            acc.row(q, lane, s, active && s < S - 1);
         }
-        cr = wave_sum(cr); cg = wave_sum(cg); cb = wave_sum(cb); asum = wave_sum(asum);
-        // argmax with first-occurrence tie break: weights are >= 0, so their bit patterns order
-        // like unsigned integers; the low word prefers the smaller sample index, 0 = "none"
-        unsigned key_hi = best_w < 0.0f ? 0u : __builtin_bit_cast(unsigned, best_w);
-        unsigned key_lo = best_w < 0.0f ? 0u : 0xffffffffu - (unsigned)best_s;
-        wave_max_key(key_hi, key_lo);
-        best_w = key_lo == 0u ? -1.0f : __builtin_bit_cast(float, key_hi);
-        best_s = key_lo == 0u ? 0 : (int)(0xffffffffu - key_lo);
+        acc.finish();
         if (lane == 0) {
-            color[ray * 3 + 0] = cr; color[ray * 3 + 1] = cg; color[ray * 3 + 2] = cb;
-            alpha_out[ray] = asum;
-            if (depth != nullptr) {
-                const int pick = (asum < 0.1f || best_w < 0.0f) ? S - 1 : best_s;
-                depth[ray] = tr[pick];
-            }
+            color[ray * 3 + 0] = acc.cr; color[ray * 3 + 1] = acc.cg; color[ray * 3 + 2] = acc.cb;
+            alpha_out[ray] = acc.asum;
+            if (depth != nullptr) depth[ray] = tr[acc.depth_pick(S)];
         }
     }
 }

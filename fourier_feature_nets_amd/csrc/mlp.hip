@@ -19,6 +19,8 @@
 // weight packs and 1-bit ReLU masks.  A "wide" variant (two waves per 32-sample block, 64 KiB
 // slab) covers 512-channel layers.
 #include "common.h"
+#include "composite_terms.h"
+#include "occupancy_map.h"
 
 namespace ffn {
 
@@ -588,6 +590,146 @@ mlp_forward_kernel(const ffn_mlp_chain ch, const float* __restrict__ packed_w,
     }
 }
 
+// ---------------------------------------------------------------------------------- fused render
+// Inference in ONE launch: t-sampling -> sample positions -> Fourier-feature MLP -> sigmoid /
+// softplus -> front-to-back compositing (K2 + K3 + K4 + K5; ray_caster.py:103-159 renders a
+// frame as sample / model / composite passes over HBM-resident (R,S,3) and (R,S,4) arrays).
+// A wavefront owns whole rays.  A ray's samples go through the chain interpreter in blocks of
+// 32 (the forward kernel's unit); the logits of two consecutive blocks land on the two lane
+// halves, which is exactly the "sample s on lane s & 63" row layout of the composite scan, so
+// the scan consumes them straight from registers.  HBM traffic per ray: 8 B ray id + 32 B ray
+// state in, 20 B (or 3 B of u8 pixel) out -- samples, features and logits never leave the CU.
+//
+// Optional empty-space skipping (occupancy grid, K9 semantics: a sample in an empty cell has
+// sigma = 0, so its weight is 0 and its transmittance factor min(1, 1 + 1e-10) = 1): the wave
+// first compacts the ray's occupied samples (ballot + popcount ranks, a 512-B slot list in
+// LDS), runs only ceil(m / 32) blocks, and composites over the kept samples with each one's
+// OWN delta = t[j+1] - t[j] -- the same colour / alpha as evaluating every sample.
+struct RenderParams {
+    const float* starts; const float* dirs; const float* near_far; int64_t total_rays;
+    const int64_t* ray_index; int64_t ray_base; const uint8_t* valid; int num_rays; int S;
+    const float* unit; const float* t_values;
+    const uint32_t* occ_bits; GridMap map;
+    float* color; float* alpha; float* depth; int32_t* nan_flag;
+    uint8_t* image; int64_t pixel_offset;
+};
+
+__global__ void __launch_bounds__(256, 1)
+render_fused_kernel(const ffn_mlp_chain ch, const float* __restrict__ packed_w,
+                    const float* __restrict__ bias, const RenderParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    stage_encoding_tables(ch.enc, reinterpret_cast<float*>(smem + kWavesPerBlock * kActBytesPerWave),
+                          threadIdx.x, 256);
+    {
+        float* bl = reinterpret_cast<float*>(smem + kWavesPerBlock * kActBytesPerWave + kEncTableBytes);
+        for (int i = threadIdx.x; i < ch.bias_floats; i += 256) bl[i] = bias[i];
+    }
+    __syncthreads();
+    WaveCtx w;
+    int64_t stride;
+    wave_setup<false>(w, smem, kSamplesPerWave, stride);
+    w.block = 0;                       // nothing is saved in inference: slab addressing is unused
+    w.masks = nullptr;
+    const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint16_t* slots = reinterpret_cast<uint16_t*>(smem + kWavesPerBlock * kActBytesPerWave + kEncTableBytes +
+                                                  kBiasLdsFloats * 4) + wave_in_block * 256;
+    const int S = p.S;
+    const int waves = gridDim.x * kWavesPerBlock;
+    for (int r = blockIdx.x * kWavesPerBlock + wave_in_block; r < p.num_rays; r += waves) {
+        const int64_t ray = p.ray_index != nullptr ? p.ray_index[r] : p.ray_base + r;
+        if (p.valid != nullptr && p.valid[ray] == 0) {      // misses the volume: black, no pixel
+            if (w.lane == 0) {
+                if (p.color != nullptr) {
+                    p.color[(int64_t)r * 3 + 0] = 0.f; p.color[(int64_t)r * 3 + 1] = 0.f;
+                    p.color[(int64_t)r * 3 + 2] = 0.f;
+                }
+                if (p.alpha != nullptr) p.alpha[r] = 0.f;
+                if (p.depth != nullptr) p.depth[r] = 0.f;
+            }
+            continue;
+        }
+        const float sx = p.starts[ray * 3 + 0], sy = p.starts[ray * 3 + 1], sz = p.starts[ray * 3 + 2];
+        const float dx = p.dirs[ray * 3 + 0], dy = p.dirs[ray * 3 + 1], dz = p.dirs[ray * 3 + 2];
+        const float near = p.near_far[ray], far = p.near_far[p.total_rays + ray];
+        const float span = __fsub_rn(far, near);
+        // t of sample j: given, or near + linspace(0,1,S)[j] * (far - near) with separately
+        // rounded multiply and add like the sampling kernel (bit-identical t and positions)
+        const float* trow = p.t_values != nullptr ? p.t_values + (int64_t)r * S : nullptr;
+        auto t_of = [&](int j) -> float {
+            return trow != nullptr ? trow[j] : __fadd_rn(near, __fmul_rn(p.unit[j], span));
+        };
+        int m = S;
+        if (p.occ_bits != nullptr) {
+            m = 0;
+            for (int base = 0; base < S; base += 64) {
+                const int j = base + w.lane;
+                const bool in_ray = j < S;
+                const float t = t_of(in_ray ? j : S - 1);
+                const float px = __fadd_rn(sx, __fmul_rn(t, dx)), py = __fadd_rn(sy, __fmul_rn(t, dy)),
+                            pz = __fadd_rn(sz, __fmul_rn(t, dz));
+                const bool keep = in_ray && occupied_at(p.map, p.occ_bits, px, py, pz);
+                const uint64_t mask = __ballot(keep);
+                const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                           __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                if (keep) slots[m + rank] = (uint16_t)j;
+                m += __popcll(mask);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+        RayAccum acc;
+        acc.reset();
+        const int nblk = (m + 31) >> 5;
+        for (int row = 0; 2 * row < nblk; ++row) {
+            float4 lg = make_float4(0.f, 0.f, 0.f, 0.f);
+            float tj = 0.0f;
+            int jj = 0;
+            bool act = false;
+            for (int hb = 0; hb < 2; ++hb) {
+                const int k = 2 * row + hb;
+                if (k >= nblk) break;
+                const int slot = 32 * k + w.s;
+                const bool valid = slot < m;
+                const int sl = valid ? slot : m - 1;          // tail lanes recompute the last sample
+                const int j = p.occ_bits != nullptr ? (int)slots[sl] : sl;
+                const float t = t_of(j);
+                w.x0 = __fadd_rn(sx, __fmul_rn(t, dx));
+                w.x1 = __fadd_rn(sy, __fmul_rn(t, dy));
+                w.x2 = __fadd_rn(sz, __fmul_rn(t, dz));
+                w.v0 = dx; w.v1 = dy; w.v2 = dz;
+                w.logit[0] = w.logit[1] = w.logit[2] = w.logit[3] = 0.0f;
+                run_chain<kInfer, false>(ch, w, packed_w, nullptr);
+                float out[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) out[c] = w.logit[c] + __shfl_xor(w.logit[c], 32);
+                if (w.h == hb) {
+                    lg = make_float4(out[0], out[1], out[2], out[3]);
+                    tj = t; jj = j; act = valid;
+                }
+            }
+            const bool last = jj == S - 1;
+            const float tnext = (act && !last) ? t_of(jj + 1) : 0.0f;
+            const SampleTerms q = make_terms(lg, tj, tnext, last, act, p.nan_flag);
+            acc.row(q, w.lane, jj, act && !last);
+        }
+        acc.finish();
+        if (w.lane == 0) {
+            if (p.color != nullptr) {
+                p.color[(int64_t)r * 3 + 0] = acc.cr; p.color[(int64_t)r * 3 + 1] = acc.cg;
+                p.color[(int64_t)r * 3 + 2] = acc.cb;
+            }
+            if (p.alpha != nullptr) p.alpha[r] = acc.asum;
+            if (p.depth != nullptr) p.depth[r] = t_of(acc.depth_pick(S));
+            if (p.image != nullptr) {      // (x * 255) truncated to u8 (ray_sampler.py:193-196)
+                uint8_t* px = p.image + (ray - p.pixel_offset) * 3;
+                px[0] = (uint8_t)(int)(acc.cr * 255.0f);
+                px[1] = (uint8_t)(int)(acc.cg * 255.0f);
+                px[2] = (uint8_t)(int)(acc.cb * 255.0f);
+            }
+        }
+    }
+}
+
 // Backward-data chain: consumes d_logits (N,4) and the saved forward activations, writes
 // dZ of every hidden layer (block layout) for the weight-gradient kernel.
 template <bool WIDE>
@@ -668,13 +810,14 @@ static const size_t kLdsBytes = (size_t)kWavesPerBlock * kActBytesPerWave + kEnc
 
 // one resident workgroup per CU (its ~150 KiB of LDS admit no second one)
 static int64_t persistent_grid(int64_t blocks32, int teams) {
-    static int cus = 0;
+    static int cu_count[64] = {0};          // per device ordinal (an immutable attribute cache)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    int cus = cu_count[dev];
     if (cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+        cu_count[dev] = cus;
     }
     const int64_t wgs = (blocks32 + teams - 1) / teams;
     return wgs < cus ? wgs : cus;
@@ -714,6 +857,43 @@ extern "C" int ffn_mlp_forward(const ffn_mlp_chain* chain, const float* packed_w
         else launch_forward<kInfer, false>(chain, packed_w, bias, positions, views, n, logits, saved, masks, stream);
     }
     return check_launch("ffn_mlp_forward");
+}
+
+extern "C" int ffn_render_fused_fwd(const ffn_mlp_chain* chain, const float* packed_w,
+                                    const float* bias, const ffn_render_rays* rays,
+                                    const ffn_occupancy* occupancy, const ffn_render_out* out,
+                                    void* stream) {
+    if (rays == nullptr || out == nullptr) return fail_arg("ffn_render_fused_fwd: null argument");
+    if (rays->num_rays == 0) return 0;
+    if (rays->num_rays < 0 || rays->num_samples < 1 || rays->num_samples > 256)
+        return fail_arg("ffn_render_fused_fwd: need 1 <= num_samples <= 256");
+    if (validate_chain(chain, false) || chain->wide)
+        return fail_arg("ffn_render_fused_fwd: bad chain (512-wide chains render through ffn_mlp_forward)");
+    if (rays->t_values == nullptr && rays->unit == nullptr)
+        return fail_arg("ffn_render_fused_fwd: unit or t_values is required");
+    RenderParams p;
+    p.starts = rays->starts; p.dirs = rays->directions; p.near_far = rays->near_far;
+    p.total_rays = rays->num_rays_total; p.ray_index = rays->ray_index;
+    p.ray_base = rays->ray_base; p.valid = rays->valid;
+    p.num_rays = rays->num_rays; p.S = rays->num_samples;
+    p.unit = rays->unit; p.t_values = rays->t_values;
+    p.occ_bits = nullptr;
+    const float zero3[3] = {0.f, 0.f, 0.f}, one3[3] = {1.f, 1.f, 1.f};
+    p.map = make_map(zero3, one3, 1);      // unused without a grid
+    if (occupancy != nullptr && occupancy->bits != nullptr) {
+        if (occupancy->resolution < 1 || occupancy->resolution > 1024)
+            return fail_arg("ffn_render_fused_fwd: occupancy resolution");
+        p.occ_bits = occupancy->bits;
+        p.map = make_map(occupancy->box_min, occupancy->box_size, occupancy->resolution);
+    }
+    p.color = out->color; p.alpha = out->alpha; p.depth = out->depth; p.nan_flag = out->nan_flag;
+    p.image = out->image; p.pixel_offset = out->pixel_offset;
+    const int64_t wgs = ((int64_t)rays->num_rays + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int64_t grid = persistent_grid(wgs * kWavesPerBlock, kWavesPerBlock);
+    allow_big_lds(&render_fused_kernel);
+    hipLaunchKernelGGL(render_fused_kernel, dim3((unsigned)grid), dim3(256), kLdsBytes,
+                       (hipStream_t)stream, *chain, packed_w, bias, p);
+    return check_launch("ffn_render_fused_fwd");
 }
 
 template <bool WIDE>

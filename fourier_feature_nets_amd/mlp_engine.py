@@ -77,6 +77,26 @@ class FfnReduceJob(ctypes.Structure):
                 ("col_map", ctypes.c_void_p)]
 
 
+class FfnRenderRays(ctypes.Structure):
+    _fields_ = [("starts", ctypes.c_void_p), ("directions", ctypes.c_void_p),
+                ("near_far", ctypes.c_void_p), ("num_rays_total", ctypes.c_int64),
+                ("ray_index", ctypes.c_void_p), ("ray_base", ctypes.c_int64),
+                ("valid", ctypes.c_void_p), ("num_rays", ctypes.c_int32),
+                ("num_samples", ctypes.c_int32), ("unit", ctypes.c_void_p),
+                ("t_values", ctypes.c_void_p)]
+
+
+class FfnOccupancy(ctypes.Structure):
+    _fields_ = [("bits", ctypes.c_void_p), ("box_min", ctypes.c_float * 3),
+                ("box_size", ctypes.c_float * 3), ("resolution", ctypes.c_int32)]
+
+
+class FfnRenderOut(ctypes.Structure):
+    _fields_ = [("color", ctypes.c_void_p), ("alpha", ctypes.c_void_p), ("depth", ctypes.c_void_p),
+                ("nan_flag", ctypes.c_void_p), ("image", ctypes.c_void_p),
+                ("pixel_offset", ctypes.c_int64)]
+
+
 def _struct_array_to_device(items, device):
     if not items:
         return torch.zeros((0,), dtype=torch.uint8, device=device)
@@ -564,6 +584,52 @@ class MlpProgram:
                   _dev(self.bias_buf), _dev(positions, name="positions"),
                   _dev(views, name="views"), c_i64(n), _dev(logits), _dev(acts), _dev(masks))
         return logits
+
+    def render(self, starts: torch.Tensor, directions: torch.Tensor, near_far: torch.Tensor,
+               ray_index, num_samples: int, unit: Optional[torch.Tensor],
+               t_values: Optional[torch.Tensor] = None, occupancy=None, want_color=True,
+               want_depth=False, nan_flag: Optional[torch.Tensor] = None,
+               image: Optional[torch.Tensor] = None, pixel_offset: int = 0):
+        """Fused inference render of the rays ``ray_index`` -- device int64 ids into the sampler
+        state, or a ``(first id, count, valid mask)`` tuple for a contiguous range filtered in
+        the kernel (a whole camera, no index list, no host sync): one launch, nothing but the
+        per-ray results touches HBM.  Returns
+        (color (R,3) | None, alpha (R) | None, depth (R) | None); ``image`` (H,W,3) uint8,
+        zeroed by the caller, additionally receives the truncated u8 pixels at
+        ``ray id - pixel_offset``.  ``occupancy`` = an OccupancyGrid switches on empty-space
+        skipping."""
+        if self.wide:
+            raise NotImplementedError("the fused render kernel covers chains of <= 256 channels")
+        base, valid = 0, None
+        if isinstance(ray_index, tuple):
+            base, rays, valid = int(ray_index[0]), int(ray_index[1]), ray_index[2]
+            ray_index = None
+        else:
+            rays = int(ray_index.shape[0])
+        dev = self.device
+        color = torch.empty((rays, 3), dtype=torch.float32, device=dev) if want_color else None
+        alpha = torch.empty((rays,), dtype=torch.float32, device=dev) if want_color else None
+        depth = torch.empty((rays,), dtype=torch.float32, device=dev) if want_depth else None
+        if rays == 0:
+            return color, alpha, depth
+        if t_values is not None and tuple(t_values.shape) != (rays, num_samples):
+            raise ValueError("t_values must be (num_rays, num_samples)")
+        ptr = lambda t, dtype=torch.float32: _dev(t, dtype).value or 0     # noqa: E731
+        rr = FfnRenderRays(ptr(starts), ptr(directions), ptr(near_far), int(near_far.shape[1]),
+                           ptr(ray_index, torch.int64), base, ptr(valid, torch.uint8), rays,
+                           int(num_samples), ptr(unit),
+                           ptr(t_values))
+        occ = None
+        if occupancy is not None:
+            occ = FfnOccupancy(ptr(occupancy.bits, torch.int32),
+                               (ctypes.c_float * 3)(*occupancy.box_min),
+                               (ctypes.c_float * 3)(*occupancy.box_size), int(occupancy.resolution))
+        out = FfnRenderOut(ptr(color), ptr(alpha), ptr(depth), ptr(nan_flag, torch.int32),
+                           ptr(image, torch.uint8), int(pixel_offset))
+        _call("ffn_render_fused_fwd", ctypes.byref(self.fwd), _dev(self.packed_fwd),
+              _dev(self.bias_buf), ctypes.byref(rr), None if occ is None else ctypes.byref(occ),
+              ctypes.byref(out))
+        return color, alpha, depth
 
     def backward(self, d_logits: torch.Tensor, positions: torch.Tensor,
                  views: Optional[torch.Tensor], saved: torch.Tensor, grads: torch.Tensor):

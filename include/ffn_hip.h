@@ -270,6 +270,61 @@ int ffn_mlp_forward(const ffn_mlp_chain* chain, const float* packed_w, const flo
                     const float* positions, const float* views, int64_t n, float* logits,
                     float* saved, uint32_t* masks, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Fused inference render: K2 + K3 + K4 + K5 in one launch.
+ * Replaces the body of Raycaster.render_image / batched_render (ray_caster.py:103-159:
+ * sampler.sample -> model -> activations -> calculate_blend_weights -> sums, each a pass over
+ * HBM-resident (R,S,3)/(R,S,4) arrays) for an eval-mode model: per ray, the t-samples, the
+ * positions, the features, every hidden activation and the logits stay on the CU; only the
+ * ray id + ray state are read and the composited pixel is written.
+ *   rays:      resident sampler state (K1's outputs) + the ids of the rays to render.
+ *              t_values == NULL: t_j = near + unit[j] * (far - near) (non-stratified uniform
+ *              sampling, ray_sampler.py:380-381, rounded like ffn_sample_t); otherwise the
+ *              caller's (R,S) t-values (stratified / opacity-guided samplers).
+ *   occupancy: NULL or an occupancy grid (K9): samples in empty cells are not evaluated
+ *              (sigma = 0 there: weight 0, transmittance factor 1) -- PSNR-level parity with
+ *              the full render, exactly the K9 semantics.
+ *   out:       any of color (R,3), alpha (R), depth (R) may be NULL; image != NULL also
+ *              writes the u8 pixel (x*255 truncated, ray_sampler.py:193-196) at pixel
+ *              ray_id - pixel_offset of an (H*W,3) frame the caller has zeroed.
+ * The chain must be a narrow (<= 256-channel) forward chain; num_samples <= 256.
+ */
+typedef struct ffn_render_rays {
+    const float* starts;       /* (num_rays_total,3)                                   */
+    const float* directions;   /* (num_rays_total,3), also the view directions          */
+    const float* near_far;     /* (2,num_rays_total)                                   */
+    int64_t num_rays_total;
+    const int64_t* ray_index;  /* (num_rays) int64 ray ids, or NULL: ids ray_base + 0..R-1   */
+    int64_t ray_base;
+    const uint8_t* valid;      /* NULL, or K1's (num_rays_total) mask: rays with valid == 0
+                                  are not traced (zeros in color/alpha/depth, no pixel):
+                                  a whole camera renders without a filtered index list  */
+    int32_t num_rays;
+    int32_t num_samples;
+    const float* unit;         /* (num_samples) torch.linspace(0,1,S), or NULL with t_values */
+    const float* t_values;     /* (num_rays,num_samples) or NULL                       */
+} ffn_render_rays;
+
+typedef struct ffn_occupancy {
+    const uint32_t* bits;      /* resolution^3 bits (ffn_occupancy_build)               */
+    float box_min[3];
+    float box_size[3];
+    int32_t resolution;
+} ffn_occupancy;
+
+typedef struct ffn_render_out {
+    float* color;
+    float* alpha;
+    float* depth;
+    int32_t* nan_flag;         /* as ffn_composite_fwd; may be NULL                    */
+    uint8_t* image;
+    int64_t pixel_offset;
+} ffn_render_out;
+
+int ffn_render_fused_fwd(const ffn_mlp_chain* chain, const float* packed_w, const float* bias,
+                         const ffn_render_rays* rays, const ffn_occupancy* occupancy,
+                         const ffn_render_out* out, void* stream);
+
 /* Backward-data chain: d_logits (N,4) + ReLU sign masks -> dZ slabs (same slab geometry as
  * `saved`).  packed_wt holds the transposed operand packs. */
 int ffn_mlp_backward_data(const ffn_mlp_chain* chain, const float* packed_wt,

@@ -1,6 +1,7 @@
 """Renders an orbit of PNG frames from a trained checkpoint on the MI355X path (counterpart of
-the reference's orbit_video.py).  With several GPUs (torch.distributed.run) frame f goes to
-rank f mod world: replicas only, no collective."""
+the reference's orbit_video.py): one fused-kernel launch per frame, copy-out and PNG encoding
+overlapped with the next frames (FrameSink).  With several GPUs (torch.distributed.run) frame f
+goes to rank f mod world: replicas only, no collective."""
 
 import os
 import sys
@@ -33,10 +34,14 @@ def main():
                              args.batch_size, device=device)
     os.makedirs(args.output_dir, exist_ok=True)
     bar = ffn.ETABar("Rendering", max=len(mine))
-    for local, frame in enumerate(mine):
-        bar.next()
-        image = caster.render_image(sampler, local, args.batch_size)
-        _cli.save_png(os.path.join(args.output_dir, "frame_{:05d}.png".format(frame)), image)
+    # frames stay on the GPU until the sink's side stream copies them out; PNG encoding runs on
+    # worker threads, so the next frame's kernels are already queued while this one is written
+    with ffn.FrameSink() as sink:
+        for local, frame in enumerate(mine):
+            bar.next()
+            image = caster.render_image_device(sampler, local, args.batch_size)
+            sink.submit(image, os.path.join(args.output_dir, "frame_{:05d}.png".format(frame)))
+    caster.check_finite()
     bar.finish()
     return 0
 

@@ -32,6 +32,11 @@ def test_plan_struct_sizes_match_header():
     #include <stddef.h>
     #include "ffn_hip.h"
     int main(void) {
+      printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu ", sizeof(ffn_render_rays),
+             offsetof(ffn_render_rays, ray_base), offsetof(ffn_render_rays, num_samples),
+             offsetof(ffn_render_rays, t_values), sizeof(ffn_occupancy),
+             offsetof(ffn_occupancy, resolution), sizeof(ffn_render_out),
+             offsetof(ffn_render_out, image), offsetof(ffn_render_out, pixel_offset));
       printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(ffn_encoding),
              sizeof(ffn_step), sizeof(ffn_mlp_chain), offsetof(ffn_mlp_chain, step),
              offsetof(ffn_mlp_chain, num_steps), offsetof(ffn_mlp_chain, bias_floats),
@@ -47,7 +52,12 @@ def test_plan_struct_sizes_match_header():
         inc = os.path.dirname(_lib.HEADER_PATH)
         subprocess.run(["gcc", "-I", inc, c_path, "-o", exe], check=True)
         out = subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()
-    got = [ctypes.sizeof(me.FfnEncoding), ctypes.sizeof(me.FfnStep), ctypes.sizeof(me.FfnMlpChain),
+    got = [ctypes.sizeof(me.FfnRenderRays), me.FfnRenderRays.ray_base.offset,
+           me.FfnRenderRays.num_samples.offset, me.FfnRenderRays.t_values.offset,
+           ctypes.sizeof(me.FfnOccupancy), me.FfnOccupancy.resolution.offset,
+           ctypes.sizeof(me.FfnRenderOut), me.FfnRenderOut.image.offset,
+           me.FfnRenderOut.pixel_offset.offset,
+           ctypes.sizeof(me.FfnEncoding), ctypes.sizeof(me.FfnStep), ctypes.sizeof(me.FfnMlpChain),
            me.FfnMlpChain.step.offset, me.FfnMlpChain.num_steps.offset,
            me.FfnMlpChain.bias_floats.offset, me.FfnMlpChain.slot_offset.offset,
            me.FfnStep.w_off.offset, me.FfnStep.save_enc_slot.offset, ctypes.sizeof(me.FfnWgradUnit),

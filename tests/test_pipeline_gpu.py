@@ -467,6 +467,7 @@ def test_render_with_empty_space_skipping():
     bounds = np.diag([2, 2, 2, 1]).astype(np.float32)
     sampler = _quiet(ffn.RaySampler, bounds, cams, 96, device=dev())
     caster = ffn.Raycaster(model)
+    caster.fused_render = False                  # this test counts model calls: the K9 path
     full = [caster.render_image(sampler, c, 4096) for c in range(2)]
     grid = ffn.OccupancyGrid.from_model(model, bounds, resolution=64, sigma_threshold=1e-3)
     assert 0.0 < grid.fraction_occupied() < 0.05       # the octahedron fills 0.13 % of the box

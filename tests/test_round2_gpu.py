@@ -48,7 +48,6 @@ def test_public_blend_weights_against_golden(golden):
     sigma = torch.nn.functional.softplus(_t(g["logits"])[..., 3])
     w = ffn.calculate_blend_weights(t.to(dev()), sigma.to(dev()))
     np.testing.assert_allclose(w.cpu().numpy(), g["weights"], rtol=1e-5, atol=1e-7)
-    assert np.allclose(orc.blend_weights(t, sigma).numpy(), g["weights"], rtol=1e-6, atol=1e-8)
 
 
 @pytest.mark.parametrize("S", [2, 16, 37, 64, 65, 130, 256])
@@ -388,3 +387,148 @@ def test_orbit_video_two_ranks_write_the_same_frames(tmp_path):
         b = np.asarray(Image.open(os.path.join(two, name)))
         assert np.array_equal(a, b), name
     assert ffn.load_model(ckpt) is not None
+
+
+# ----------------------------------------------------------------------------------- fused render
+def _scene_sampler(num_samples, stratified=False, opacity_model=None, cams=None):
+    import fourier_feature_nets_amd as ffn
+    data = np.load(SCENE)
+    n_train = int(data["split_counts"][0])
+    take = range(n_train) if cams is None else cams
+    cameras = [ffn.CameraInfo.create("c%d" % i, ffn.Resolution(16, 16), data["intrinsics"][i],
+                                     data["extrinsics"][i]) for i in take]
+    return _quiet(ffn.RaySampler, data["bounds"], cameras, num_samples, stratified, opacity_model,
+                  64, device=dev())
+
+
+def _render_both_ways(caster, sampler, rays, seed=None):
+    """(fused RenderResult, unfused RenderResult) of the same rays."""
+    if seed is not None:
+        torch.manual_seed(seed)
+    with torch.no_grad():
+        fused = caster.render_rays(sampler, rays, include_depth=True)
+        if seed is not None:
+            torch.manual_seed(seed)
+        plain = caster.render(sampler.sample(rays, None), True)
+    return fused, plain
+
+
+@pytest.mark.parametrize("S", [16, 32, 37, 64, 96, 128, 200, 256])
+def test_fused_render_equals_the_three_pass_render(golden, S):
+    """ffn_render_fused_fwd (sampling + encoding + MLP + compositing in one launch, logits
+    consumed from registers) == sampler.sample -> model -> composite kernels on the same rays:
+    identical t / positions by construction, colour and alpha to 1e-6, same depth pick."""
+    import fourier_feature_nets_amd as ffn
+    from tests.test_pipeline_gpu import _small_model
+    model = _small_model(golden("training"))
+    caster = ffn.Raycaster(model)
+    sampler = _scene_sampler(S)
+    rays = sampler.valid_index(torch.arange(0, sampler.num_rays, 3, device=dev()))
+    fused, plain = _render_both_ways(caster, sampler, rays)
+    np.testing.assert_allclose(fused.color.cpu().numpy(), plain.color.cpu().numpy(), rtol=2e-6, atol=1e-6)
+    np.testing.assert_allclose(fused.alpha.cpu().numpy(), plain.alpha.cpu().numpy(), rtol=2e-6, atol=1e-6)
+    same = (fused.depth == plain.depth).float().mean()
+    assert float(same) > 0.99
+    caster.check_finite()
+    # a whole-camera range filtered by the validity mask in the kernel == the filtered index list
+    with torch.no_grad():
+        per = sampler.rays_per_camera
+        ranged = caster.render_rays(sampler, (per, per), include_depth=True)
+        ids = torch.arange(per, 2 * per, device=dev())
+        listed = caster.render_rays(sampler, sampler.valid_index(ids), include_depth=True)
+    keep = sampler.valid[ids] != 0
+    assert torch.equal(ranged.color[keep], listed.color) and torch.equal(ranged.alpha[keep], listed.alpha)
+    assert torch.equal(ranged.depth[keep], listed.depth)
+    assert float(ranged.color[~keep].abs().max()) == 0.0 if bool((~keep).any()) else True
+
+
+def test_fused_render_full_nerf_and_samplers(golden):
+    """View-dependent full NeRF through the fused kernel; stratified and opacity-guided samplers
+    hand their t-values to it (same seeded noise for both paths)."""
+    import fourier_feature_nets_amd as ffn
+    from tests.test_kernels_gpu import _load_nerf
+    from tests.test_pipeline_gpu import _small_model
+    model, _ = _load_nerf(golden("models"), "nerf", [4], True)
+    caster = ffn.Raycaster(model)
+    coarse = _small_model(golden("training"))
+    for sampler, seed in ((_scene_sampler(64), None), (_scene_sampler(64, stratified=True), 3),
+                          (_scene_sampler(64, stratified=True, opacity_model=coarse), 4)):
+        rays = sampler.valid_index(torch.arange(1, sampler.num_rays, 5, device=dev()))
+        fused, plain = _render_both_ways(caster, sampler, rays, seed)
+        np.testing.assert_allclose(fused.color.cpu().numpy(), plain.color.cpu().numpy(), rtol=2e-6, atol=1e-6)
+        np.testing.assert_allclose(fused.alpha.cpu().numpy(), plain.alpha.cpu().numpy(), rtol=2e-6, atol=1e-6)
+
+
+def test_fused_render_image_and_fallbacks(golden):
+    """render_image through the fused kernel (u8 pixels written by the kernel) vs the unfused
+    path: at most one u8 level apart, almost everywhere identical; a 512-wide model silently
+    takes the unfused path."""
+    import fourier_feature_nets_amd as ffn
+    from tests.test_kernels_gpu import _load_fourier
+    from tests.test_pipeline_gpu import _small_model
+    model = _small_model(golden("training"))
+    caster = ffn.Raycaster(model)
+    sampler = _scene_sampler(64)
+    a = caster.render_image(sampler, 1, 100)
+    caster.fused_render = False
+    b = caster.render_image(sampler, 1, 100)
+    assert a.shape == b.shape == (16, 16, 3) and a.dtype == np.uint8
+    diff = np.abs(a.astype(np.int32) - b.astype(np.int32))
+    assert diff.max() <= 1 and (diff == 0).mean() > 0.98
+    assert a.max() > 0
+    wide, _ = _load_fourier(golden("models"), "gaussian512")
+    wcaster = ffn.Raycaster(wide)
+    assert not wcaster._can_fuse(sampler)
+    assert wcaster.render_image(sampler, 0, 100).shape == (16, 16, 3)
+
+
+def test_fused_render_with_empty_space_skipping():
+    """Per-ray compaction inside the fused kernel == the K9 compaction path == (PSNR-level) the
+    full render: samples in empty cells have sigma = 0, weight 0 and transmittance factor 1."""
+    import fourier_feature_nets_amd as ffn
+    from tests.test_pipeline_gpu import _octahedron_model
+    model = _octahedron_model()
+    caster = ffn.Raycaster(model)
+    size = 48
+    cams = []
+    for i in range(2):
+        k, e = look_at_camera([3.5 * math.cos(i + 0.4), 0.8, 3.5 * math.sin(i + 0.4)], size, size)
+        cams.append(ffn.CameraInfo.create("c%d" % i, ffn.Resolution(size, size), k, e))
+    bounds = np.eye(4, dtype=np.float32) * 2
+    sampler = _quiet(ffn.RaySampler, bounds, cams, 128, device=dev())
+    rays = sampler.valid_index(torch.arange(0, sampler.num_rays, device=dev()))
+    with torch.no_grad():
+        full = caster.render_rays(sampler, rays, include_depth=True)
+        caster.occupancy = ffn.OccupancyGrid.from_model(model, bounds, 32, 0.01, True)
+        assert 0.0 < caster.occupancy.fraction_occupied() < 0.2
+        skip_fused = caster.render_rays(sampler, rays, include_depth=True)
+        skip_k9 = caster.render(sampler.sample(rays, None), True)
+    # fused skipping == K9 skipping (same samples evaluated, the others contribute exactly 0)
+    np.testing.assert_allclose(skip_fused.color.cpu().numpy(), skip_k9.color.cpu().numpy(), rtol=2e-6, atol=1e-6)
+    np.testing.assert_allclose(skip_fused.alpha.cpu().numpy(), skip_k9.alpha.cpu().numpy(), rtol=2e-6, atol=1e-6)
+    # and close to the full render
+    mse = float((skip_fused.color - full.color).square().mean())
+    assert mse < 1e-5, mse
+    assert float(full.alpha.max()) > 0.5 and float((full.alpha < 1e-3).float().mean()) > 0.3
+    hit = full.alpha > 0.3
+    assert float((skip_fused.depth[hit] - full.depth[hit]).abs().max()) < 0.2
+
+
+def test_frame_sink_writes_frames_asynchronously(tmp_path, golden):
+    """FrameSink: device frames -> pinned ring -> PNG files, more frames than ring slots."""
+    import fourier_feature_nets_amd as ffn
+    from PIL import Image
+    from tests.test_pipeline_gpu import _small_model
+    caster = ffn.Raycaster(_small_model(golden("training")))
+    sampler = _scene_sampler(32)
+    expected = {}
+    with ffn.FrameSink(slots=2, workers=2) as sink:
+        for i in range(7):
+            img = caster.render_image_device(sampler, i, 64)
+            expected[i] = img.cpu().numpy()
+            sink.submit(img, str(tmp_path / ("f%d.png" % i)))
+    assert sink.frames == 7
+    for i, exp in expected.items():
+        got = np.asarray(Image.open(str(tmp_path / ("f%d.png" % i))))
+        assert np.array_equal(got, exp)
+    assert np.array_equal(expected[0], caster.render_image(sampler, 0, 64))
