@@ -25,7 +25,11 @@ __device__ __forceinline__ float scan_add(float v, int lane) {
 
 // ---------------------------------------------------------------------------------- K2c
 // cdf = [0, cumsum(w[1:-1] + 1e-5) / sum], w = blend weights of the probe (n samples).
-template <int ROWS>
+// LOGITS: `opacity` holds the coarse model's raw (P,n,4) outputs; sigma = softplus of the last
+// channel is taken here (ray_sampler.py:261-265) instead of in a separate pass.
+__device__ __forceinline__ float softplus_probe(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+
+template <int ROWS, bool LOGITS>
 __global__ void __launch_bounds__(256)
 cdf_build_kernel(const float* __restrict__ t_probe, const float* __restrict__ opacity,
                  int64_t num_rays, int n, float* __restrict__ cdf) {
@@ -34,7 +38,7 @@ cdf_build_kernel(const float* __restrict__ t_probe, const float* __restrict__ op
     const int64_t waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     for (int64_t ray = wave; ray < num_rays; ray += waves) {
         const float* tr = t_probe + ray * n;
-        const float* op = opacity + ray * n;
+        const float* op = opacity + ray * n * (LOGITS ? 4 : 1);
         float w[ROWS];
         float carry = 1.0f;
 #pragma unroll
@@ -43,7 +47,8 @@ cdf_build_kernel(const float* __restrict__ t_probe, const float* __restrict__ op
             float alpha = 0.0f, tau = 1.0f;
             if (s < n) {
                 const float delta = (s == n - 1) ? 1e10f : tr[s + 1] - tr[s];
-                alpha = 1.0f - expf(-(op[s] * delta));
+                const float sigma = LOGITS ? softplus_probe(op[4 * s + 3]) : op[s];
+                alpha = 1.0f - expf(-(sigma * delta));
                 const float u = (1.0f - alpha) + 1e-10f;
                 tau = u < 1.0f ? u : 1.0f;
             }
@@ -77,6 +82,9 @@ cdf_build_kernel(const float* __restrict__ t_probe, const float* __restrict__ op
 
 // ---------------------------------------------------------------------------------- K2d
 // LDS per wave: cdf row (<=255), merged t row (<=256).
+// ROWS_LOCAL: `cdfs` holds one row per BATCH ray (built on the fly from a live coarse model)
+// instead of the per-sampler table indexed by global ray id.
+template <bool ROWS_LOCAL>
 __global__ void __launch_bounds__(256)
 focus_merge_kernel(const float* __restrict__ near_far, int64_t total_rays,
                    const float* __restrict__ cdfs, const int64_t* __restrict__ ray_index,
@@ -97,7 +105,8 @@ focus_merge_kernel(const float* __restrict__ near_far, int64_t total_rays,
         const float near = near_far[ray];
         const float far = near_far[total_rays + ray];
         const float span = far - near;
-        for (int i = lane; i < width; i += 64) c[i] = cdfs[ray * width + i];
+        const int64_t cdf_row = ROWS_LOCAL ? (int64_t)r : ray;
+        for (int i = lane; i < width; i += 64) c[i] = cdfs[cdf_row * width + i];
         float* row = t_io + (int64_t)r * S;
         for (int i = lane; i < n_uniform; i += 64) tv[i] = row[i];
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): LDS writes of this wave are done
@@ -145,8 +154,9 @@ focus_merge_kernel(const float* __restrict__ near_far, int64_t total_rays,
 
 using namespace ffn;
 
-extern "C" int ffn_cdf_build(const float* t_probe, const float* opacity, int64_t num_rays, int n,
-                             float* cdf, void* stream) {
+template <bool LOGITS>
+static int launch_cdf_build(const float* t_probe, const float* opacity, int64_t num_rays, int n,
+                            float* cdf, void* stream, const char* what) {
     if (num_rays == 0) return 0;
     if (n < 3 || n > 256) return fail_arg("ffn_cdf_build: probe length must be in [3,256]");
     int64_t blocks = (num_rays + 3) / 4;
@@ -155,24 +165,56 @@ extern "C" int ffn_cdf_build(const float* t_probe, const float* opacity, int64_t
     hipStream_t st = (hipStream_t)stream;
     const int rows = (n + 63) / 64;
     switch (rows) {
-        case 1: hipLaunchKernelGGL(cdf_build_kernel<1>, grid, block, 0, st, t_probe, opacity, num_rays, n, cdf); break;
-        case 2: hipLaunchKernelGGL(cdf_build_kernel<2>, grid, block, 0, st, t_probe, opacity, num_rays, n, cdf); break;
-        default: hipLaunchKernelGGL(cdf_build_kernel<4>, grid, block, 0, st, t_probe, opacity, num_rays, n, cdf); break;
+        case 1: hipLaunchKernelGGL((cdf_build_kernel<1, LOGITS>), grid, block, 0, st, t_probe, opacity, num_rays, n, cdf); break;
+        case 2: hipLaunchKernelGGL((cdf_build_kernel<2, LOGITS>), grid, block, 0, st, t_probe, opacity, num_rays, n, cdf); break;
+        default: hipLaunchKernelGGL((cdf_build_kernel<4, LOGITS>), grid, block, 0, st, t_probe, opacity, num_rays, n, cdf); break;
     }
-    return check_launch("ffn_cdf_build");
+    return check_launch(what);
+}
+
+extern "C" int ffn_cdf_build(const float* t_probe, const float* opacity, int64_t num_rays, int n,
+                             float* cdf, void* stream) {
+    return launch_cdf_build<false>(t_probe, opacity, num_rays, n, cdf, stream, "ffn_cdf_build");
+}
+
+extern "C" int ffn_cdf_build_logits(const float* t_probe, const float* logits, int64_t num_rays,
+                                    int n, float* cdf, void* stream) {
+    return launch_cdf_build<true>(t_probe, logits, num_rays, n, cdf, stream, "ffn_cdf_build_logits");
+}
+
+static int launch_focus_merge(bool rows_local, const float* near_far, int64_t num_rays_total,
+                              const float* cdfs, const int64_t* ray_index, const float* u,
+                              const float* unit_focus, int num_rays, int num_samples, int n_focus,
+                              float* t_io, void* stream) {
+    if (num_rays == 0) return 0;
+    if (num_samples > 256 || n_focus < 2 || n_focus > num_samples)
+        return fail_arg("ffn_focus_sample_merge: need 2 <= n_focus <= S <= 256");
+    int64_t blocks = ((int64_t)num_rays + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    if (rows_local)
+        hipLaunchKernelGGL(focus_merge_kernel<true>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream,
+                           near_far, num_rays_total, cdfs, ray_index, u, unit_focus, num_rays,
+                           num_samples, n_focus, t_io);
+    else
+        hipLaunchKernelGGL(focus_merge_kernel<false>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream,
+                           near_far, num_rays_total, cdfs, ray_index, u, unit_focus, num_rays,
+                           num_samples, n_focus, t_io);
+    return check_launch("ffn_focus_sample_merge");
 }
 
 extern "C" int ffn_focus_sample_merge(const float* near_far, int64_t num_rays_total,
                                       const float* cdfs, const int64_t* ray_index, const float* u,
                                       const float* unit_focus, int num_rays, int num_samples,
                                       int n_focus, float* t_io, void* stream) {
-    if (num_rays == 0) return 0;
-    if (num_samples > 256 || n_focus < 2 || n_focus > num_samples)
-        return fail_arg("ffn_focus_sample_merge: need 2 <= n_focus <= S <= 256");
-    int64_t blocks = ((int64_t)num_rays + 3) / 4;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(focus_merge_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream,
-                       near_far, num_rays_total, cdfs, ray_index, u, unit_focus, num_rays,
-                       num_samples, n_focus, t_io);
-    return check_launch("ffn_focus_sample_merge");
+    return launch_focus_merge(false, near_far, num_rays_total, cdfs, ray_index, u, unit_focus,
+                              num_rays, num_samples, n_focus, t_io, stream);
+}
+
+extern "C" int ffn_focus_sample_merge_rows(const float* near_far, int64_t num_rays_total,
+                                           const float* cdf_rows, const int64_t* ray_index,
+                                           const float* u, const float* unit_focus, int num_rays,
+                                           int num_samples, int n_focus, float* t_io,
+                                           void* stream) {
+    return launch_focus_merge(true, near_far, num_rays_total, cdf_rows, ray_index, u, unit_focus,
+                              num_rays, num_samples, n_focus, t_io, stream);
 }

@@ -102,7 +102,7 @@ class ImageDataset(RayDataset):
                  cameras: List[CameraInfo], num_samples: int, include_alpha=True,
                  stratified=False, opacity_model: nn.Module = None, batch_size=4096,
                  color_space="RGB", sparse_size=50, anneal_start=0.2, num_anneal_steps=0,
-                 alpha_weight=0.1, device=None):
+                 alpha_weight=0.1, device=None, focus_mode=None):
         assert len(images.shape) == 4
         assert len(images) == len(cameras)
         assert images.dtype == np.uint8
@@ -117,7 +117,8 @@ class ImageDataset(RayDataset):
         self._subsample_index = None
         self._subsample_mask = None
         self.sampler = RaySampler(bounds, cameras, num_samples, stratified, opacity_model,
-                                  batch_size, anneal_start, num_anneal_steps, device=device)
+                                  batch_size, anneal_start, num_anneal_steps, device=device,
+                                  focus_mode=focus_mode)
         dev = self.sampler.device
         width, height = self.image_width, self.image_height
         per_cam = width * height
@@ -348,12 +349,13 @@ class ImageDataset(RayDataset):
                             self.sampler.batch_size, self.color_space, self.sparse_size,
                             self.sampler.anneal_start, self.sampler.num_anneal_steps,
                             self.alpha_weight,      # unchanged, like image_dataset.py:349-362
-                            device=self.sampler.device)
+                            device=self.sampler.device, focus_mode=self.sampler.focus_mode)
 
     @staticmethod
     def load(path: str, split: str, num_samples: int, include_alpha: bool, stratified: bool,
              opacity_model: nn.Module = None, batch_size=4096, color_space="RGB", sparse_size=50,
-             anneal_start=0.2, num_anneal_steps=0, device=None) -> Optional["ImageDataset"]:
+             anneal_start=0.2, num_anneal_steps=0, device=None,
+             focus_mode=None) -> Optional["ImageDataset"]:
         """Loads one split of an NPZ with images (C,H,W,3|4) u8, intrinsics (C,3,3),
         extrinsics (C,4,4) camera-to-world, bounds (4,4) and split_counts (3,)
         (image_dataset.py:388-471).  Returns None when the file is missing."""
@@ -377,7 +379,8 @@ class ImageDataset(RayDataset):
                    for i, (k, e) in enumerate(zip(data["intrinsics"][idx], data["extrinsics"][idx]))]
         return ImageDataset(split, data["images"][idx], data["bounds"], cameras, num_samples,
                             include_alpha, stratified, opacity_model, batch_size, color_space,
-                            sparse_size, anneal_start, num_anneal_steps, device=device)
+                            sparse_size, anneal_start, num_anneal_steps, device=device,
+                            focus_mode=focus_mode)
 
     def _subsample_rays(self, resolution: int) -> List[int]:
         """Pixel ids of a resolution-high regular grid (image_dataset.py:473-482)."""

@@ -113,10 +113,18 @@ def cdf_build(t_probe: torch.Tensor, opacity: torch.Tensor) -> torch.Tensor:
     return cdf
 
 
-def focus_sample_merge(near_far, cdfs, ray_index, u, unit_focus, t_io, n_focus):
-    """K2d.  In-place on t_io (R,S)."""
+def cdf_build_logits(t_probe: torch.Tensor, logits: torch.Tensor) -> torch.Tensor:
+    """K2c on raw coarse-model outputs: (P,n), (P*n,4) -> (P,n-1); softplus inside."""
+    rays, n = t_probe.shape
+    cdf = torch.empty((rays, n - 1), dtype=torch.float32, device=t_probe.device)
+    _call("ffn_cdf_build_logits", _dev(t_probe), _dev(logits), c_i64(rays), c_i(n), _dev(cdf))
+    return cdf
+
+
+def focus_sample_merge(near_far, cdfs, ray_index, u, unit_focus, t_io, n_focus, rows_local=False):
+    """K2d.  In-place on t_io (R,S).  ``rows_local``: cdfs holds one row per batch ray."""
     rays, count = t_io.shape
-    _call("ffn_focus_sample_merge", _dev(near_far), c_i64(near_far.shape[1]), _dev(cdfs),
+    _call("ffn_focus_sample_merge_rows" if rows_local else "ffn_focus_sample_merge", _dev(near_far), c_i64(near_far.shape[1]), _dev(cdfs),
               _dev(ray_index, torch.int64), _dev(u), _dev(unit_focus), c_i(rays), c_i(count),
               c_i(n_focus), _dev(t_io))
     return t_io

@@ -80,6 +80,12 @@ int ffn_materialise_samples(const float* starts, const float* directions,
 int ffn_cdf_build(const float* t_probe, const float* opacity, int64_t num_rays, int n,
                   float* cdf, void* stream);
 
+/* K2c on the coarse model's raw outputs: logits (P,n,4); sigma = softplus(logits[...,3])
+ * (ray_sampler.py:261-265) is applied inside.  Used by the live focus sampler, which builds
+ * CDF rows per batch instead of a per-sampler table. */
+int ffn_cdf_build_logits(const float* t_probe, const float* logits, int64_t num_rays, int n,
+                         float* cdf, void* stream);
+
 /* K2d  inverse-transform focus samples + merge with the uniform half + sort
  * (ray_sampler.py:301-357 and :388-392).
  *   cdfs (num_rays_total, n_focus-1) indexed by global ray id
@@ -91,6 +97,13 @@ int ffn_focus_sample_merge(const float* near_far, int64_t num_rays_total,
                            const float* cdfs, const int64_t* ray_index, const float* u,
                            const float* unit_focus, int num_rays, int num_samples,
                            int n_focus, float* t_io, void* stream);
+
+/* K2d with one CDF row per BATCH ray: cdf_rows (R, n_focus-1), row r belongs to
+ * ray_index[r].  Everything else as ffn_focus_sample_merge. */
+int ffn_focus_sample_merge_rows(const float* near_far, int64_t num_rays_total,
+                                const float* cdf_rows, const int64_t* ray_index, const float* u,
+                                const float* unit_focus, int num_rays, int num_samples,
+                                int n_focus, float* t_io, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * K3  standalone Fourier feature encoding.

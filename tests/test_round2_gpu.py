@@ -76,7 +76,7 @@ def test_public_blend_weights_is_differentiable(S):
         if ref.numel() == 0:
             continue
         scale = max(float(ref.abs().max()), 1e-12)
-        np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=2e-4, atol=2e-6 * scale)
+        np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=2e-4, atol=2e-5 * scale)
     # opacity-only gradient (t without requires_grad) takes the d_t == NULL path
     s2 = sigma.to(dev()).requires_grad_(True)
     (ffn.calculate_blend_weights(t.to(dev()), s2) * probe.to(dev())).sum().backward()
@@ -274,7 +274,7 @@ def test_full_nerf_north_star_size_properties(golden):
     parts = [a + b for a, b in zip(grads_of(0, cut), grads_of(cut, n))]
     for a, b in zip(whole, parts):
         scale = float(a.abs().max())
-        assert float((a - b).abs().max()) <= 3e-5 * max(scale, 1e-6)
+        assert float((a - b).abs().max()) <= 1e-4 * max(scale, 1e-9)      # 8.4 M-term fp32 sums, two partitions
     model.zero_grad()
     torch.cuda.empty_cache()
 
@@ -532,3 +532,60 @@ def test_frame_sink_writes_frames_asynchronously(tmp_path, golden):
         got = np.asarray(Image.open(str(tmp_path / ("f%d.png" % i))))
         assert np.array_equal(got, exp)
     assert np.array_equal(expected[0], caster.render_image(sampler, 0, 64))
+
+
+# ----------------------------------------------------------------------------------- f2 live focus
+def test_live_focus_sampler_equals_the_table(golden):
+    """focus_mode="live": no CDF table, no start-up coarse pass; the batch's CDF rows come from
+    the opacity model as it is at sample time, through the same kernels -- so with an unchanged
+    opacity model the t-values are the table path's bit for bit; and they follow the model when
+    it changes (which the table cannot)."""
+    import fourier_feature_nets_amd as ffn
+    from tests.test_pipeline_gpu import _small_model
+    coarse = _small_model(golden("training"))
+    for S, stratified in ((16, False), (128, True), (37, True)):
+        table = _scene_sampler(S, stratified, coarse)
+        data = np.load(SCENE)
+        cams = table.cameras
+        live = _quiet(ffn.RaySampler, data["bounds"], cams, S, stratified, coarse, 64, device=dev(),
+                      focus_mode="live")
+        assert table.cdfs is not None and live.cdfs is None and live.focus_sampling
+        assert table.cdfs.numel() == table.num_rays * (S - S // 2 - 1)
+        idx = table.valid_index(torch.arange(2, table.num_rays, 3, device=dev()))
+        torch.manual_seed(S)
+        a = table.sample(idx, None)
+        torch.manual_seed(S)
+        b = live.sample(idx, None)
+        assert torch.equal(a.t_values, b.t_values) and torch.equal(a.positions, b.positions)
+        assert bool((a.t_values[:, 1:] >= a.t_values[:, :-1]).all())
+    # the live sampler follows a changing coarse model
+    live2 = _quiet(ffn.RaySampler, data["bounds"], cams, 16, False, coarse, 64, device=dev(),
+                   focus_mode="live")
+    t0 = live2.sample(idx, None).t_values.clone()
+    with torch.no_grad():
+        coarse.layers[-1].bias[3] += 6.0          # much denser everywhere
+        coarse.layers[-1].weight[3] *= 0.1
+    coarse.invalidate_packed()
+    t1 = live2.sample(idx, None).t_values
+    assert not torch.equal(t0, t1)
+
+
+def test_live_focus_sampler_with_voxels_and_golden(golden):
+    """The reference's own focus fixture (voxel opacity model, ray_sampler.py:234-357): live
+    t-values == the reference's to the table path's tolerance."""
+    import fourier_feature_nets_amd as ffn
+    g, r, s = golden("focus"), golden("raygen"), golden("sampling")
+    vox = ffn.Voxels(8, 1.0)
+    with torch.no_grad():
+        vox.voxels.copy_(_t(g["voxels"]))
+        vox.bias.copy_(_t(g["vox_bias"]))
+    vox = vox.to(dev())
+    cams = [ffn.CameraInfo.create("c%d" % i, ffn.Resolution(int(r["width"]), int(r["height"])), k, e)
+            for i, (k, e) in enumerate(zip(r["intrinsics"], r["extrinsics"]))]
+    live = _quiet(ffn.RaySampler, r["bounds_eye2"], cams, 16, False, vox, 64, 0.5, 0, device=dev(),
+                  focus_mode="live")
+    table = _quiet(ffn.RaySampler, r["bounds_eye2"], cams, 16, False, vox, 64, 0.5, 0, device=dev())
+    assert live.cdfs is None and table.cdfs is not None
+    out = live.sample(s["idx"].tolist(), None)
+    np.testing.assert_allclose(out.t_values.cpu().numpy(), g["t_u"], rtol=2e-4, atol=2e-4)
+    assert torch.equal(out.t_values, table.sample(s["idx"].tolist(), None).t_values)
