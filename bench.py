@@ -5,19 +5,27 @@
 One "step" is one complete optimisation step of the reference's training loop
 (ray_caster.py:319-329) on one batch of synthetic rays: stratified t-sampling -> fused
 Fourier-MLP forward -> alpha compositing -> loss -> backward (composite, dgrad, wgrad) ->
-[RCCL all-reduce] -> clip + Adam.  Workload = BASELINE.json configs[1]: tiny NeRF
+[one RCCL all-reduce] -> clip + Adam.  Workload = BASELINE.json configs[1]: tiny NeRF
 (PositionalFourierMLP(3,4,5.5), 256 channels) on a synthetic 100 x 400x400 RGBA dataset,
 64 samples/ray, 65536 rays per GPU per step (weak scaling).  Inputs (ray state, ground truth,
 weights) are resident in HBM before the timed region.
 
-Rank 0 prints ONE JSON line (metric, value, roofline of the dominant kernel, CPU baseline).
+``--gpus N`` without a launcher spawns its own N ranks (torch.distributed.run, one per GPU).
+Rank 0 prints ONE JSON line: the metric, the roofline of the dominant kernel, per-kernel
+timings, the all-reduce cost (N > 1), and -- at N = 1 -- the reporting-only legs: frames/sec of
+the fused render (with and without frame I/O), the MLP kernels at the north-star launch shape,
+a full optimisation step of BASELINE configs[2] (full NeRF, 64 uniform + 64 opacity-guided
+samples with a live coarse model) and the CPU baseline.
 """
 
 import argparse
+import contextlib
+import io
 import json
-import math
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -27,6 +35,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+TRAFFIC_PROFILE = "profiles/r02_hbm_traffic.json"
+
+KERNEL_OF = {"ffn_mlp_forward": "mlp_forward_kernel<train>",
+             "ffn_mlp_backward_data": "mlp_backward_data_kernel",
+             "ffn_mlp_wgrad_units": "wgrad_unit_kernel"}
+SYMBOL_OF = {"mlp_forward_kernel<train>": "ffn::mlp_forward_kernel<1, false>",
+             "mlp_backward_data_kernel": "ffn::mlp_backward_data_kernel<false>",
+             "wgrad_unit_kernel": "ffn::wgrad_unit_kernel"}
 
 
 def parse_args():
@@ -42,6 +58,8 @@ def parse_args():
     ap.add_argument("--no-render", action="store_true", help="skip the frames/sec leg")
     ap.add_argument("--no-target-shape", action="store_true",
                     help="skip the MFMA-utilisation leg at the north-star shape (NeRF, 65536 x 128)")
+    ap.add_argument("--no-config3", action="store_true",
+                    help="skip the full-NeRF + focus-sampling optimisation-step leg")
     ap.add_argument("--model", default="tiny", choices=["tiny", "nerf", "gaussian512"],
                     help="tiny = BASELINE configs[1] (the metric's config); nerf = configs[2]-shaped "
                          "full NeRF (8x256, skip, view branch), use with --samples 128")
@@ -109,7 +127,7 @@ def physical_cores():
     return logical, logical
 
 
-def cpu_baseline(args, model_state, log):
+def cpu_baseline(args, model_state):
     """The oracle's training step (the reference's ATen op sequence restated) on the host
     cores, on a bounded sample of the same workload: full training step and forward only."""
     from oracle import ffn_oracle as orc
@@ -165,6 +183,73 @@ def cpu_baseline(args, model_state, log):
                                                       S, cores)}
 
 
+class KernelTimer:
+    """HIP events around the three MLP entry points, on the stream they are launched on."""
+
+    def __init__(self):
+        from fourier_feature_nets_amd import _lib as lib_mod
+        self.lib = lib_mod
+        self.orig = lib_mod.call
+        self.spans = {}
+        self.on = False
+        lib_mod.call = self._call
+
+    def _call(self, name, *a):
+        key = KERNEL_OF.get(name)
+        if key is None or not self.on:
+            return self.orig(name, *a)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self.orig(name, *a)
+        e1.record()
+        self.spans.setdefault(key, []).append((e0, e1))
+
+    def close(self):
+        self.lib.call = self.orig
+
+    def summary(self, prog, n_samples):
+        specs = prog.layers
+        fwd = 2 * sum(sp.out * sp.ld for sp in specs)
+        flops = {"mlp_forward_kernel<train>": fwd, "wgrad_unit_kernel": fwd,
+                 "mlp_backward_data_kernel": 2 * sum(sp.out * sp.act_in for sp in specs)}
+        out = {}
+        for key, pairs in self.spans.items():
+            ms = [a.elapsed_time(b) for a, b in pairs]
+            avg = sum(ms) / len(ms)
+            tf = flops[key] * n_samples / (avg * 1e-3) / 1e12
+            out[key] = {"avg_ms": round(avg, 4), "launches": len(ms), "achieved": round(tf, 2),
+                        "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4), "flop_per_sample": flops[key]}
+        return out
+
+
+def git_head():
+    try:
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True,
+                              text=True, timeout=10).stdout.strip() or None
+    except Exception:
+        return None
+
+
+def traffic_of(kernel_name, args):
+    """HBM bytes per launch of `kernel_name` from the committed PMC passes (rocprofv3 cannot run
+    inside this process).  Returns (bytes | None, provenance)."""
+    path = os.path.join(ROOT, TRAFFIC_PROFILE)
+    source = {"file": TRAFFIC_PROFILE, "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE "
+              "in separate passes over this bench.py; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
+              "(gfx950 FETCH_SIZE correction, MI355X_MICROARCH.md section HBM)"}
+    if not os.path.exists(path):
+        fallback = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+        if not os.path.exists(fallback):
+            return None, None
+        path, source["file"] = fallback, "profiles/r01_hbm_traffic.json"
+    with open(path) as f:
+        doc = json.load(f)
+    source["profiled_commit"] = doc.get("commit")
+    if doc.get("config") != {"rays": args.rays, "samples": args.samples} or args.model != "tiny":
+        return None, source
+    return doc["kernels"].get(SYMBOL_OF[kernel_name], {}).get("hbm_bytes"), source
+
+
 def target_shape_leg(device):
     """MFMA utilisation of the fused Fourier-MLP kernels at the shape BASELINE.json's target is
     stated on: full NeRF, one launch of 65 536 rays x 128 samples (synthetic positions / view
@@ -182,53 +267,152 @@ def target_shape_leg(device):
     d_logits = torch.randn((n, 4), generator=gen, device=device) / n
     saved = torch.empty((prog.saved_floats(n),), dtype=torch.float32, device=device)
     grads = torch.empty((prog.num_grad_floats,), dtype=torch.float32, device=device)
-    from fourier_feature_nets_amd import _lib as lib_mod
-    orig_call = lib_mod.call
-    spans = {}
-
-    def timed(name, *a):
-        key = {"ffn_mlp_forward": "mlp_forward_kernel<train>",
-               "ffn_mlp_backward_data": "mlp_backward_data_kernel",
-               "ffn_mlp_wgrad_units": "wgrad_unit_kernel"}.get(name)
-        if key is None:
-            return orig_call(name, *a)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        orig_call(name, *a)
-        e1.record()
-        spans.setdefault(key, []).append((e0, e1))
-
-    lib_mod.call = timed
+    timer = KernelTimer()
     try:
         for it in range(3):
             if it == 1:
-                spans.clear()
+                timer.on = True
             prog.forward(pos, view, saved)
             prog.backward(d_logits, pos, view, saved, grads)
         torch.cuda.synchronize()
     finally:
-        lib_mod.call = orig_call
-    specs = prog.layers
-    fwd = 2 * sum(sp.out * sp.ld for sp in specs)
-    flops = {"mlp_forward_kernel<train>": fwd, "wgrad_unit_kernel": fwd,
-             "mlp_backward_data_kernel": 2 * sum(sp.out * sp.act_in for sp in specs)}
-    out = {}
-    total_ms = 0.0
-    for key, pairs in spans.items():
-        ms = sum(a.elapsed_time(b) for a, b in pairs) / len(pairs)
-        total_ms += ms
-        tf = flops[key] * n / (ms * 1e-3) / 1e12
-        out[key] = {"avg_ms": round(ms, 3), "achieved": round(tf, 2),
-                    "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4), "flop_per_sample": flops[key]}
-    all_flops = sum(flops.values()) * n
+        timer.close()
+    kernels = timer.summary(prog, n)
+    total_ms = sum(k["avg_ms"] for k in kernels.values())
+    all_flops = sum(k["flop_per_sample"] for k in kernels.values()) * n
     del saved, pos, view, d_logits
+    prog._workspaces.clear()
     torch.cuda.empty_cache()
+    tf = all_flops / (total_ms * 1e-3) / 1e12
     return {"workload": "NeRF(8,256,9,10,3,4,[4],True), one launch of 65536 rays x 128 samples "
                         "(fused Fourier-MLP kernels only)",
-            "kernels": out, "mlp_ms": round(total_ms, 3),
-            "achieved": round(all_flops / (total_ms * 1e-3) / 1e12, 2),
-            "frac": round(all_flops / (total_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
-            "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "dtype": "f32"}
+            "kernels": kernels, "mlp_ms": round(total_ms, 3), "achieved": round(tf, 2),
+            "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4), "peak": F32_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "dtype": "f32"}
+
+
+def config3_leg(device, cams, images, bounds, rays_per_step=65536, steps=3):
+    """BASELINE configs[2] at full size, driver-visible: one complete optimisation step of the
+    full NeRF (8x256 trunk, skip, sigma head, bottleneck, view branch) with S = 128 = 64
+    stratified uniform + 64 opacity-guided samples per ray, the coarse model (a tiny NeRF)
+    evaluated LIVE on the batch's 64 probe points per ray (no CDF table), 65 536 rays; plus
+    frames/sec of the same model through the fused render kernel."""
+    import fourier_feature_nets_amd as ffn
+    torch.cuda.empty_cache()
+    torch.manual_seed(20080524)
+    fine = ffn.NeRF(8, 256, 9, 10, 3, 4, [4], True).to(device)
+    coarse = ffn.PositionalFourierMLP(3, 4, 5.5).to(device)
+    t0 = time.perf_counter()
+    with contextlib.redirect_stdout(io.StringIO()):
+        dataset = ffn.ImageDataset("train", images, bounds, cams, 128, True, True, coarse, 4096,
+                                   anneal_start=0.2, num_anneal_steps=2000, device=device,
+                                   focus_mode="live")
+    torch.cuda.synchronize()
+    startup_s = time.perf_counter() - t0
+    assert dataset.sampler.cdfs is None
+    engine = ffn.TrainEngine(fine, 0.0, None)
+    valid_ids = torch.nonzero(dataset.sampler.valid != 0).flatten()
+    gen = torch.Generator(device=device).manual_seed(4321)
+    prog = fine.program()
+    coarse_events = []
+    sampler = dataset.sampler
+    live_rows = sampler._live_cdf_rows
+    timer = KernelTimer()
+
+    def timed_rows(index):
+        # the coarse pass runs the same entry points as the fine model: keep it out of the
+        # fine model's kernel timers and time it as one span
+        was_on, timer.on = timer.on, False
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = live_rows(index)
+        e1.record()
+        timer.on = was_on
+        if was_on:
+            coarse_events.append((e0, e1))
+        return out
+
+    sampler._live_cdf_rows = timed_rows
+    try:
+        def run_step(step):
+            pick = torch.randint(0, valid_ids.numel(), (rays_per_step,), device=device, generator=gen)
+            return engine.train_step(dataset, valid_ids[pick], step, 5e-4 * 0.1 ** (step / 250000))
+
+        run_step(0)
+        torch.cuda.synchronize()
+        timer.on = True
+        t0 = time.perf_counter()
+        for step in range(1, 1 + steps):
+            loss = run_step(step)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        timer.on = False
+        engine.check_finite()
+        fine_kernels = timer.summary(prog, rays_per_step * 128)
+    finally:
+        timer.close()
+        sampler._live_cdf_rows = live_rows
+    coarse_ms = sum(a.elapsed_time(b) for a, b in coarse_events) / max(len(coarse_events), 1)
+    step_ms = 1e3 * elapsed / steps
+    mlp_ms = sum(k["avg_ms"] for k in fine_kernels.values())
+    flop = sum(k["flop_per_sample"] for k in fine_kernels.values()) * rays_per_step * 128
+    out = {"workload": "lego_400-shaped full NeRF train step: NeRF(8,256,9,10,3,4,[4],True), "
+                       "S = 128 = 64 stratified uniform + 64 opacity-guided samples, live coarse "
+                       "model PositionalFourierMLP(3,4,5.5) on 64 probe points per ray, %d rays/step, "
+                       "100 cams x 400x400, exact-f32 MFMA" % rays_per_step,
+           "step_ms": round(step_ms, 2), "rays_per_s": round(rays_per_step / (step_ms * 1e-3), 1),
+           "steps": steps, "final_loss": float(loss), "sampler_startup_s": round(startup_s, 3),
+           "cdf_table_bytes": 0, "coarse_pass_ms": round(coarse_ms, 3),
+           "fine_mlp_ms": round(mlp_ms, 3), "kernels": fine_kernels,
+           "fine_mlp_frac_of_f32_mfma_peak": round(flop / (mlp_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+           "whole_step_frac_of_f32_mfma_peak": round(flop / (step_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)}
+    del engine
+    prog._workspaces.clear()
+    torch.cuda.empty_cache()
+    # frames/sec of the full NeRF, 128 samples/ray, fused render (a plain uniform sampler like
+    # orbit_video without an opacity model: every pixel ray of the frame)
+    caster = ffn.Raycaster(fine)
+    with contextlib.redirect_stdout(io.StringIO()):
+        orbit = ffn.RaySampler(bounds, cams[:2], 128, device=device)
+    caster.render_image_device(orbit, 0, 32768)
+    torch.cuda.synchronize()
+    r0 = time.perf_counter()
+    for f in range(2):
+        caster.render_image_device(orbit, f, 32768)
+    torch.cuda.synchronize()
+    out["render_fps_400x400_128_samples"] = round(2 / (time.perf_counter() - r0), 3)
+    caster.check_finite()
+    return out
+
+
+def render_leg(args, caster, sampler, world, rank, barrier):
+    """frames/sec of 400x400 renders through the fused kernel: kernels only (frames stay on the
+    GPU), with the synchronous D2H copy of each frame (what render_image returns to a caller),
+    and with asynchronous copy-out + PNG encoding (FrameSink)."""
+    import fourier_feature_nets_amd as ffn
+    frames = [f for f in range(8 * world) if f % world == rank]
+    caster.render_image(sampler, frames[0], 32768)
+    out = {}
+    for mode in ("device", "host", "png"):
+        torch.cuda.synchronize()
+        barrier()
+        r0 = time.perf_counter()
+        if mode == "device":
+            for f in frames:
+                caster.render_image_device(sampler, f, 32768)
+        elif mode == "host":
+            for f in frames:
+                caster.render_image(sampler, f, 32768)
+        else:
+            with tempfile.TemporaryDirectory() as tmp, ffn.FrameSink() as sink:
+                for f in frames:
+                    sink.submit(caster.render_image_device(sampler, f, 32768),
+                                os.path.join(tmp, "frame_%05d.png" % f))
+        torch.cuda.synchronize()
+        barrier()
+        out[mode] = 8 * world / (time.perf_counter() - r0)
+    caster.check_finite()
+    return out
 
 
 def spawn_ranks(args):
@@ -238,7 +422,6 @@ def spawn_ranks(args):
     FFN_BENCH_SHARE_GPU=1 (all ranks on cuda:0 over gloo: a functional check of the sharding /
     reduction / timing code on a one-GPU box, never a measurement)."""
     import socket
-    import subprocess
     visible = torch.cuda.device_count()
     env = dict(os.environ)
     if visible < args.gpus:
@@ -264,8 +447,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible and there is no CPU fallback")
-    # FFN_BENCH_SHARE_GPU=1 (with FFN_BENCH_BACKEND=gloo): all ranks on cuda:0 -- a functional
-    # check of the N > 1 path on a one-GPU box, not a measurement
+    # FFN_BENCH_SHARE_GPU=1 (gloo): all ranks on cuda:0 -- a functional check of the N > 1 path
+    # on a one-GPU box, not a measurement
     shared_gpu = os.environ.get("FFN_BENCH_SHARE_GPU") == "1"
     if shared_gpu:
         local_rank = 0
@@ -273,11 +456,11 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     group = None
+    backend = os.environ.get("FFN_BENCH_BACKEND", "nccl")
     if world > 1 or "RANK" in os.environ:      # under torch.distributed.run: RCCL even for 1 rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        backend = os.environ.get("FFN_BENCH_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
@@ -288,10 +471,7 @@ def main():
                          "torch.distributed.run --nproc-per-node == --gpus, or without a launcher)"
                          % (args.gpus, world))
 
-    import contextlib
-    import io
     import fourier_feature_nets_amd as ffn
-    from fourier_feature_nets_amd import ops
 
     torch.manual_seed(20080524)
     if args.model == "nerf":
@@ -304,8 +484,7 @@ def main():
     cams = [ffn.CameraInfo.create("train%03d" % i, ffn.Resolution(args.size, args.size), intr, p)
             for i, p in enumerate(poses)]
     bounds = np.diag([2, 2, 2, 1]).astype(np.float32)
-    quiet = io.StringIO()
-    with contextlib.redirect_stdout(quiet):
+    with contextlib.redirect_stdout(io.StringIO()):
         probe = ffn.RaySampler(bounds, cams, args.samples, device=device)
         images = analytic_images(probe)
         del probe
@@ -321,25 +500,7 @@ def main():
     global_batch = args.rays * world
     prog = model.program()
     n_samples = args.rays * args.samples
-
-    # per-kernel timing with events on the launch stream
-    timers = {"fwd": [], "dgrad": [], "wgrad": []}
-    from fourier_feature_nets_amd import _lib as lib_mod
-    orig_call = lib_mod.call
-
-    def timed_call(name, *a):
-        key = {"ffn_mlp_forward": "fwd", "ffn_mlp_backward_data": "dgrad",
-               "ffn_mlp_wgrad_units": "wgrad"}.get(name)
-        if key is None or not timed_call.on:
-            return orig_call(name, *a)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        orig_call(name, *a)
-        e1.record()
-        timers[key].append((e0, e1))
-
-    timed_call.on = False
-    lib_mod.call = timed_call
+    timer = KernelTimer()
 
     def run_step(step):
         pick = torch.randint(0, valid_ids.numel(), (global_batch,), device=device, generator=gen)
@@ -357,7 +518,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
-    timed_call.on = True
+    timer.on = True
     if engine.collective_events is not None:
         engine.collective_events.clear()
     t0 = time.perf_counter()
@@ -368,22 +529,14 @@ def main():
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    timed_call.on = False
+    timer.on = False
+    timer.close()
     engine.check_finite()
+    kernels = timer.summary(prog, n_samples)
 
     # ---- render leg: 400x400 frames of the first cameras (replicas only: frame f -> rank f%world)
     caster = ffn.Raycaster(model)
-    frames = [] if args.no_render else [f for f in range(8 * world) if f % world == rank]
-    for f in frames[:1]:
-        caster.render_image(dataset.sampler, f, 32768)
-    torch.cuda.synchronize()
-    barrier()
-    r0 = time.perf_counter()
-    for f in frames:
-        caster.render_image(dataset.sampler, f, 32768)
-    torch.cuda.synchronize()
-    barrier()
-    render_s = time.perf_counter() - r0
+    render = None if args.no_render else render_leg(args, caster, dataset.sampler, world, rank, barrier)
     if group is not None:
         import torch.distributed as dist
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -391,35 +544,12 @@ def main():
         elapsed = float(tmax.item())
 
     if rank == 0:
-        specs = prog.layers
-        fwd_flops = 2 * sum(sp.out * sp.ld for sp in specs)
-        dgrad_flops = 2 * sum(sp.out * sp.act_in for sp in specs)      # no dgrad into encodings
-        flops = {"fwd": fwd_flops, "dgrad": dgrad_flops, "wgrad": fwd_flops}
-        kernels = {}
-        for key, pairs in timers.items():
-            if not pairs:
-                continue
-            ms = [a.elapsed_time(b) for a, b in pairs]
-            avg = sum(ms) / max(len(ms), 1)
-            achieved = flops[key] * n_samples / (avg * 1e-3) / 1e12 if avg > 0 else 0.0
-            kernels[key] = {"avg_ms": round(avg, 4), "launches": len(ms),
-                            "achieved": round(achieved, 2),
-                            "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
-                            "flop_per_sample": flops[key]}
         dominant = max(kernels, key=lambda k: kernels[k]["avg_ms"])
-        # HBM bytes per launch from the PMC passes committed under profiles/ (same workload)
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-        symbol = {"fwd": "ffn::mlp_forward_kernel<1, false>",
-                  "dgrad": "ffn::mlp_backward_data_kernel<false>",
-                  "wgrad": "ffn::wgrad_unit_kernel"}
-        if os.path.exists(tpath):
-            with open(tpath) as f:
-                tdata = json.load(f)
-            if tdata["config"] == {"rays": args.rays, "samples": args.samples} and args.model == "tiny":
-                traffic = tdata["kernels"].get(symbol[dominant], {}).get("hbm_bytes")
-        names = {"fwd": "mlp_forward_kernel<train>", "dgrad": "mlp_backward_data_kernel",
-                 "wgrad": "wgrad_unit_kernel"}
+        traffic, traffic_source = traffic_of(dominant, args)
+        label = {"tiny": ("tiny NeRF", "PositionalFourierMLP(3,4,5.5) 256ch"),
+                 "nerf": ("full NeRF", "NeRF(8,256,9,10,3,4,[4],True)"),
+                 "gaussian512": ("512-wide Gaussian-feature",
+                                 "GaussianFourierMLP(3,4,10.0,num_channels=512)")}[args.model]
         result = {
             "metric": "rays/sec (train)",
             "value": global_batch * args.steps / elapsed,
@@ -435,30 +565,31 @@ def main():
             "data": "synthetic",
             "config": {"workload": "antinous_400-shaped %s train step: %d cams x %dx%d, %s, "
                                    "%d samples/ray, %d rays/GPU/step, exact-f32 MFMA"
-                                   % ({"tiny": "tiny NeRF", "nerf": "full NeRF",
-                                       "gaussian512": "512-wide Gaussian-feature"}[args.model],
-                                      args.cameras, args.size, args.size,
-                                      {"tiny": "PositionalFourierMLP(3,4,5.5) 256ch",
-                                       "nerf": "NeRF(8,256,9,10,3,4,[4],True)",
-                                       "gaussian512": "GaussianFourierMLP(3,4,10.0,num_channels=512)"}[args.model],
+                                   % (label[0], args.cameras, args.size, args.size, label[1],
                                       args.samples, args.rays),
                        "rays_per_gpu": args.rays, "samples_per_ray": args.samples,
-                       "parallelism": "dp%d" % world, "final_loss": float(loss)},
-            "roofline": {"bound": "mfma", "kernel": names[dominant],
+                       "parallelism": "dp%d" % world, "final_loss": float(loss),
+                       "commit": git_head()},
+            "roofline": {"bound": "mfma", "kernel": dominant,
                          "achieved": kernels[dominant]["achieved"],
                          "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": kernels[dominant]["frac"], "traffic": traffic,
+                         "traffic_source": traffic_source,
                          "algorithmic_flop_per_launch": kernels[dominant]["flop_per_sample"] * n_samples},
-            "kernels": {names[k]: v for k, v in kernels.items()},
-            "render": None if args.no_render else {
-                       "metric": "frames/sec %dx%d render" % (args.size, args.size),
-                       "value": 8 * world / render_s, "frames": 8 * world,
-                       "samples_per_ray": args.samples, "includes": "sampling, fused MLP, "
-                       "composite, u8 assembly and the D2H copy of each frame"},
+            "kernels": kernels,
+            "render": None if render is None else {
+                "metric": "frames/sec %dx%d render" % (args.size, args.size),
+                "value": render["host"], "frames": 8 * world, "samples_per_ray": args.samples,
+                "path": "fused render kernel: one launch per frame (sampling + encoding + MLP + "
+                        "compositing + u8 pixels)",
+                "kernels_only_fps": render["device"],
+                "with_sync_d2h_fps": render["host"],
+                "with_async_d2h_and_png_fps": render["png"],
+                "includes": "value = with_sync_d2h_fps: every frame copied to the host before the "
+                            "next one starts (what Raycaster.render_image returns)"},
         }
         if engine.collective_events:
             us = [1e3 * a.elapsed_time(b) for a, b in engine.collective_events]
-            backend = os.environ.get("FFN_BENCH_BACKEND", "nccl")
             result["collective"] = {
                 "op": "all_reduce(sum) of [flat gradients | 2 loss sums], one per step",
                 "backend": "rccl" if backend == "nccl" else backend + " (host-staged)",
@@ -468,13 +599,16 @@ def main():
                 "shared_gpu": shared_gpu}
         else:
             result["collective"] = None
-        result["north_star_shape"] = None if (args.no_target_shape or args.model != "tiny") \
-            else target_shape_leg(device)
-        if not args.no_cpu_baseline and world == 1 and args.model == "tiny":
-            state = {k: v.detach() for k, v in model.state_dict().items()}
-            result["cpu_baseline"] = cpu_baseline(args, state, None)
-        else:
-            result["cpu_baseline"] = None
+        solo = world == 1 and args.model == "tiny"
+        state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        # free the headline leg's buffers before the large reporting-only legs
+        del engine, caster
+        prog._workspaces.clear()
+        torch.cuda.empty_cache()
+        result["north_star_shape"] = target_shape_leg(device) if solo and not args.no_target_shape else None
+        result["config3_step"] = (config3_leg(device, cams, images, bounds)
+                                  if solo and not args.no_config3 and args.size == 400 else None)
+        result["cpu_baseline"] = cpu_baseline(args, state) if solo and not args.no_cpu_baseline else None
         print(json.dumps(result), flush=True)
     if group is not None:
         import torch.distributed as dist

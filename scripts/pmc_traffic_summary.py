@@ -1,6 +1,6 @@
 """Folds the two rocprofv3 PMC passes of scripts/pmc_traffic.sh into profiles/*.json:
 
-    python scripts/pmc_traffic_summary.py gpurun_out/traffic profiles/r01_hbm_traffic.json
+    python scripts/pmc_traffic_summary.py gpurun_out/traffic profiles/r02_hbm_traffic.json [commit]
 
 FETCH_SIZE / WRITE_SIZE are reported in KB per dispatch.  gfx950 correction (MI355X_MICROARCH.md,
 HBM section): FETCH_SIZE counts TCC_EA0_RDREQ x 64 B while wide streaming reads are 128-B
@@ -30,7 +30,7 @@ def per_kernel(path, counter):
     return acc
 
 
-def main(src, out, rays=65536, samples=64):
+def main(src, out, commit=None, rays=65536, samples=64):
     fetch = per_kernel(src + "/fetch_counter_collection.csv", "FETCH_SIZE")
     write = per_kernel(src + "/write_counter_collection.csv", "WRITE_SIZE")
     kernels = collections.OrderedDict()
@@ -46,11 +46,11 @@ def main(src, out, rays=65536, samples=64):
                    "KB per launch averaged over launches; hbm_bytes = (2*FETCH_SIZE + "
                    "WRITE_SIZE)*1024 (gfx950: FETCH_SIZE counts 128-B requests as 64 B for wide "
                    "streaming reads, MI355X_MICROARCH.md section HBM)",
-           "config": {"rays": rays, "samples": samples}, "kernels": kernels}
+           "commit": commit, "config": {"rays": rays, "samples": samples}, "kernels": kernels}
     with open(out, "w") as f:
         json.dump(doc, f, indent=1)
     print("wrote", out, len(kernels), "kernels")
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else None)
