@@ -3,9 +3,15 @@ JSON (mean of each counter over the launches of every ffn:: kernel, plus mean du
 
     python scripts/pmc_counter_summary.py in_counter_collection.csv out.json "note" [commit]
 
-Derived ratios (when the counters are present): mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES /
-SQ_BUSY_CYCLES (both in cycles, summed over the SQs that were busy), valu_inst_per_mfma_inst,
-lds_conflict_frac = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE or / SQ_WAVE_CYCLES*4.
+Derived ratios (when the counters are present):
+  mfma_busy_frac = (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs) / (SQ_BUSY_CYCLES / 32 shader engines):
+      the share of the kernel's busy cycles in which a SIMD's matrix pipe is executing.  The
+      normalisation is checked on the data itself: MFMA_BUSY / 1024 equals SQ_INSTS_MFMA / 1024 x 64
+      cycles for v_mfma_f32_32x32x2_f32, and SQ_BUSY / 32 / duration gives a 2.1-2.2 GHz clock.
+  effective_clock_ghz = SQ_BUSY_CYCLES / 32 / duration
+  valu_insts_per_mfma_inst = (SQ_INSTS_VALU - SQ_INSTS_MFMA) / SQ_INSTS_MFMA
+  *_frac_of_wave_cycles: SQ_ACTIVE_INST_VALU, SQ_WAIT_INST_ANY, SQ_WAIT_ANY over SQ_WAVE_CYCLES
+  lds_bank_conflict: SQ_LDS_BANK_CONFLICT cycles over 4 x SQ_WAVE_CYCLES (quad-cycles)
 """
 
 import collections
@@ -35,7 +41,11 @@ def main(src, out, note, commit=None):
         entry = {"launches": n, "avg_us_under_pmc": round(sum(k["ns"].values()) / n / 1e3, 1),
                  "counters": {c: round(v, 1) for c, v in mean.items()}}
         if mean.get("SQ_BUSY_CYCLES") and "SQ_VALU_MFMA_BUSY_CYCLES" in mean:
-            entry["mfma_busy_frac"] = round(mean["SQ_VALU_MFMA_BUSY_CYCLES"] / mean["SQ_BUSY_CYCLES"], 4)
+            entry["mfma_busy_frac"] = round((mean["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024) /
+                                            (mean["SQ_BUSY_CYCLES"] / 32), 4)
+        if mean.get("SQ_BUSY_CYCLES"):
+            entry["effective_clock_ghz"] = round(mean["SQ_BUSY_CYCLES"] / 32 /
+                                                 (sum(k["ns"].values()) / n), 3)
         if mean.get("SQ_INSTS_MFMA") and "SQ_INSTS_VALU" in mean:
             entry["valu_insts_per_mfma_inst"] = round(
                 (mean["SQ_INSTS_VALU"] - mean["SQ_INSTS_MFMA"]) / mean["SQ_INSTS_MFMA"], 4)
@@ -45,6 +55,8 @@ def main(src, out, note, commit=None):
         if mean.get("SQ_WAVE_CYCLES") and "SQ_WAIT_INST_ANY" in mean:
             entry["issue_stall_frac_of_wave_cycles"] = round(
                 mean["SQ_WAIT_INST_ANY"] / mean["SQ_WAVE_CYCLES"], 4)
+        if mean.get("SQ_WAVE_CYCLES") and "SQ_WAIT_ANY" in mean:
+            entry["wait_any_frac_of_wave_cycles"] = round(mean["SQ_WAIT_ANY"] / mean["SQ_WAVE_CYCLES"], 4)
         if mean.get("SQ_WAVE_CYCLES") and "SQ_LDS_BANK_CONFLICT" in mean:
             # SQ_LDS_BANK_CONFLICT counts cycles, SQ_WAVE_CYCLES quad-cycles (MI355X_MICROARCH.md)
             entry["lds_bank_conflict_frac_of_wave_cycles"] = round(
