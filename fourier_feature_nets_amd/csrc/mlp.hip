@@ -245,7 +245,14 @@ __device__ __forceinline__ void team_barrier() {
     __builtin_amdgcn_s_barrier();
 }
 
-template <int OT, int MODE, bool WIDE>
+// FLAV specialises the epilogue on the step's (wave-uniform) flavour, so that its flags are not
+// tested inside the unrolled tile loop (each runtime flag there is a scalar branch per channel
+// quad: 3-4 fetch bubbles x 32 quads per step, in a loop with ~25 instructions per quad):
+//   0 generic (flags read from the step at run time -- the narrow tile counts)
+//   1 slab destination, no fused head, no output save   (hidden layers; dgrad steps)
+//   2 slab destination, output saved                    (forward: fused head + save; dgrad: last step)
+//   3 slab destination, fused head, no save             (forward inference)
+template <int OT, int MODE, bool WIDE, int FLAV>
 __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step& L,
                                          const ffn_step* next, WaveCtx& w,
                                          const float* __restrict__ packed_w,
@@ -400,7 +407,10 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
     if (MODE != kInfer && L.save_out_slot >= 0 && w.active) save_out = slab_block(ch, slab_out, L.save_out_slot, w);
     // fused logits head: this lane holds channels 8*group + 4h + p of its sample; their
     // products with the head's rows accumulate per lane, the partial sums meet at the end
-    const bool fused_head = MODE != kBackward && L.head_off >= 0;
+    const bool fused_head = FLAV == 0 ? (MODE != kBackward && L.head_off >= 0)
+                                      : (MODE != kBackward && FLAV >= 2);
+    const bool to_slab = FLAV == 0 ? L.dst == 0 : true;
+    const bool save_y = FLAV == 0 ? save_out != nullptr : FLAV == 2;
     const float* hw = w.bias_lds + (fused_head ? L.head_off : 0) + 4 + 16 * w.h;
     if (fused_head && w.h == 0 && half == 0) {
         const f32x4 hb = *reinterpret_cast<const f32x4*>(w.bias_lds + L.head_off);
@@ -409,6 +419,11 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
     }
     if (WIDE) team_barrier();        // every K loop of this step has finished reading the slab
     unsigned sign_bits[4] = {0u, 0u, 0u, 0u};
+    // ReLU as a signed-integer max on the bit pattern: floats below +0 (and -0) are negative
+    // integers, so max(bits, 0) is relu(t) in ONE instruction -- fmaxf costs three here (IEEE
+    // canonicalisation of the input, the max, a select on the runtime relu flag); a step
+    // without ReLU uses the floor INT_MIN (identity).
+    const int relu_floor = L.relu ? 0 : (int)0x80000000;
 #pragma unroll
     for (int o = 0; o < 8; ++o) {
         if (o < ot_next) {               // (uniform) the next step may have more tiles than this one
@@ -427,11 +442,22 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
                     // (a word that received a single tile -- OT == 1 -- was shifted 16 times only)
                     const int filled = ((OT & 1) && o == OT - 1) ? 16 : 32;
                     const int bit = filled - 1 - (16 * (o & 1) + 4 * q + p);
-                    y[p] = ((word >> bit) & 1u) ? acc[o][4 * q + p] : 0.0f;
+                    // all-ones / zero from the mask bit (one v_bfe_i32), then one v_and
+                    const int keep = ((int)(word << (31 - bit))) >> 31;
+                    const float a = acc[o][4 * q + p];     // (a scalar copy: bit_cast of a vector
+                    y[p] = __builtin_bit_cast(float, __builtin_bit_cast(int, a) & keep);   // element reads lane 0)
                 }
                 w.act[group * 64 + w.lane] = y;
-                if (save_out != nullptr) save_out[saved_index(2 * group + w.h, w.s)] = y;
+                if (save_y) save_out[saved_index(2 * group + w.h, w.s)] = y;
             } else {
+                // fused head: this quad's four weight rows are requested BEFORE its ReLU / sign-bit
+                // work and its slab write (which the compiler must keep them ordered against), so
+                // that work covers the LDS latency instead of a wait in front of the FMAs
+                f32x4 hw4[4];
+                if (fused_head) {
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) hw4[p] = *reinterpret_cast<const f32x4*>(hw + group * 32 + p * 4);
+                }
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
                     float t = acc[o][4 * q + p];
@@ -440,19 +466,17 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
                     if (MODE == kTrainFwd)
                         sign_bits[o >> 1] = __builtin_amdgcn_alignbit(sign_bits[o >> 1],
                                                                       __builtin_bit_cast(unsigned, 0.0f - t), 31);
-                    if (L.relu) t = __builtin_fmaxf(t, 0.0f);
-                    y[p] = t;
+                    y[p] = __builtin_bit_cast(float, __builtin_elementwise_max(__builtin_bit_cast(int, t), relu_floor));
                 }
-                if (L.dst == 0) {
+                if (to_slab) {
                     w.act[group * 64 + w.lane] = y;
                     if (fused_head) {
 #pragma unroll
                         for (int p = 0; p < 4; ++p) {
-                            const f32x4 w4 = *reinterpret_cast<const f32x4*>(hw + group * 32 + p * 4);
 #pragma unroll
-                            for (int c = 0; c < 4; ++c) w.logit[c] = __builtin_fmaf(y[p], w4[c], w.logit[c]);
+                            for (int c = 0; c < 4; ++c) w.logit[c] = __builtin_fmaf(y[p], hw4[p][c], w.logit[c]);
                         }
-                        if (MODE == kTrainFwd && save_out != nullptr) save_out[saved_index(2 * group + w.h, w.s)] = y;
+                        if (MODE == kTrainFwd && save_y) save_out[saved_index(2 * group + w.h, w.s)] = y;
                     }
                 } else if (!WIDE && o == 0 && q == 0) {
                     // real outputs = rows 0..out_n-1 of tile 0 = registers 0..3 of h == 0
@@ -493,12 +517,22 @@ __device__ __forceinline__ void run_chain(const ffn_mlp_chain& ch, WaveCtx& w,
     for (int li = 0; li < ch.num_steps; ++li) {
         const ffn_step& L = ch.step[li];
         const ffn_step* next = li + 1 < ch.num_steps ? &ch.step[li + 1] : nullptr;
-        switch (L.out_tiles / TW) {
-            case 8: run_step<8, MODE, WIDE>(ch, L, next, w, packed_w, pre, slab_out); break;
-            case 4: run_step<4, MODE, WIDE>(ch, L, next, w, packed_w, pre, slab_out); break;
-            case 2: run_step<2, MODE, WIDE>(ch, L, next, w, packed_w, pre, slab_out); break;
-            default: run_step<1, MODE, WIDE>(ch, L, next, w, packed_w, pre, slab_out); break;
-        }
+        const int ot = L.out_tiles / TW;
+        if (ot == 8) {
+            // the 256-channel steps (all the time of every supported model) get a specialised
+            // epilogue; the flavour is a property of the step, known before its K loops start.
+            // (Only as many specialisations as the register allocator digests: every inlined
+            // copy of run_step shares the kernel's 512 registers.)
+            const bool saves = MODE != kInfer && L.save_out_slot >= 0 && w.active;
+            const bool head = MODE != kBackward && L.head_off >= 0;
+            if (MODE == kBackward) {
+                if (saves) run_step<8, MODE, WIDE, 2>(ch, L, next, w, packed_w, pre, slab_out);
+                else run_step<8, MODE, WIDE, 1>(ch, L, next, w, packed_w, pre, slab_out);
+            } else if (!head && L.dst == 0) run_step<8, MODE, WIDE, 1>(ch, L, next, w, packed_w, pre, slab_out);
+            else run_step<8, MODE, WIDE, 0>(ch, L, next, w, packed_w, pre, slab_out);
+        } else if (ot == 4) run_step<4, MODE, WIDE, 0>(ch, L, next, w, packed_w, pre, slab_out);
+        else if (ot == 2) run_step<2, MODE, WIDE, 0>(ch, L, next, w, packed_w, pre, slab_out);
+        else run_step<1, MODE, WIDE, 0>(ch, L, next, w, packed_w, pre, slab_out);
     }
 }
 

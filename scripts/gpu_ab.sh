@@ -1,0 +1,14 @@
+# A/B on ONE box: baseline library (scripts/probes/variants/libffn_base.so) vs the current build,
+# interleaved twice (clocks drift between boxes by several percent, so never compare across calls)
+mkdir -p gpurun_out/ab
+for rep in 1 2; do
+  for lib in base new; do
+    if [ $lib = base ]; then export FFN_HIP_LIBRARY=$PWD/scripts/probes/variants/libffn_base.so; else unset FFN_HIP_LIBRARY; fi
+    python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-config3 --no-target-shape --no-render > gpurun_out/ab/${lib}_${rep}.json 2> gpurun_out/ab/${lib}_${rep}.err
+    python - <<PY
+import json
+b = json.loads(open("gpurun_out/ab/${lib}_${rep}.json").read().strip().split("\n")[-1])
+print("${lib} ${rep}", round(b["ms_per_step"], 3), {k.split("_kernel")[0]: v["avg_ms"] for k, v in b["kernels"].items()})
+PY
+  done
+done

@@ -29,12 +29,16 @@ def instrument(mode):
     head = "    f32x16 acc[OT];\n    if (MODE == kBackward) {"
     s = sub(s, head, "    const bool dbg_on = blockIdx.x == 3 && (threadIdx.x >> 6) == 1 && w.block < 3 * 1024 + 16;\n    "
             + STAMP % "" + "\n" + head)
-    kloops_done = "    // ---- next step's first weight group rides under this step's epilogue -----------"
+    kloops_done = "    const int ot_next = next != nullptr ? next->out_tiles / TW : 0;"
     s = sub(s, kloops_done, "    " + STAMP % "" + "\n" + kloops_done)
     end = "    if (WIDE) team_barrier();        // the step's output is in the slab\n}"
     if mode == "steps":
         seg = "        const f32x4* xa = w.act + w.lane;\n        x0 = xa[0];"
         s = sub(s, seg, "        " + STAMP % "-" + "\n" + seg)      # negative = a K loop starts
+        s = sub(s, end, "    " + STAMP % "" + "\n}")
+    elif mode == "tiles":          # one stamp per output tile of the epilogue loop
+        tile = "        if (o >= OT) continue;\n"
+        s = sub(s, tile, tile + "        " + STAMP % "" + "\n")
         s = sub(s, end, "    " + STAMP % "" + "\n}")
     else:
         init_done = "    const f32x4* wp = reinterpret_cast<const f32x4*>(packed_w + L.w_off) + half * OT * 64;   // uniform"
@@ -58,7 +62,7 @@ extern "C" int ffn_dbg_read(long long* out, int reset) {
 
 def main():
     mode = sys.argv[1] if len(sys.argv) > 1 else "steps"
-    assert mode in ("steps", "epilogue")
+    assert mode in ("steps", "epilogue", "tiles")
     os.makedirs(OUT, exist_ok=True)
     src = os.path.join(OUT, "mlp_dbg.hip")
     with open(src, "w") as f:
