@@ -92,6 +92,12 @@ class TrainEngine:
             # a gloo group (CPU tests, several ranks sharing one GPU) reduces through the host
             self._host_staged = dist.get_backend(process_group) == "gloo"
         self.collective_events = None     # set to [] to record (start, end) events per all-reduce
+        # OPT-IN empty-space skipping during training (BASELINE config 5; no counterpart in the
+        # reference): with an OccupancyGrid here, the MLP forward / backward run only on the
+        # samples in occupied cells; the others are treated as sigma = 0 constants (no colour, no
+        # gradient).  New semantics -- PSNR-level parity with the full step, never the default.
+        self.occupancy = None
+        self.last_evaluated_fraction = None   # device scalar-free diagnostic: M / N of the last launch
         self._saved = {}
         self.loss_history = None          # set to [] to record every step's loss (device scalars)
         model.invalidate_packed()
@@ -144,19 +150,31 @@ class TrainEngine:
             chunk = rays[lo:lo + per_launch]
             first = lo == 0
             t, pos, views = self._samples(sampler, chunk, step)
-            saved = self._saved_buffer(prog, pos.shape[0])
-            logits = prog.forward(pos, views, saved)
+            index = None
+            if self.occupancy is not None:
+                # compaction (one D2H sync for the count), MLP on the occupied samples only
+                total = pos.shape[0]
+                pos, views, index = self.occupancy.compact(pos, views)
+                self.last_evaluated_fraction = pos.shape[0] / max(total, 1)
+                saved = self._saved_buffer(prog, max(pos.shape[0], 1))
+                packed = prog.forward(pos, views, saved)
+                logits = ops.scatter_logits(packed, index, total)
+            else:
+                saved = self._saved_buffer(prog, pos.shape[0])
+                logits = prog.forward(pos, views, saved)
             color, alpha, _ = ops.composite_fwd(logits, t, False, self.nan_flag)
             part, d_color, d_alpha = ops.mse_loss(color, alpha, dataset.colors, alphas, chunk,
                                                   1.0 / (3 * global_count), aw / global_count,
                                                   sums_out=sums if first else None)
-            d_logits = ops.composite_bwd(logits, t, d_color, d_alpha)
+            d_logits = ops.composite_bwd(logits, t, d_color, d_alpha).view(-1, 4)
+            if index is not None:
+                d_logits = ops.gather_logits(d_logits, index)
             if first:
-                prog.backward(d_logits.view(-1, 4), pos, views, saved, self.grads)
+                prog.backward(d_logits, pos, views, saved, self.grads)
             else:
                 if getattr(self, "_grads_part", None) is None:
                     self._grads_part = torch.empty_like(self.grads)
-                prog.backward(d_logits.view(-1, 4), pos, views, saved, self._grads_part)
+                prog.backward(d_logits, pos, views, saved, self._grads_part)
                 self.grads.add_(self._grads_part)
                 sums.add_(part)
         if self.group is not None:

@@ -151,6 +151,15 @@ scatter_logits_kernel(const float4* __restrict__ packed, const int32_t* __restri
         out[index[i]] = packed[i];
 }
 
+// K9g: the inverse of the scatter for the backward pass -- d_logits rows of the evaluated samples
+__global__ void __launch_bounds__(256)
+gather_logits_kernel(const float4* __restrict__ full, const int32_t* __restrict__ index, int64_t m,
+                     float4* __restrict__ packed) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m;
+         i += (int64_t)gridDim.x * blockDim.x)
+        packed[i] = full[index[i]];
+}
+
 }  // namespace ffn
 
 using namespace ffn;
@@ -217,6 +226,15 @@ extern "C" int ffn_scatter_logits(const float* packed, const int32_t* index, int
         hipLaunchKernelGGL(scatter_logits_kernel, dim3(stream_grid(m)), dim3(256), 0, st,
                            (const float4*)packed, index, m, (float4*)out);
     return check_launch("ffn_scatter_logits");
+}
+
+extern "C" int ffn_gather_logits(const float* full, const int32_t* index, int64_t m, float* packed,
+                                 void* stream) {
+    if (m < 0) return fail_arg("ffn_gather_logits: shape");
+    if (m == 0) return 0;
+    hipLaunchKernelGGL(gather_logits_kernel, dim3(stream_grid(m)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)full, index, m, (float4*)packed);
+    return check_launch("ffn_gather_logits");
 }
 
 // ---------------------------------------------------------------------------------- K10

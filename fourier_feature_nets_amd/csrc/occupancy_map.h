@@ -11,13 +11,18 @@ struct GridMap {
     int G;
 };
 
-// samples outside the box are kept (the reference evaluates them too)
+// A sample outside the box takes the occupancy of the nearest cell (clamped indices): rays are
+// sampled between their entry and exit points of this same box, so "outside" only happens by
+// rounding on a face -- and a rule that kept such samples would make every ray evaluate its two
+// end points (one whole 32-sample block per ray in the fused render kernel).  NaN positions
+// (rays that miss the volume) count as occupied: they are filtered by ray id, not by value.
 __device__ __forceinline__ bool occupied_at(const GridMap& m, const uint32_t* __restrict__ bits,
                                             float x, float y, float z) {
     const float fx = (x - m.min0) * m.inv0, fy = (y - m.min1) * m.inv1, fz = (z - m.min2) * m.inv2;
-    const float g = (float)m.G;
-    if (!(fx >= 0.0f && fy >= 0.0f && fz >= 0.0f && fx < g && fy < g && fz < g)) return true;
-    const int ix = (int)fx, iy = (int)fy, iz = (int)fz;
+    if (!(fx == fx && fy == fy && fz == fz)) return true;
+    const float top = (float)(m.G - 1);
+    const int ix = (int)fminf(fmaxf(fx, 0.0f), top), iy = (int)fminf(fmaxf(fy, 0.0f), top),
+              iz = (int)fminf(fmaxf(fz, 0.0f), top);
     const int64_t cell = ((int64_t)iz * m.G + iy) * m.G + ix;
     return (bits[cell >> 5] >> (cell & 31)) & 1u;
 }

@@ -36,6 +36,26 @@ class OccupancyGrid:
         lo, hi = world.min(axis=0), world.max(axis=0)
         return lo, hi - lo
 
+    @staticmethod
+    def cell_centres(bounds: np.ndarray, resolution: int, device) -> torch.Tensor:
+        """(G^3,3) world positions of the cell centres, x fastest (the bit order)."""
+        lo, size = OccupancyGrid.box_of(bounds)
+        g = int(resolution)
+        axis = [torch.arange(g, dtype=torch.float32, device=device).add_(0.5).mul_(float(size[d]) / g)
+                .add_(float(lo[d])) for d in range(3)]
+        zz, yy, xx = torch.meshgrid(axis[2], axis[1], axis[0], indexing="ij")
+        return torch.stack([xx, yy, zz], dim=-1).reshape(-1, 3).contiguous()
+
+    @classmethod
+    def from_logits(cls, logits: torch.Tensor, bounds: np.ndarray, resolution: int,
+                    sigma_threshold: float = 0.01, dilate: bool = True) -> "OccupancyGrid":
+        """Grid from precomputed (G^3,4) raw outputs at ``cell_centres`` (any density source:
+        a voxelised model, an analytic scene)."""
+        lo, size = cls.box_of(bounds)
+        bits = ops.occupancy_build(logits.contiguous(), int(resolution), float(sigma_threshold),
+                                   bool(dilate))
+        return cls(bits, lo, size, int(resolution))
+
     @classmethod
     def from_model(cls, model, bounds: np.ndarray, resolution: int = 128,
                    sigma_threshold: float = 0.01, dilate: bool = True,

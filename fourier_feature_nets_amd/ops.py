@@ -269,6 +269,15 @@ def scatter_logits(packed: torch.Tensor, index: torch.Tensor, n: int,
     return out
 
 
+def gather_logits(full: torch.Tensor, index: torch.Tensor) -> torch.Tensor:
+    """K9g.  (N,4) rows at ``index`` (int32) -> (M,4)."""
+    m = index.shape[0]
+    out = torch.empty((m, 4), dtype=torch.float32, device=full.device)
+    if m > 0:
+        _call("ffn_gather_logits", _dev(full), _dev(index, torch.int32), c_i64(m), _dev(out))
+    return out
+
+
 # --------------------------------------------------------------------------------- voxels
 def voxels_forward(volume: torch.Tensor, bias: torch.Tensor, positions: torch.Tensor, side: int,
                    scale: float) -> torch.Tensor:

@@ -417,8 +417,9 @@ int64_t ffn_mlp_wgrad_partial_floats(void);
  *   occupied when softplus(sigma logit) > sigma_threshold; dilate != 0 also marks the 26
  *   neighbours (needs scratch_bits of the same size).
  * ffn_occupancy_count: block_offsets (ceil(n/256) int32) <- exclusive scan of the number of
- *   occupied samples per 256-sample block; *total (device int64) <- their sum.  Samples outside
- *   the box count as occupied.
+ *   occupied samples per 256-sample block; *total (device int64) <- their sum.  A sample outside
+ *   the box takes the occupancy of the nearest cell (indices clamped); NaN positions count as
+ *   occupied.
  * ffn_occupancy_compact: packs the occupied samples (order preserved): out_positions /
  *   out_views (total,3), out_index (total) = their position in the input.
  * ffn_scatter_logits: out (n,4) <- (0,0,0,empty_sigma_logit) everywhere, then
@@ -434,6 +435,10 @@ int ffn_occupancy_compact(const float* positions, const float* views, int64_t n,
                           float* out_positions, float* out_views, int32_t* out_index, void* stream);
 int ffn_scatter_logits(const float* packed, const int32_t* index, int64_t m, int64_t n,
                        float empty_sigma_logit, float* out, void* stream);
+/* K9g: packed[i] = full[index[i]] for (.,4) rows -- the backward of the scatter (training with
+ * empty-space skipping: d_logits of the evaluated samples). */
+int ffn_gather_logits(const float* full, const int32_t* index, int64_t m, float* packed,
+                      void* stream);
 
 /* ---- K10: dense voxel radiance field (voxels_model.py:35-45): trilinear lookup of a
  * (4,S,S,S) volume at positions/scale in [-1,1]^3 (grid_sample semantics: x = fastest axis,

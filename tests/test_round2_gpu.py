@@ -589,3 +589,86 @@ def test_live_focus_sampler_with_voxels_and_golden(golden):
     out = live.sample(s["idx"].tolist(), None)
     np.testing.assert_allclose(out.t_values.cpu().numpy(), g["t_u"], rtol=2e-4, atol=2e-4)
     assert torch.equal(out.t_values, table.sample(s["idx"].tolist(), None).t_values)
+
+
+# ----------------------------------------------------------------------------------- config 5: skip in training
+def _cpu_occupied(grid, flat):
+    """occupancy_map.h's occupied_at restated in torch float32 on the CPU."""
+    g = grid.resolution
+    lo = torch.tensor(grid.box_min, dtype=torch.float32)
+    inv = torch.tensor([np.float32(g) / np.float32(v) for v in grid.box_size], dtype=torch.float32)
+    f = (flat - lo) * inv
+    cell = f.clamp(0, g - 1).to(torch.int64)          # outside the box: the nearest cell
+    idx = (cell[:, 2] * g + cell[:, 1]) * g + cell[:, 0]
+    words = grid.bits.cpu().to(torch.int64) & 0xffffffff
+    bit = (words[idx >> 5] >> (idx & 31)) & 1
+    return bit == 1
+
+
+def test_training_step_with_empty_space_skipping(golden):
+    """TrainEngine.occupancy (opt-in, BASELINE config 5): (a) a grid with every cell occupied
+    gives the plain step bit for bit; (b) a partial grid gives the step of a model whose
+    samples in empty cells are the constants (0,0,0,-100) -- sigma = 0, no gradient -- checked
+    against the oracle with exactly that masking."""
+    import fourier_feature_nets_amd as ffn
+    from tests.test_pipeline_gpu import _oracle_model, _small_model
+    g = golden("training")
+    data = np.load(SCENE)
+    bounds = data["bounds"]
+
+    def fresh():
+        model = _small_model(g)
+        train = _quiet(ffn.ImageDataset.load, SCENE, "train", 16, True, False, device=dev())
+        return model, train, ffn.TrainEngine(model)
+
+    res = 16
+    centres = ffn.OccupancyGrid.cell_centres(bounds, res, dev())
+    logits = torch.zeros((centres.shape[0], 4), device=dev())
+    batch = None
+    finals = []
+    for full in (None, True):
+        model, train, engine = fresh()
+        batch = torch.arange(0, len(train), 3, device=dev())
+        if full:
+            logits[:, 3] = 5.0
+            engine.occupancy = ffn.OccupancyGrid.from_logits(logits, bounds, res, 0.01, False)
+            assert engine.occupancy.fraction_occupied() == 1.0
+        loss = float(engine.train_step(train, batch, None, 5e-4))
+        finals.append((loss, engine.flat.clone()))
+        if full:
+            assert engine.last_evaluated_fraction == 1.0
+    assert finals[0][0] == finals[1][0] and torch.equal(finals[0][1], finals[1][1])
+
+    # (b) a ball of occupied cells around the origin
+    model, train, engine = fresh()
+    logits[:, 3] = 5.0 - 14.0 * centres.norm(dim=1)
+    grid = ffn.OccupancyGrid.from_logits(logits, bounds, res, 0.01, True)
+    assert 0.02 < grid.fraction_occupied() < 0.6
+    engine.occupancy = grid
+    loss = float(engine.train_step(train, batch, None, 5e-4))
+    assert 0.0 < engine.last_evaluated_fraction < 0.9
+    ref = _oracle_model(g)
+
+    class Masked:
+        use_view = False
+
+        def parameters(self):
+            return ref.parameters()
+
+        def __call__(self, flat, views=None):
+            keep = _cpu_occupied(grid, flat)
+            const = torch.tensor([0.0, 0.0, 0.0, -100.0])
+            return torch.where(keep[:, None], ref(flat), const)
+
+    rays = train.ray_ids(batch).cpu()
+    smp = train.sampler
+    state = {"starts": smp.starts.cpu(), "directions": smp.directions.cpu(), "near_far": smp.near_far.cpu()}
+    pos, view, t, _ = orc.sample(state, rays.numpy(), None, 16)
+    keep = _cpu_occupied(grid, pos.reshape(-1, 3))
+    assert abs(float(keep.float().mean()) - engine.last_evaluated_fraction) < 1e-6
+    gc, ga = orc.ground_truth(train.colors.cpu(), train.alphas.cpu(), rays)
+    trainer = orc.OracleTrainer(Masked(), 5e-4)
+    ref_loss = trainer.step(pos, view, t, gc, ga, 5e-4)
+    assert abs(loss - ref_loss) < 2e-6 * max(1.0, abs(ref_loss)), (loss, ref_loss)
+    for layer, w in zip(model.layers, ref.weights):
+        np.testing.assert_allclose(layer.weight.detach().cpu().numpy(), w.detach().numpy(), rtol=0, atol=3e-5)
