@@ -60,6 +60,8 @@ def parse_args():
                     help="skip the MFMA-utilisation leg at the north-star shape (NeRF, 65536 x 128)")
     ap.add_argument("--no-config3", action="store_true",
                     help="skip the full-NeRF + focus-sampling optimisation-step leg")
+    ap.add_argument("--no-config5", action="store_true",
+                    help="skip the 512-wide Gaussian-feature 800x800 optimisation-step leg")
     ap.add_argument("--no-skip-leg", action="store_true",
                     help="skip the (separately labelled) empty-space-skipping leg")
     ap.add_argument("--model", default="tiny", choices=["tiny", "nerf", "gaussian512"],
@@ -439,6 +441,70 @@ def skip_leg(device, dataset, bounds, rays_per_step, steps=4):
             "render_fps_kernels_only": round(fps, 2)}
 
 
+def config5_leg(device, bounds, rays_per_step=32768, samples=128, cameras=25, size=800, steps=3):
+    """BASELINE configs[4] on one GPU: Gaussian Fourier features (sigma = 10), 512-wide MLP
+    (the two-waves-per-block "wide" kernels), 800x800 frames, 128 samples/ray -- one optimisation
+    step without and with the opt-in occupancy grid (the octree-accelerated skip of the config;
+    new semantics, labelled)."""
+    import fourier_feature_nets_amd as ffn
+    torch.cuda.empty_cache()
+    torch.manual_seed(20080524)
+    model = ffn.GaussianFourierMLP(3, 4, 10.0, num_channels=512).to(device)
+    intr, poses = synthetic_rig(cameras, size)
+    cams = [ffn.CameraInfo.create("train%03d" % i, ffn.Resolution(size, size), intr, p)
+            for i, p in enumerate(poses)]
+    with contextlib.redirect_stdout(io.StringIO()):
+        probe = ffn.RaySampler(bounds, cams, samples, device=device)
+        images = analytic_images(probe)
+        del probe
+        dataset = ffn.ImageDataset("train", images, bounds, cams, samples, True, True,
+                                   anneal_start=0.2, num_anneal_steps=2000, device=device)
+    del images
+    valid_ids = torch.nonzero(dataset.sampler.valid != 0).flatten()
+    gen = torch.Generator(device=device).manual_seed(555)
+    prog = model.program()
+    res = 128
+    centres = ffn.OccupancyGrid.cell_centres(bounds, res, device)
+    logits = torch.zeros((centres.shape[0], 4), device=device)
+    logits[:, 3] = torch.where(centres.norm(dim=1) < 0.6, 10.0, -30.0)
+    grid = ffn.OccupancyGrid.from_logits(logits, bounds, res, 0.01, True)
+    del centres, logits
+    out = {"workload": "trex_800-shaped 512-wide Gaussian-feature train step: GaussianFourierMLP(3,4,"
+                       "10.0,num_channels=512), %d cams x %dx%d, %d samples/ray, %d rays/step, "
+                       "exact-f32 MFMA (wide kernels)" % (cameras, size, size, samples, rays_per_step)}
+    for label, occ in (("full", None), ("with_occupancy_grid", grid)):
+        engine = ffn.TrainEngine(model, 0.0, None)
+        engine.occupancy = occ
+        timer = KernelTimer()
+        try:
+            def run_step(step):
+                pick = torch.randint(0, valid_ids.numel(), (rays_per_step,), device=device, generator=gen)
+                return engine.train_step(dataset, valid_ids[pick], step, 5e-4)
+
+            run_step(0)
+            torch.cuda.synchronize()
+            timer.on = occ is None
+            t0 = time.perf_counter()
+            for step in range(1, 1 + steps):
+                run_step(step)
+            torch.cuda.synchronize()
+            step_ms = 1e3 * (time.perf_counter() - t0) / steps
+            engine.check_finite()
+        finally:
+            timer.close()
+        entry = {"step_ms": round(step_ms, 3), "rays_per_s": round(rays_per_step / (step_ms * 1e-3), 1)}
+        if occ is None:
+            entry["kernels"] = timer.summary(prog, rays_per_step * samples)
+        else:
+            entry["evaluated_sample_fraction"] = round(engine.last_evaluated_fraction, 4)
+            entry["label"] = "opt-in empty-space skipping: not the reference's semantics"
+        out[label] = entry
+        del engine
+        prog._workspaces.clear()
+        torch.cuda.empty_cache()
+    return out
+
+
 def render_leg(args, caster, sampler, world, rank, barrier):
     """frames/sec of 400x400 renders through the fused kernel: kernels only (frames stay on the
     GPU), with the synchronous D2H copy of each frame (what render_image returns to a caller),
@@ -664,6 +730,10 @@ def main():
                                   if solo and not args.no_config3 and args.size == 400 else None)
         result["empty_space_skipping"] = (skip_leg(device, dataset, bounds, args.rays)
                                           if solo and not args.no_skip_leg else None)
+        del dataset
+        torch.cuda.empty_cache()
+        result["config5_step"] = (config5_leg(device, bounds)
+                                  if solo and not args.no_config5 and args.size == 400 else None)
         result["cpu_baseline"] = cpu_baseline(args, state) if solo and not args.no_cpu_baseline else None
         print(json.dumps(result), flush=True)
     if group is not None:
