@@ -656,7 +656,13 @@ def main():
 
     # ---- render leg: 400x400 frames of the first cameras (replicas only: frame f -> rank f%world)
     caster = ffn.Raycaster(model)
-    render = None if args.no_render else render_leg(args, caster, dataset.sampler, world, rank, barrier)
+    render = None
+    if not args.no_render:
+        # like orbit_video.py:76-78: a plain (non-stratified) sampler over the frames' cameras
+        with contextlib.redirect_stdout(io.StringIO()):
+            frame_sampler = ffn.RaySampler(bounds, cams[:8 * world], args.samples, False, device=device)
+        render = render_leg(args, caster, frame_sampler, world, rank, barrier)
+        del frame_sampler
     if group is not None:
         import torch.distributed as dist
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
