@@ -320,23 +320,21 @@ def config3_leg(device, cams, images, bounds, rays_per_step=65536, steps=3):
     prog = fine.program()
     coarse_events = []
     sampler = dataset.sampler
-    live_rows = sampler._live_cdf_rows
+    live_rows = sampler.sample_t
     timer = KernelTimer()
 
-    def timed_rows(index):
-        # the coarse pass runs the same entry points as the fine model: keep it out of the
-        # fine model's kernel timers and time it as one span
-        was_on, timer.on = timer.on, False
+    def timed_rows(index, step):
+        # t-sampling of the step = uniform half + the fused coarse pass (probe points -> coarse
+        # model -> CDF -> inverse transform -> merge, one launch): timed as one span
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        out = live_rows(index)
+        out = live_rows(index, step)
         e1.record()
-        timer.on = was_on
-        if was_on:
+        if timer.on:
             coarse_events.append((e0, e1))
         return out
 
-    sampler._live_cdf_rows = timed_rows
+    sampler.sample_t = timed_rows
     try:
         def run_step(step):
             pick = torch.randint(0, valid_ids.numel(), (rays_per_step,), device=device, generator=gen)
@@ -355,7 +353,7 @@ def config3_leg(device, cams, images, bounds, rays_per_step=65536, steps=3):
         fine_kernels = timer.summary(prog, rays_per_step * 128)
     finally:
         timer.close()
-        sampler._live_cdf_rows = live_rows
+        del sampler.sample_t
     coarse_ms = sum(a.elapsed_time(b) for a, b in coarse_events) / max(len(coarse_events), 1)
     step_ms = 1e3 * elapsed / steps
     mlp_ms = sum(k["avg_ms"] for k in fine_kernels.values())
@@ -366,7 +364,7 @@ def config3_leg(device, cams, images, bounds, rays_per_step=65536, steps=3):
                        "100 cams x 400x400, exact-f32 MFMA" % rays_per_step,
            "step_ms": round(step_ms, 2), "rays_per_s": round(rays_per_step / (step_ms * 1e-3), 1),
            "steps": steps, "final_loss": float(loss), "sampler_startup_s": round(startup_s, 3),
-           "cdf_table_bytes": 0, "coarse_pass_ms": round(coarse_ms, 3),
+           "cdf_table_bytes": 0, "sampling_incl_coarse_pass_ms": round(coarse_ms, 3),
            "fine_mlp_ms": round(mlp_ms, 3), "kernels": fine_kernels,
            "fine_mlp_frac_of_f32_mfma_peak": round(flop / (mlp_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
            "whole_step_frac_of_f32_mfma_peak": round(flop / (step_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)}

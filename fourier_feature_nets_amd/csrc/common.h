@@ -36,6 +36,20 @@ __device__ __forceinline__ float np_min(float a, float b) {
     return (a != a || b != b) ? __builtin_nanf("") : (a < b ? a : b);
 }
 
+// a*b + c with the product and the sum rounded separately, whatever -ffp-contract the including
+// file is compiled with (HIP's __fmul_rn / __fadd_rn are plain operators and DO get fused into
+// an fma after inlining).  The sampling arithmetic of the reference is a sequence of separate
+// ATen ops (mul, then add), so bit-exact t-values and positions need exactly this.
+__device__ __forceinline__ float mul_add_rn(float a, float b, float c) {
+#pragma clang fp contract(off)
+    const float p = a * b;
+    return p + c;
+}
+__device__ __forceinline__ float sub_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a - b;
+}
+
 // Encoding tables live in LDS while a kernel runs: per encoding four rows [b row 0 | b row 1 |
 // b row 2 | a] of 256 floats (F <= 256; the tail of a row is zero), so that the entries of
 // two consecutive frequencies are one aligned 8-byte read.

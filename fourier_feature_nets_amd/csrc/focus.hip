@@ -1,34 +1,16 @@
 // Opacity-guided ("focus") sampling: per-ray CDF build, inverse-transform sampling, and the
-// merge + sort with the uniform half.  One wavefront per ray; compiled with
-// -ffp-contract=off (the lerp arithmetic is bit-identical to the reference's op sequence,
-// the CDF itself differs from torch.cumsum only by summation order).
+// merge + sort with the uniform half.  One wavefront per ray; the per-ray arithmetic lives in
+// focus_terms.h with floating-point contraction switched off per function (the lerp arithmetic
+// is bit-identical to the reference's op sequence, the CDF itself differs from torch.cumsum
+// only by summation order).
 #include "common.h"
+#include "focus_terms.h"
 
 namespace ffn {
 
-__device__ __forceinline__ float scan_mul(float v, int lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const float up = __shfl_up(v, off, 64);
-        if (lane >= off) v *= up;
-    }
-    return v;
-}
-__device__ __forceinline__ float scan_add(float v, int lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const float up = __shfl_up(v, off, 64);
-        if (lane >= off) v += up;
-    }
-    return v;
-}
-
 // ---------------------------------------------------------------------------------- K2c
-// cdf = [0, cumsum(w[1:-1] + 1e-5) / sum], w = blend weights of the probe (n samples).
 // LOGITS: `opacity` holds the coarse model's raw (P,n,4) outputs; sigma = softplus of the last
 // channel is taken here (ray_sampler.py:261-265) instead of in a separate pass.
-__device__ __forceinline__ float softplus_probe(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
-
 template <int ROWS, bool LOGITS>
 __global__ void __launch_bounds__(256)
 cdf_build_kernel(const float* __restrict__ t_probe, const float* __restrict__ opacity,
@@ -39,44 +21,18 @@ cdf_build_kernel(const float* __restrict__ t_probe, const float* __restrict__ op
     for (int64_t ray = wave; ray < num_rays; ray += waves) {
         const float* tr = t_probe + ray * n;
         const float* op = opacity + ray * n * (LOGITS ? 4 : 1);
-        float w[ROWS];
-        float carry = 1.0f;
+        float sigma[ROWS], delta[ROWS];
 #pragma unroll
         for (int row = 0; row < ROWS; ++row) {
             const int s = row * 64 + lane;
-            float alpha = 0.0f, tau = 1.0f;
+            sigma[row] = 0.0f;
+            delta[row] = 0.0f;
             if (s < n) {
-                const float delta = (s == n - 1) ? 1e10f : tr[s + 1] - tr[s];
-                const float sigma = LOGITS ? softplus_probe(op[4 * s + 3]) : op[s];
-                alpha = 1.0f - expf(-(sigma * delta));
-                const float u = (1.0f - alpha) + 1e-10f;
-                tau = u < 1.0f ? u : 1.0f;
+                sigma[row] = LOGITS ? softplus_probe(op[4 * s + 3]) : op[s];
+                if (s < n - 1) delta[row] = tr[s + 1] - tr[s];
             }
-            const float incl = scan_mul(tau, lane);
-            float excl = __shfl_up(incl, 1, 64);
-            if (lane == 0) excl = 1.0f;
-            w[row] = alpha * (carry * excl);
-            carry *= __shfl(incl, 63, 64);
         }
-        // interior weights + 1e-5, running sum
-        float run[ROWS];
-        float base = 0.0f;
-#pragma unroll
-        for (int row = 0; row < ROWS; ++row) {
-            const int s = row * 64 + lane;
-            const float v = (s >= 1 && s <= n - 2) ? w[row] + 1e-5f : 0.0f;
-            const float incl = scan_add(v, lane);
-            run[row] = base + incl;
-            base += __shfl(incl, 63, 64);
-        }
-        const float total = base;
-        float* out = cdf + ray * (n - 1);
-        if (lane == 0) out[0] = 0.0f;
-#pragma unroll
-        for (int row = 0; row < ROWS; ++row) {
-            const int s = row * 64 + lane;
-            if (s >= 1 && s <= n - 2) out[s] = run[row] / total;
-        }
+        cdf_of_probe<ROWS>(sigma, delta, n, lane, cdf + ray * (n - 1));
     }
 }
 
@@ -111,42 +67,7 @@ focus_merge_kernel(const float* __restrict__ near_far, int64_t total_rays,
         for (int i = lane; i < n_uniform; i += 64) tv[i] = row[i];
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): LDS writes of this wave are done
         __builtin_amdgcn_wave_barrier();
-        for (int i = lane; i < n_focus; i += 64) {
-            const float uu = u[(int64_t)r * n_focus + i];
-            // searchsorted(right=True): number of cdf entries <= u (cdf is ascending)
-            int lo_b = 0, hi_b = width;
-            while (lo_b < hi_b) {
-                const int mid = (lo_b + hi_b) >> 1;
-                if (c[mid] <= uu) lo_b = mid + 1; else hi_b = mid;
-            }
-            const int k = lo_b;
-            const int lo = k - 1 > 0 ? k - 1 : 0;
-            const int hi = k < width - 1 ? k : width - 1;
-            const float c_lo = c[lo], c_hi = c[hi];
-            // bin centres of linspace(near, far, n_focus)
-            const float g_lo0 = near + unit_focus[lo] * span, g_lo1 = near + unit_focus[lo + 1] * span;
-            const float g_hi0 = near + unit_focus[hi] * span, g_hi1 = near + unit_focus[hi + 1] * span;
-            const float t_lo = 0.5f * (g_lo0 + g_lo1);
-            const float t_hi = 0.5f * (g_hi0 + g_hi1);
-            float denom = c_hi - c_lo;
-            if (denom < 1e-5f) denom = 1.0f;
-            const float frac = (uu - c_lo) / denom;
-            tv[n_uniform + i] = t_lo + frac * (t_hi - t_lo);
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-        // rank sort: position = #smaller + #equal-with-lower-index
-        for (int i = lane; i < S; i += 64) {
-            const float v = tv[i];
-            int rank = 0;
-            for (int j = 0; j < S; ++j) {
-                const float o = tv[j];
-                rank += (o < v || (o == v && j < i)) ? 1 : 0;
-            }
-            row[rank] = v;
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
+        focus_merge_ray(near, span, c, tv, u + (int64_t)r * n_focus, unit_focus, S, n_focus, lane, row);
     }
 }
 

@@ -20,6 +20,7 @@
 // slab) covers 512-channel layers.
 #include "common.h"
 #include "composite_terms.h"
+#include "focus_terms.h"
 #include "occupancy_map.h"
 
 namespace ffn {
@@ -685,12 +686,12 @@ render_fused_kernel(const ffn_mlp_chain ch, const float* __restrict__ packed_w,
         const float sx = p.starts[ray * 3 + 0], sy = p.starts[ray * 3 + 1], sz = p.starts[ray * 3 + 2];
         const float dx = p.dirs[ray * 3 + 0], dy = p.dirs[ray * 3 + 1], dz = p.dirs[ray * 3 + 2];
         const float near = p.near_far[ray], far = p.near_far[p.total_rays + ray];
-        const float span = __fsub_rn(far, near);
+        const float span = sub_rn(far, near);
         // t of sample j: given, or near + linspace(0,1,S)[j] * (far - near) with separately
         // rounded multiply and add like the sampling kernel (bit-identical t and positions)
         const float* trow = p.t_values != nullptr ? p.t_values + (int64_t)r * S : nullptr;
         auto t_of = [&](int j) -> float {
-            return trow != nullptr ? trow[j] : __fadd_rn(near, __fmul_rn(p.unit[j], span));
+            return trow != nullptr ? trow[j] : mul_add_rn(p.unit[j], span, near);
         };
         int m = S;
         if (p.occ_bits != nullptr) {
@@ -699,8 +700,7 @@ render_fused_kernel(const ffn_mlp_chain ch, const float* __restrict__ packed_w,
                 const int j = base + w.lane;
                 const bool in_ray = j < S;
                 const float t = t_of(in_ray ? j : S - 1);
-                const float px = __fadd_rn(sx, __fmul_rn(t, dx)), py = __fadd_rn(sy, __fmul_rn(t, dy)),
-                            pz = __fadd_rn(sz, __fmul_rn(t, dz));
+                const float px = mul_add_rn(t, dx, sx), py = mul_add_rn(t, dy, sy), pz = mul_add_rn(t, dz, sz);
                 const bool keep = in_ray && occupied_at(p.map, p.occ_bits, px, py, pz);
                 const uint64_t mask = __ballot(keep);
                 const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
@@ -727,9 +727,9 @@ render_fused_kernel(const ffn_mlp_chain ch, const float* __restrict__ packed_w,
                 const int sl = valid ? slot : m - 1;          // tail lanes recompute the last sample
                 const int j = p.occ_bits != nullptr ? (int)slots[sl] : sl;
                 const float t = t_of(j);
-                w.x0 = __fadd_rn(sx, __fmul_rn(t, dx));
-                w.x1 = __fadd_rn(sy, __fmul_rn(t, dy));
-                w.x2 = __fadd_rn(sz, __fmul_rn(t, dz));
+                w.x0 = mul_add_rn(t, dx, sx);
+                w.x1 = mul_add_rn(t, dy, sy);
+                w.x2 = mul_add_rn(t, dz, sz);
                 w.v0 = dx; w.v1 = dy; w.v2 = dz;
                 w.logit[0] = w.logit[1] = w.logit[2] = w.logit[3] = 0.0f;
                 run_chain<kInfer, false>(ch, w, packed_w, nullptr);
@@ -761,6 +761,79 @@ render_fused_kernel(const ffn_mlp_chain ch, const float* __restrict__ packed_w,
                 px[2] = (uint8_t)(int)(acc.cb * 255.0f);
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------- fused focus
+// Opacity-guided sampling with a LIVE coarse model in one launch (ray_sampler.py:234-357 and
+// :388-392, which the reference runs as a start-up pass over every ray into a (rays, S_f - 1)
+// table): per ray, the wave evaluates the coarse model on the S_f <= 64 probe points
+// t = linspace(near, far, S_f) through the chain interpreter (two 32-sample blocks whose sigma
+// logits land on the two lane halves = one row of the scan), builds the blend-weight CDF in
+// registers and its own -- now idle -- LDS slab, draws the S_f inverse-transform samples, merges
+// them with the uniform half already in t_io and writes the sorted row.  Probe positions, logits,
+// opacities and CDF rows never exist in HBM.  Arithmetic = K2a/K2c/K2d's (focus_terms.h), so
+// the t-values are the table path's bit for bit.
+struct FocusParams {
+    const float* starts; const float* dirs; const float* near_far; int64_t total_rays;
+    const int64_t* ray_index; int num_rays; int S; int n_focus;
+    const float* unit_focus; const float* u; float* t_io;
+};
+
+__global__ void __launch_bounds__(256, 1)
+focus_fused_kernel(const ffn_mlp_chain ch, const float* __restrict__ packed_w,
+                   const float* __restrict__ bias, const FocusParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    stage_encoding_tables(ch.enc, reinterpret_cast<float*>(smem + kWavesPerBlock * kActBytesPerWave),
+                          threadIdx.x, 256);
+    {
+        float* bl = reinterpret_cast<float*>(smem + kWavesPerBlock * kActBytesPerWave + kEncTableBytes);
+        for (int i = threadIdx.x; i < ch.bias_floats; i += 256) bl[i] = bias[i];
+    }
+    __syncthreads();
+    WaveCtx w;
+    int64_t stride;
+    wave_setup<false>(w, smem, kSamplesPerWave, stride);
+    w.block = 0;
+    w.masks = nullptr;
+    const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int waves = gridDim.x * kWavesPerBlock;
+    const int n = p.n_focus;
+    const int nblk = (n + 31) >> 5;
+    for (int r = blockIdx.x * kWavesPerBlock + wave_in_block; r < p.num_rays; r += waves) {
+        const int64_t ray = p.ray_index[r];
+        const float sx = p.starts[ray * 3 + 0], sy = p.starts[ray * 3 + 1], sz = p.starts[ray * 3 + 2];
+        const float dx = p.dirs[ray * 3 + 0], dy = p.dirs[ray * 3 + 1], dz = p.dirs[ray * 3 + 2];
+        const float near = p.near_far[ray], far = p.near_far[p.total_rays + ray];
+        const float span = sub_rn(far, near);
+        auto t_of = [&](int j) -> float { return mul_add_rn(p.unit_focus[j], span, near); };
+        float sigma_logit = 0.0f;
+        for (int hb = 0; hb < 2; ++hb) {
+            if (hb >= nblk) break;
+            const int slot = 32 * hb + w.s;
+            const int j = slot < n ? slot : n - 1;
+            const float t = t_of(j);
+            w.x0 = mul_add_rn(t, dx, sx);
+            w.x1 = mul_add_rn(t, dy, sy);
+            w.x2 = mul_add_rn(t, dz, sz);
+            w.v0 = dx; w.v1 = dy; w.v2 = dz;
+            w.logit[0] = w.logit[1] = w.logit[2] = w.logit[3] = 0.0f;
+            run_chain<kInfer, false>(ch, w, packed_w, nullptr);
+            const float out = w.logit[3] + __shfl_xor(w.logit[3], 32);
+            if (w.h == hb) sigma_logit = out;
+        }
+        // probe sample s sits on lane s
+        float sigma[1], delta[1];
+        sigma[0] = w.lane < n ? softplus_probe(sigma_logit) : 0.0f;
+        delta[0] = w.lane < n - 1 ? sub_rn(t_of(w.lane + 1), t_of(w.lane)) : 0.0f;
+        float* c = reinterpret_cast<float*>(w.act);       // the wave's slab is idle between rays
+        float* tv = c + 256;
+        cdf_of_probe<1>(sigma, delta, n, w.lane, c);
+        float* row = p.t_io + (int64_t)r * p.S;
+        for (int i = w.lane; i < p.S - n; i += 64) tv[i] = row[i];
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        focus_merge_ray(near, span, c, tv, p.u + (int64_t)r * n, p.unit_focus, p.S, n, w.lane, row);
     }
 }
 
@@ -928,6 +1001,28 @@ extern "C" int ffn_render_fused_fwd(const ffn_mlp_chain* chain, const float* pac
     hipLaunchKernelGGL(render_fused_kernel, dim3((unsigned)grid), dim3(256), kLdsBytes,
                        (hipStream_t)stream, *chain, packed_w, bias, p);
     return check_launch("ffn_render_fused_fwd");
+}
+
+extern "C" int ffn_focus_fused(const ffn_mlp_chain* chain, const float* packed_w, const float* bias,
+                               const float* starts, const float* directions, const float* near_far,
+                               int64_t num_rays_total, const int64_t* ray_index, int num_rays,
+                               int num_samples, int n_focus, const float* unit_focus, const float* u,
+                               float* t_io, void* stream) {
+    if (num_rays == 0) return 0;
+    if (num_rays < 0 || num_samples > 256 || n_focus < 3 || n_focus > 64 || n_focus > num_samples)
+        return fail_arg("ffn_focus_fused: need 3 <= n_focus <= 64, n_focus <= S <= 256");
+    if (validate_chain(chain, false) || chain->wide)
+        return fail_arg("ffn_focus_fused: bad chain (narrow forward chains only)");
+    FocusParams p;
+    p.starts = starts; p.dirs = directions; p.near_far = near_far; p.total_rays = num_rays_total;
+    p.ray_index = ray_index; p.num_rays = num_rays; p.S = num_samples; p.n_focus = n_focus;
+    p.unit_focus = unit_focus; p.u = u; p.t_io = t_io;
+    const int64_t wgs = ((int64_t)num_rays + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int64_t grid = persistent_grid(wgs * kWavesPerBlock, kWavesPerBlock);
+    allow_big_lds(&focus_fused_kernel);
+    hipLaunchKernelGGL(focus_fused_kernel, dim3((unsigned)grid), dim3(256), kLdsBytes,
+                       (hipStream_t)stream, *chain, packed_w, bias, p);
+    return check_launch("ffn_focus_fused");
 }
 
 template <bool WIDE>

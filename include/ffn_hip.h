@@ -338,6 +338,21 @@ int ffn_render_fused_fwd(const ffn_mlp_chain* chain, const float* packed_w, cons
                          const ffn_render_rays* rays, const ffn_occupancy* occupancy,
                          const ffn_render_out* out, void* stream);
 
+/* Fused live focus sampling: the coarse pass of ray_sampler.py:234-269 (probe the opacity model
+ * on n_focus <= 64 points t = linspace(near, far, n_focus) per ray, sigma = softplus of its last
+ * output), the CDF of :59-67 and the inverse-transform sampling + merge + sort of :301-357 /
+ * :388-392 in ONE launch, per batch ray, with no per-sampler table.  `chain` describes the
+ * opacity model (a narrow forward chain; view directions = the ray directions when it takes
+ * them).  t_io (R,S): on entry the first S-n_focus entries of each row hold the uniform samples
+ * (ffn_sample_t with t_stride = S); on exit all S samples sorted.  u (R,n_focus) as
+ * ffn_focus_sample_merge.  Arithmetic identical to ffn_sample_t + ffn_cdf_build_logits +
+ * ffn_focus_sample_merge_rows. */
+int ffn_focus_fused(const ffn_mlp_chain* chain, const float* packed_w, const float* bias,
+                    const float* starts, const float* directions, const float* near_far,
+                    int64_t num_rays_total, const int64_t* ray_index, int num_rays,
+                    int num_samples, int n_focus, const float* unit_focus, const float* u,
+                    float* t_io, void* stream);
+
 /* Backward-data chain: d_logits (N,4) + ReLU sign masks -> dZ slabs (same slab geometry as
  * `saved`).  packed_wt holds the transposed operand packs. */
 int ffn_mlp_backward_data(const ffn_mlp_chain* chain, const float* packed_wt,

@@ -416,8 +416,9 @@ def _render_both_ways(caster, sampler, rays, seed=None):
 @pytest.mark.parametrize("S", [16, 32, 37, 64, 96, 128, 200, 256])
 def test_fused_render_equals_the_three_pass_render(golden, S):
     """ffn_render_fused_fwd (sampling + encoding + MLP + compositing in one launch, logits
-    consumed from registers) == sampler.sample -> model -> composite kernels on the same rays:
-    identical t / positions by construction, colour and alpha to 1e-6, same depth pick."""
+    consumed from registers) == sampler.sample -> model -> composite kernels on the same rays,
+    BIT FOR BIT: t and positions are rounded op by op like the sampling kernels (mul_add_rn),
+    the chain interpreter and the composite terms are the same code."""
     import fourier_feature_nets_amd as ffn
     from tests.test_pipeline_gpu import _small_model
     model = _small_model(golden("training"))
@@ -425,10 +426,8 @@ def test_fused_render_equals_the_three_pass_render(golden, S):
     sampler = _scene_sampler(S)
     rays = sampler.valid_index(torch.arange(0, sampler.num_rays, 3, device=dev()))
     fused, plain = _render_both_ways(caster, sampler, rays)
-    np.testing.assert_allclose(fused.color.cpu().numpy(), plain.color.cpu().numpy(), rtol=2e-6, atol=1e-6)
-    np.testing.assert_allclose(fused.alpha.cpu().numpy(), plain.alpha.cpu().numpy(), rtol=2e-6, atol=1e-6)
-    same = (fused.depth == plain.depth).float().mean()
-    assert float(same) > 0.99
+    assert torch.equal(fused.color, plain.color) and torch.equal(fused.alpha, plain.alpha)
+    assert torch.equal(fused.depth, plain.depth)
     caster.check_finite()
     # a whole-camera range filtered by the validity mask in the kernel == the filtered index list
     with torch.no_grad():
@@ -455,8 +454,7 @@ def test_fused_render_full_nerf_and_samplers(golden):
                           (_scene_sampler(64, stratified=True, opacity_model=coarse), 4)):
         rays = sampler.valid_index(torch.arange(1, sampler.num_rays, 5, device=dev()))
         fused, plain = _render_both_ways(caster, sampler, rays, seed)
-        np.testing.assert_allclose(fused.color.cpu().numpy(), plain.color.cpu().numpy(), rtol=2e-6, atol=1e-6)
-        np.testing.assert_allclose(fused.alpha.cpu().numpy(), plain.alpha.cpu().numpy(), rtol=2e-6, atol=1e-6)
+        assert torch.equal(fused.color, plain.color) and torch.equal(fused.alpha, plain.alpha)
 
 
 def test_fused_render_image_and_fallbacks(golden):
@@ -672,3 +670,35 @@ def test_training_step_with_empty_space_skipping(golden):
     assert abs(loss - ref_loss) < 2e-6 * max(1.0, abs(ref_loss)), (loss, ref_loss)
     for layer, w in zip(model.layers, ref.weights):
         np.testing.assert_allclose(layer.weight.detach().cpu().numpy(), w.detach().numpy(), rtol=0, atol=3e-5)
+
+
+def test_fused_focus_kernel_equals_the_five_launch_live_path(golden):
+    """ffn_focus_fused (probe -> coarse model -> CDF -> inverse transform -> merge in one launch,
+    nothing in HBM in between) == sample_t + materialise + forward + cdf_build_logits +
+    focus_sample_merge_rows, bit for bit, for tiny-NeRF and view-dependent NeRF coarse models."""
+    import fourier_feature_nets_amd as ffn
+    from tests.test_kernels_gpu import _load_nerf
+    from tests.test_pipeline_gpu import _small_model
+    data = np.load(SCENE)
+    nerf, _ = _load_nerf(golden("models"), "nerf_small", [2], False)
+    for coarse in (_small_model(golden("training")), nerf):
+        for S, stratified in ((128, True), (64, False), (7, True)):
+            cams = _scene_sampler(8).cameras
+            smp = _quiet(ffn.RaySampler, data["bounds"], cams, S, stratified, coarse, 64,
+                         device=dev(), focus_mode="live")
+            n_focus = S - S // 2
+            assert smp._can_fuse_focus(n_focus) == (n_focus >= 3)
+            idx = smp.valid_index(torch.arange(1, smp.num_rays, 4, device=dev()))
+            torch.manual_seed(S)
+            fused = smp.sample_t(idx, None)
+            smp.fused_focus = False
+            torch.manual_seed(S)
+            plain = smp.sample_t(idx, None)
+            assert torch.equal(fused, plain)
+            assert bool((fused[:, 1:] >= fused[:, :-1]).all())
+    # a 512-wide opacity model or a voxel grid takes the five-launch path
+    from tests.test_kernels_gpu import _load_fourier
+    wide, _ = _load_fourier(golden("models"), "gaussian512")
+    smp = _quiet(ffn.RaySampler, data["bounds"], cams, 16, False, wide, 64, device=dev(), focus_mode="live")
+    assert not smp._can_fuse_focus(8)
+    assert smp.sample_t(idx, None).shape == (idx.numel(), 16)
