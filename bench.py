@@ -62,6 +62,8 @@ def parse_args():
                     help="skip the full-NeRF + focus-sampling optimisation-step leg")
     ap.add_argument("--no-config5", action="store_true",
                     help="skip the 512-wide Gaussian-feature 800x800 optimisation-step leg")
+    ap.add_argument("--no-bf16-leg", action="store_true",
+                    help="skip the (separately labelled) split-bf16 inference leg")
     ap.add_argument("--no-skip-leg", action="store_true",
                     help="skip the (separately labelled) empty-space-skipping leg")
     ap.add_argument("--model", default="tiny", choices=["tiny", "nerf", "gaussian512"],
@@ -503,6 +505,60 @@ def config5_leg(device, bounds, rays_per_step=32768, samples=128, cameras=25, si
     return out
 
 
+def bf16_leg(device, bounds, cams, samples):
+    """OPT-IN split-bf16 inference mode, separately labelled: every f32 product as three
+    v_mfma_f32_32x32x16_bf16 products with f32 accumulation (mlp_bf16.hip).  Frames/sec of the
+    400x400 render (three passes: sampling, MLP, compositing) and the error against the exact-f32
+    render of the same frames; algorithmic FLOPs against the bf16 matrix peak."""
+    import fourier_feature_nets_amd as ffn
+    torch.manual_seed(20080524)
+    model = ffn.PositionalFourierMLP(3, 4, 5.5).to(device)
+    caster = ffn.Raycaster(model)
+    with contextlib.redirect_stdout(io.StringIO()):
+        sampler = ffn.RaySampler(bounds, cams[:8], samples, False, device=device)
+    exact = [caster.render_image_device(sampler, f, 1 << 20).clone() for f in range(2)]
+    prog = model.program()
+    n = 65536 * samples
+    x = torch.rand((n, 3), device=device) * 2 - 1
+    flops = 2 * sum(sp.out * sp.ld for sp in prog.layers) * n
+    timings = {}
+    outs = {}
+    for mode, fn in (("f32", lambda: prog.forward(x, None, None)), ("bf16x3", lambda: prog.forward16(x, None))):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            outs[mode] = fn()
+        e1.record()
+        torch.cuda.synchronize()
+        timings[mode] = e0.elapsed_time(e1) / 3
+    err = float((outs["f32"] - outs["bf16x3"]).abs().max())
+    scale = float(outs["f32"].abs().max())
+    del x, outs
+    model.precision = "bf16x3"
+    fast = [caster.render_image_device(sampler, f, 1 << 20).clone() for f in range(2)]
+    torch.cuda.synchronize()
+    r0 = time.perf_counter()
+    for f in range(8):
+        caster.render_image_device(sampler, f, 1 << 20)
+    torch.cuda.synchronize()
+    fps = 8 / (time.perf_counter() - r0)
+    caster.check_finite()
+    mse = float(torch.stack([(a.float() - b.float()).square().mean() for a, b in zip(exact, fast)]).mean())
+    psnr = 10 * np.log10(255.0 ** 2 / max(mse, 1e-12))
+    return {"label": "opt-in split-bf16 inference (3 bf16 matrix products per f32 product, f32 "
+                     "accumulation): not the exact-f32 parity mode; reported separately from the headline",
+            "mlp_forward_ms": {k: round(v, 3) for k, v in timings.items()},
+            "mlp_speedup_vs_exact_f32": round(timings["f32"] / timings["bf16x3"], 2),
+            "algorithmic_tflops": round(flops / (timings["bf16x3"] * 1e-3) / 1e12, 1),
+            "frac_of_bf16_mfma_peak_2500": round(flops / (timings["bf16x3"] * 1e-3) / 1e12 / 2500.0, 4),
+            "matrix_flops_issued_over_algorithmic": 3.0,
+            "max_abs_logit_error_vs_f32": err, "max_abs_logit": scale,
+            "render_fps_400x400_%d_samples_kernels_only" % samples: round(fps, 2),
+            "render_psnr_db_vs_exact_f32_frames": round(float(psnr), 2)}
+
+
 def render_leg(args, caster, sampler, world, rank, barrier):
     """frames/sec of 400x400 renders through the fused kernel: kernels only (frames stay on the
     GPU), with the synchronous D2H copy of each frame (what render_image returns to a caller),
@@ -734,6 +790,8 @@ def main():
                                   if solo and not args.no_config3 and args.size == 400 else None)
         result["empty_space_skipping"] = (skip_leg(device, dataset, bounds, args.rays)
                                           if solo and not args.no_skip_leg else None)
+        result["split_bf16_inference"] = (bf16_leg(device, bounds, cams, args.samples)
+                                          if solo and not args.no_bf16_leg else None)
         del dataset
         torch.cuda.empty_cache()
         result["config5_step"] = (config5_leg(device, bounds)

@@ -28,6 +28,7 @@ SOURCES = {
     "encode.hip": [],
     "optim.hip": ["-ffp-contract=off"],
     "mlp.hip": [],
+    "mlp_bf16.hip": [],
     "wgrad.hip": [],
     "occupancy.hip": [],
 }

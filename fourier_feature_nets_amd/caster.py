@@ -305,7 +305,7 @@ class Raycaster(nn.Module):
     def _can_fuse(self, sampler: RaySampler) -> bool:
         model = self.model
         return (self.fused_render and hasattr(model, "program") and sampler.num_samples <= 256
-                and not model.program().wide)
+                and getattr(model, "precision", "f32") == "f32" and not model.program().wide)
 
     def render_rays(self, sampler: RaySampler, rays, include_depth=False,
                     image: Optional[torch.Tensor] = None, pixel_offset: int = 0,

@@ -1,0 +1,394 @@
+// Split-bf16 inference mode of the fused Fourier-feature MLP (OPT-IN, separately labelled; the
+// exact-f32 kernels of mlp.hip stay the parity mode and the headline).
+//
+// v_mfma_f32_32x32x2_f32 runs on the FP32 vector lanes (157 TFLOP/s, and no VALU work overlaps
+// it); v_mfma_f32_32x32x16_bf16 runs on the matrix units at 16x that rate.  Every f32 operand
+// is split into two bf16 parts, x = x_hi + x_lo (16 mantissa bits together), and every product
+// into three matrix instructions  w_hi x_lo + w_lo x_hi + w_hi x_hi  with f32 accumulation: a
+// relative error of ~2^-16 per product instead of f32's 2^-24, at 3/16 of the matrix time.
+//
+// At that speed the f32 kernel's organisation no longer works: streaming every weight from L2
+// per 32-sample block would need ~48 TB/s.  Here the four waves of a workgroup advance in
+// LOCKSTEP through the chain, each on its own block of 32 samples, and share every weight
+// K block through LDS (a ring of eight 16 KiB K blocks fed five blocks ahead of their use by
+// all 256 threads, operands read one block ahead, one workgroup barrier per four K blocks); the
+// activations never touch LDS at all: with the bf16 operand layout the accumulators of layer l
+// (lane = (h, sample), registers r <-> channel 8q + 4h + p) become the B operand of layer l+1
+// in place -- K block G of the next layer is the eight accumulator registers 8(G&1) .. 8(G&1)+7
+// of tile G/2, converted to (hi, lo) bf16 pairs.  The weight packs are permuted to that K order
+// on the host (ffn_mlp_pack_bf16).  Encoding features are generated per K block in registers
+// (four angles per lane), overlapping the previous block's matrix instructions.
+#include <type_traits>
+
+#include "common.h"
+
+namespace ffn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kBlockVecs16 = 1024;                  // one K block of weights: 8 tiles x (hi, lo) x 64 lanes x 16 B
+constexpr int kRingBlocks16 = 8;                    // LDS ring: two chunks of four K blocks (128 KiB)
+constexpr int kBiasFloats16 = 4096;
+constexpr size_t kLdsBytes16 = (size_t)kRingBlocks16 * kBlockVecs16 * 16 + kEncTableBytes + kBiasFloats16 * 4;
+
+// ---------------------------------------------------------------------------------- pack
+// dst[(((G*tiles + o)*2 + part)*64 + lane)*8 + j] = part(src[32*o + (lane & 31)][col_map[16*G + 8*(lane >> 5) + j]])
+// (rows past the matrix are zero: the forward kernel always runs tiles = 8)
+// part 0 = bf16(v) (round to nearest even), part 1 = bf16(v - float(part 0)).
+__global__ void __launch_bounds__(256)
+pack_bf16_kernel(const float* __restrict__ src, int rows, int cols, int ld,
+                 const int32_t* __restrict__ col_map, int kblocks, int tiles,
+                 uint16_t* __restrict__ dst) {
+    const int64_t total = (int64_t)kblocks * tiles * 64 * 8;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(e & 7);
+        const int lane = (int)((e >> 3) & 63);
+        const int64_t go = e >> 9;
+        const int o = (int)(go % tiles);
+        const int G = (int)(go / tiles);
+        const int r = 32 * o + (lane & 31);
+        const int c = col_map[16 * G + 8 * (lane >> 5) + j];
+        float v = 0.0f;
+        if (c >= 0 && r < rows && c < cols) v = src[(int64_t)r * ld + c];
+        const __bf16 hi = (__bf16)v;
+        const __bf16 lo = (__bf16)(v - (float)hi);
+        const int64_t base = ((go * 2) * 64 + lane) * 8 + j;
+        dst[base] = __builtin_bit_cast(uint16_t, hi);
+        dst[base + 64 * 8] = __builtin_bit_cast(uint16_t, lo);
+    }
+}
+
+// ---------------------------------------------------------------------------------- helpers
+__device__ __forceinline__ void split8(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 h = (__bf16)x[j];
+        hi[j] = h;
+        lo[j] = (__bf16)(x[j] - (float)h);
+    }
+}
+
+struct Enc16 {
+    const float* tab;   // LDS: rows b0 | b1 | b2 | a, kEncRowPitch floats each
+    int F, raw;
+    float scale;
+};
+
+// The 8 internal feature channels 16*G + 8*h + j (j = 0..7) of this lane's sample: frequencies
+// 8G + 4h + {0,1,2,3}, (cos, sin) interleaved; channels 2F..2F+2 are the raw inputs.
+template <bool TRIG_ONLY>
+__device__ __forceinline__ void features16(const Enc16& enc, int G, int h, float x0, float x1,
+                                           float x2, float (&v)[8]) {
+    const int k0 = 8 * G + 4 * h;
+    const int kk = k0 < kEncRowPitch - 4 ? k0 : kEncRowPitch - 4;
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(enc.tab + kk);
+    const f32x4 b1 = *reinterpret_cast<const f32x4*>(enc.tab + kEncRowPitch + kk);
+    const f32x4 b2 = *reinterpret_cast<const f32x4*>(enc.tab + 2 * kEncRowPitch + kk);
+    const f32x4 amp = *reinterpret_cast<const f32x4*>(enc.tab + 3 * kEncRowPitch + kk);
+    const f32x4 s0 = (f32x4)(enc.scale * x0), s1 = (f32x4)(enc.scale * x1), s2 = (f32x4)(enc.scale * x2);
+    // same operation order as the f32 kernel: mul, fma, fma
+    f32x4 ang = b0 * s0;
+    ang = __builtin_elementwise_fma(s1, b1, ang);
+    ang = __builtin_elementwise_fma(s2, b2, ang);
+    f32x4 sn, cs;
+    fast_sincos_n<f32x4, 4>(ang, sn, cs);
+    const f32x4 c = amp * cs, s = amp * sn;
+    if (TRIG_ONLY) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[2 * i] = c[i]; v[2 * i + 1] = s[i]; }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = k0 + i;
+        const int off = 2 * (k - enc.F);
+        const float raw_even = (enc.raw && off == 0) ? x0 : ((enc.raw && off == 2) ? x2 : 0.0f);
+        const float raw_odd = (enc.raw && off == 0) ? x1 : 0.0f;
+        const bool trig = k < enc.F;
+        v[2 * i] = trig ? c[i] : raw_even;
+        v[2 * i + 1] = trig ? s[i] : raw_odd;
+    }
+}
+
+struct Ctx16 {
+    int lane, h, s, tid;
+    float x0, x1, x2, v0, v1, v2;
+    float logit[4];
+    f32x4* wbuf;              // LDS: ring of kRingBlocks16 weight K blocks
+    const float* enc_table;   // LDS
+    const float* bias_lds;    // LDS
+    const f32x4* gweights;    // all K blocks of the chain, back to back (16 KiB each)
+    int total_kb;             // K blocks of the whole chain
+    int flat;                 // next K block of the chain (0 .. total_kb-1)
+    unsigned ring;            // running K-block counter: ring slot = ring & 7
+};
+
+__device__ __forceinline__ void lockstep_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
+// One dense step.  cur_hi / cur_lo: the step's activation
+// input as bf16 pairs, K block G = channels 16G..16G+15 in the hand-off order; overwritten with
+// the step's output.  Every step runs all eight output tiles (narrower layers are zero-padded
+// by the pack: one instantiation -- a second one costs hipcc 1.5 KB of scratch per lane -- and
+// 1/24 more matrix work on the full NeRF); the tiles past the layer's width get no bias, no
+// head terms, and are never consumed.
+constexpr int OT = 8;
+__device__ __forceinline__ void step16(const ffn_mlp_chain& ch, const ffn_step& L, Ctx16& w,
+                                       bf16x8 (&cur_hi)[16], bf16x8 (&cur_lo)[16], f32x4 (&stage)[2][4],
+                                       bf16x8 (&wh)[2][8], bf16x8 (&wl)[2][8]) {
+    const int ot = L.out_tiles;                    // real tiles of this layer
+    const int kb_act = L.act_groups >> 1, kb_feat = L.aux_groups >> 1;
+
+    f32x16 acc[OT];
+    {
+        const float* bv = w.bias_lds + L.b_off + 4 * w.h;
+#pragma unroll
+        for (int o = 0; o < OT; ++o)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 b4 = *reinterpret_cast<const f32x4*>(bv + (o < ot ? 32 * o + 8 * q : 0));
+                if (o >= ot) b4 = (f32x4)(0.0f);
+#pragma unroll
+                for (int p = 0; p < 4; ++p) acc[o][4 * q + p] = b4[p];
+            }
+    }
+
+    // One K block (ring position g).  Its weight operands were read from LDS into register set
+    // PAR one block ago; while its 24 matrix instructions run, (1) the operands of block g+1 stream
+    // from LDS into set 1-PAR -- four waves in lockstep read 64 KiB per block, ~500 cycles of LDS
+    // time that would otherwise sit in front of the matrix pipe -- and (2) the weights of block g+5
+    // (cyclically: the next pass starts over) come in from L2 and are deposited into ring slot
+    // (g+5) & 7 (requested from L2 one block earlier).  ONE workgroup barrier per four K blocks: a block deposited at g is behind a barrier
+    // by g+4, i.e. readable during g+4 for g+5, and slot (g+5) & 7 was last read during g-4.
+    // Every layer has an even number of K blocks, so PAR is a compile-time property of the call site.
+    auto do_chunk = [&](const bf16x8& bh, const bf16x8& bl, auto par_tag) {
+        constexpr int PAR = decltype(par_tag)::value;
+        // (the L2 request for block g+6 goes out now and is deposited at the end of block g+1:
+        // two blocks of latency tolerance)
+        int ahead = w.flat + 6;
+        ahead = ahead < w.total_kb ? ahead : ahead - w.total_kb;
+        ahead = ahead < w.total_kb ? ahead : ahead - w.total_kb;
+        const f32x4* src = w.gweights + (int64_t)ahead * kBlockVecs16 + w.tid;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) stage[PAR][i] = src[256 * i];
+        const f32x4* nl = w.wbuf + ((w.ring + 1u) & 7u) * kBlockVecs16 + w.lane;
+#pragma unroll
+        for (int o = 0; o < OT; ++o) {
+            wh[1 - PAR][o] = __builtin_bit_cast(bf16x8, nl[(2 * o) * 64]);
+            wl[1 - PAR][o] = __builtin_bit_cast(bf16x8, nl[(2 * o + 1) * 64]);
+        }
+        // three products, tile-major: consecutive matrix instructions hit different accumulators
+#pragma unroll
+        for (int o = 0; o < OT; ++o) acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[PAR][o], bl, acc[o], 0, 0, 0);
+#pragma unroll
+        for (int o = 0; o < OT; ++o) acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[PAR][o], bh, acc[o], 0, 0, 0);
+#pragma unroll
+        for (int o = 0; o < OT; ++o) acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[PAR][o], bh, acc[o], 0, 0, 0);
+        f32x4* dst = w.wbuf + ((w.ring + 5u) & 7u) * kBlockVecs16 + w.tid;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dst[256 * i] = stage[1 - PAR][i];
+        if ((w.ring & 3u) == 3u) lockstep_barrier();
+        w.ring += 1u;
+        w.flat = w.flat + 1 < w.total_kb ? w.flat + 1 : 0;
+    };
+    using even = std::integral_constant<int, 0>;
+    using odd = std::integral_constant<int, 1>;
+
+#pragma unroll
+    for (int G = 0; G < 16; G += 2)
+        if (G < kb_act) {
+            do_chunk(cur_hi[G], cur_lo[G], even{});
+            do_chunk(cur_hi[G + 1], cur_lo[G + 1], odd{});
+        }
+    if (kb_feat > 0) {
+        Enc16 enc;
+        const ffn_encoding& e = ch.enc[L.enc_id];
+        enc.tab = w.enc_table + L.enc_id * kEncTablePitch;
+        enc.F = e.num_freq;
+        enc.raw = (e.include_input != 0 || e.num_freq == 0) ? 1 : 0;
+        enc.scale = e.scale;
+        const float p0 = L.enc_id == 0 ? w.x0 : w.v0;
+        const float p1 = L.enc_id == 0 ? w.x1 : w.v1;
+        const float p2 = L.enc_id == 0 ? w.x2 : w.v2;
+        // K blocks whose eight frequencies (both lane halves) are all real ones take the
+        // select-free feature code; the tail (raw inputs, padding) the generic one
+        int g_trig = e.num_freq >> 3;
+        g_trig = g_trig < kb_feat ? g_trig : kb_feat;
+        for (int G = 0; G < kb_feat; G += 2) {
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                float f[8];
+                if (G + sub < g_trig) features16<true>(enc, G + sub, w.h, p0, p1, p2, f);
+                else features16<false>(enc, G + sub, w.h, p0, p1, p2, f);
+                bf16x8 fh, fl;
+                split8(f, fh, fl);
+                if (sub == 0) do_chunk(fh, fl, even{});
+                else do_chunk(fh, fl, odd{});
+            }
+        }
+    }
+    // ---- epilogue: ReLU, fused head, hand-off as bf16 pairs
+    const bool fused_head = L.head_off >= 0;
+    const float* hw = w.bias_lds + (fused_head ? L.head_off : 0) + 4 + 16 * w.h;
+    if (fused_head && w.h == 0) {
+        const f32x4 hb = *reinterpret_cast<const f32x4*>(w.bias_lds + L.head_off);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) w.logit[c] += hb[c];
+    }
+    const int relu_floor = L.relu ? 0 : (int)0x80000000;
+#pragma unroll
+    for (int o = 0; o < OT; ++o) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            float y[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float t = acc[o][8 * half + j];
+                y[j] = __builtin_bit_cast(float, __builtin_elementwise_max(__builtin_bit_cast(int, t), relu_floor));
+            }
+            if (fused_head && o < ot) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    // register 8*half + j = channel 32o + 8q + 4h + p with q = 2*half + j/4, p = j%4
+                    const int group = 4 * o + 2 * half + (j >> 2);
+                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(hw + group * 32 + (j & 3) * 4);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) w.logit[c] = __builtin_fmaf(y[j], w4[c], w.logit[c]);
+                }
+            }
+            split8(y, cur_hi[2 * o + half], cur_lo[2 * o + half]);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256, 1)
+mlp_forward_bf16_kernel(const ffn_mlp_chain ch, const uint16_t* __restrict__ packed,
+                        const float* __restrict__ bias, const float* __restrict__ positions,
+                        const float* __restrict__ views, int64_t n, float* __restrict__ logits) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* enc_table = reinterpret_cast<float*>(smem + (size_t)kRingBlocks16 * kBlockVecs16 * 16);
+    float* bias_lds = reinterpret_cast<float*>(smem + (size_t)kRingBlocks16 * kBlockVecs16 * 16 + kEncTableBytes);
+    stage_encoding_tables(ch.enc, enc_table, threadIdx.x, 256);
+    for (int i = threadIdx.x; i < ch.bias_floats; i += 256) bias_lds[i] = bias[i];
+    Ctx16 w;
+    w.tid = threadIdx.x;
+    w.lane = threadIdx.x & 63;
+    w.h = w.lane >> 5;
+    w.s = w.lane & 31;
+    w.wbuf = reinterpret_cast<f32x4*>(smem);
+    w.enc_table = enc_table;
+    w.bias_lds = bias_lds;
+    w.gweights = reinterpret_cast<const f32x4*>(packed + ch.step[0].w_off);
+    w.total_kb = 0;
+    for (int li = 0; li < ch.num_steps; ++li) w.total_kb += (ch.step[li].act_groups + ch.step[li].aux_groups) >> 1;
+    w.flat = 0;
+    w.ring = 0u;
+    // the first five K blocks of the chain go into ring slots 0..4; from then on every K block
+    // requests the one five positions ahead (the weight stream is cyclic over the passes)
+    for (int b = 0; b < 5; ++b) {
+        const int fb = b % w.total_kb;
+        for (int i = 0; i < 4; ++i)
+            w.wbuf[b * kBlockVecs16 + w.tid + 256 * i] = w.gweights[(int64_t)fb * kBlockVecs16 + w.tid + 256 * i];
+    }
+    __syncthreads();
+    // the first block deposits what "the block before it" requested: block 5's weights
+    f32x4 stage[2][4];
+    {
+        const int fb = 5 % w.total_kb;
+        for (int i = 0; i < 4; ++i) stage[1][i] = w.gweights[(int64_t)fb * kBlockVecs16 + w.tid + 256 * i];
+    }
+    bf16x8 wh[2][8], wl[2][8];          // weight operands: set (g & 1) belongs to ring position g
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+        wh[0][o] = __builtin_bit_cast(bf16x8, w.wbuf[(2 * o) * 64 + w.lane]);
+        wl[0][o] = __builtin_bit_cast(bf16x8, w.wbuf[(2 * o + 1) * 64 + w.lane]);
+    }
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t num_blocks = (n + 31) / 32;
+    const int64_t groups = (num_blocks + 3) / 4;            // 4 blocks (one per wave) per pass
+    // the inputs of a pass are requested one pass ahead (an HBM round trip is ~5 % of a pass)
+    float in_next[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto request_inputs = [&](int64_t pass) {
+        int64_t block = pass * 4 + wave;
+        block = block < num_blocks ? block : num_blocks - 1;
+        const int64_t sample = block * 32 + w.s;
+        const int64_t src = sample < n ? sample : n - 1;
+        in_next[0] = positions[src * 3 + 0]; in_next[1] = positions[src * 3 + 1]; in_next[2] = positions[src * 3 + 2];
+        if (views != nullptr) {
+            in_next[3] = views[src * 3 + 0]; in_next[4] = views[src * 3 + 1]; in_next[5] = views[src * 3 + 2];
+        }
+    };
+    request_inputs(blockIdx.x);
+    for (int64_t pass = blockIdx.x; pass < groups; pass += gridDim.x) {
+        const int64_t block = pass * 4 + wave;
+        const bool active = block < num_blocks;
+        const int64_t sample = (active ? block : num_blocks - 1) * 32 + w.s;
+        w.x0 = in_next[0]; w.x1 = in_next[1]; w.x2 = in_next[2];
+        w.v0 = in_next[3]; w.v1 = in_next[4]; w.v2 = in_next[5];
+        request_inputs(pass + gridDim.x < groups ? pass + gridDim.x : pass);
+        w.logit[0] = w.logit[1] = w.logit[2] = w.logit[3] = 0.0f;
+        bf16x8 cur_hi[16], cur_lo[16];
+#pragma unroll
+        for (int G = 0; G < 16; ++G) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { cur_hi[G][j] = (__bf16)0.0f; cur_lo[G][j] = (__bf16)0.0f; }
+        }
+        for (int li = 0; li < ch.num_steps; ++li) step16(ch, ch.step[li], w, cur_hi, cur_lo, stage, wh, wl);
+        f32x4 out;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) out[c] = w.logit[c] + __shfl_xor(w.logit[c], 32);
+        if (w.h == 0 && active && sample < n) reinterpret_cast<f32x4*>(logits)[sample] = out;
+    }
+}
+
+}  // namespace ffn
+
+using namespace ffn;
+
+extern "C" int ffn_mlp_pack_bf16(const float* src, int rows, int cols, int ld, const int32_t* col_map,
+                                 int kblocks, int tiles, uint16_t* dst, void* stream) {
+    if (kblocks <= 0 || tiles <= 0 || col_map == nullptr) return fail_arg("ffn_mlp_pack_bf16: shape");
+    const int64_t total = (int64_t)kblocks * tiles * 512;
+    int64_t grid = (total + 255) / 256;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(pack_bf16_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, src, rows,
+                       cols, ld, col_map, kblocks, tiles, dst);
+    return check_launch("ffn_mlp_pack_bf16");
+}
+
+extern "C" int ffn_mlp_forward_bf16x3(const ffn_mlp_chain* chain, const uint16_t* packed_w,
+                                      const float* bias, const float* positions, const float* views,
+                                      int64_t n, float* logits, void* stream) {
+    if (n == 0) return 0;
+    if (n < 0 || chain == nullptr || chain->num_steps < 1 || chain->num_steps > FFN_MAX_STEPS)
+        return fail_arg("ffn_mlp_forward_bf16x3: bad chain or size");
+    if (chain->wide || chain->bias_floats < 0 || chain->bias_floats > kBiasFloats16)
+        return fail_arg("ffn_mlp_forward_bf16x3: narrow chains only");
+    for (int i = 0; i < chain->num_steps; ++i) {
+        const ffn_step& L = chain->step[i];
+        const int ot = L.out_tiles;
+        if (!(ot == 1 || ot == 2 || ot == 4 || ot == 8) || L.dst != 0 || (L.act_groups & 3) ||
+            (L.aux_groups & 3) || L.act_groups < 0 || L.act_groups > 32 || L.aux_groups < 0 ||
+            L.act_groups + L.aux_groups == 0 || (L.aux_groups > 0 && (L.enc_id < 0 || L.enc_id > 1)))
+            return fail_arg("ffn_mlp_forward_bf16x3: unsupported step (slab-destination steps with "
+                            "fused heads only)");
+    }
+    const int64_t groups = ((n + 31) / 32 + 3) / 4;
+    int cus = 256;
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    const int64_t grid = groups < cus ? groups : cus;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_forward_bf16_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes16);
+    hipLaunchKernelGGL(mlp_forward_bf16_kernel, dim3((unsigned)grid), dim3(256), kLdsBytes16,
+                       (hipStream_t)stream, *chain, packed_w, bias, positions, views, n, logits);
+    return check_launch("ffn_mlp_forward_bf16x3");
+}

@@ -202,6 +202,7 @@ class MlpProgram:
         self._build_forward()
         self._build_backward()
         self._build_wgrad_jobs()
+        self._build_forward16()
 
     # ------------------------------------------------------------------ chains
     def _fill_encodings(self, chain):
@@ -338,6 +339,45 @@ class MlpProgram:
         self.num_grad_floats = g_off
         self.packed_fwd = torch.zeros((max(w_off, 1),), dtype=torch.float32, device=self.device)
         self.bias_buf = torch.zeros((b_off,), dtype=torch.float32, device=self.device)
+
+    def _build_forward16(self):
+        """Chain + operand buffer of the OPT-IN split-bf16 inference kernel (mlp_bf16.hip): the
+        forward chain with its weight offsets pointing into a bf16 (hi, lo) operand buffer whose
+        K order is the register hand-off order of that kernel.  ``self.fwd16`` stays None for
+        chains it does not cover (512-wide layers, MFMA logits steps)."""
+        self.fwd16 = None
+        self.packed16 = None
+        self._packed16_dirty = True
+        if self.wide or self.device.type != "cuda":
+            return
+        steps = [(i, self.fwd.step[self.step_of[i]]) for i in range(len(self.layers))
+                 if self.step_of[i] is not None]
+        if any(st.dst != 0 for _, st in steps):
+            return
+        chain = FfnMlpChain.from_buffer_copy(bytes(self.fwd))
+        self.pack16_jobs = []          # (layer index, kblocks, col map tensor, element offset)
+        off = 0
+        for i, st in steps:
+            spec = self.layers[i]
+            enc = None if spec.enc_id is None else self.encodings[spec.enc_id]
+            kb_act = spec.act_in // 16
+            kb_feat = 0 if enc is None else enc.width // 16
+            cmap = []
+            for g in range(kb_act):
+                for h in range(2):
+                    for j in range(8):
+                        cmap.append(16 * g + (4 * h + j if j < 4 else 8 + 4 * h + (j - 4)))
+            for g in range(kb_feat):
+                for h in range(2):
+                    for j in range(8):
+                        nat = enc.natural_index(16 * g + 8 * h + j)
+                        cmap.append(-1 if nat < 0 else spec.act_in + nat)
+            kblocks = kb_act + kb_feat
+            chain.step[self.step_of[i]].w_off = off
+            self.pack16_jobs.append((i, kblocks, torch.tensor(cmap, dtype=torch.int32, device=self.device), off))
+            off += kblocks * 8 * 1024            # 8 tiles x (hi, lo) x 64 lanes x 8 bf16
+        self.fwd16 = chain
+        self.packed16 = torch.zeros((max(off, 1),), dtype=torch.int16, device=self.device)
 
     def _build_backward(self):
         """Backward-data chain: one step per producer layer that has consumers, walking
@@ -513,8 +553,33 @@ class MlpProgram:
                     reduce_jobs=reduce_jobs, slots=slot)
 
     # ------------------------------------------------------------------ packing
+    def pack16(self):
+        """(hi, lo) bf16 operand copies of the current weights for the split-bf16 kernel."""
+        for (i, kblocks, cmap, off) in self.pack16_jobs:
+            w = self.layers[i].weight.detach()
+            dst = self.packed16[off:off + kblocks * 8 * 1024]
+            _call("ffn_mlp_pack_bf16", _dev(w), c_i(w.shape[0]), c_i(w.shape[1]), c_i(w.stride(0)),
+                  _dev(cmap, torch.int32), c_i(kblocks), c_i(8), _dev(dst, torch.int16))
+        self._packed16_dirty = False
+
+    def forward16(self, positions: torch.Tensor, views: Optional[torch.Tensor]) -> torch.Tensor:
+        """Inference in the opt-in split-bf16 mode (3 bf16 matrix products per f32 product):
+        positions (N,3) [views (N,3)] -> raw logits (N,4)."""
+        if self.fwd16 is None:
+            raise NotImplementedError("the split-bf16 kernel covers chains of <= 256 channels whose "
+                                      "logits heads are fused")
+        if self._packed16_dirty:
+            self.pack16()
+        n = positions.shape[0]
+        logits = torch.empty((n, 4), dtype=torch.float32, device=self.device)
+        _call("ffn_mlp_forward_bf16x3", ctypes.byref(self.fwd16), _dev(self.packed16, torch.int16),
+              _dev(self.bias_buf), _dev(positions, name="positions"), _dev(views, name="views"),
+              c_i64(n), _dev(logits))
+        return logits
+
     def pack(self):
         """Re-derives the MFMA-operand copies from the current nn.Linear weights."""
+        self._packed16_dirty = True
         for i, spec in enumerate(self.layers):
             if self.step_of[i] is None:
                 continue

@@ -35,7 +35,10 @@ class _FusedChainFunction(torch.autograd.Function):
         if track:
             saved = torch.empty((prog.saved_floats(positions.shape[0]),), dtype=torch.float32,
                                 device=positions.device)
-        logits = prog.forward(positions, views, saved)
+        if not track and module.precision == "bf16x3":
+            logits = prog.forward16(positions, views)       # opt-in fast inference mode
+        else:
+            logits = prog.forward(positions, views, saved)
         ctx.module = module
         ctx.saved_acts = saved
         ctx.save_for_backward(positions, views)
@@ -68,6 +71,9 @@ class _FusedModel(nn.Module):
         nn.Module.__init__(self)
         self._prog: Optional[MlpProgram] = None
         self._packed_key = None
+        # "f32": exact-f32 MFMA everywhere (the parity mode).  "bf16x3": OPT-IN split-bf16
+        # matrix products for INFERENCE calls (no_grad / eval renders); training always runs f32.
+        self.precision = "f32"
 
     def _chain(self, device):   # -> (encodings, dense specs)
         raise NotImplementedError

@@ -353,6 +353,25 @@ int ffn_focus_fused(const ffn_mlp_chain* chain, const float* packed_w, const flo
                     int num_samples, int n_focus, const float* unit_focus, const float* u,
                     float* t_io, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * OPT-IN split-bf16 inference mode of K4 (separately labelled; the exact-f32 entry points above
+ * are the parity mode).  Every f32 operand is split into two bf16 parts and every product into
+ * three v_mfma_f32_32x32x16_bf16 instructions with f32 accumulation (~2^-16 relative error per
+ * product).  The chain is an ffn_mlp_chain whose w_off are offsets (in bf16 elements) into the
+ * operand buffer written by ffn_mlp_pack_bf16; bias / fused-head blocks are the f32 buffer of
+ * ffn_mlp_forward.  Narrow chains (<= 256 channels), slab-destination steps with fused heads.
+ *
+ * ffn_mlp_pack_bf16: dst[(((G*tiles + o)*2 + part)*64 + lane)*8 + j] =
+ *   part(src[32*o + (lane & 31)][col_map[16*G + 8*(lane >> 5) + j]]), part 0 = bf16(v) rounded to
+ *   nearest even, part 1 = bf16(v - part 0); col_map (int32, device, 16*kblocks entries) maps the
+ *   operand K order to natural columns (-1 = zero): for activation K blocks the hand-off order
+ *   16G + {4h+j | 8+4h+(j-4)}, for encoding K blocks the internal feature order 16G + 8h + j. */
+int ffn_mlp_pack_bf16(const float* src, int rows, int cols, int ld, const int32_t* col_map,
+                      int kblocks, int tiles, uint16_t* dst, void* stream);
+int ffn_mlp_forward_bf16x3(const ffn_mlp_chain* chain, const uint16_t* packed_w, const float* bias,
+                           const float* positions, const float* views, int64_t n, float* logits,
+                           void* stream);
+
 /* Backward-data chain: d_logits (N,4) + ReLU sign masks -> dZ slabs (same slab geometry as
  * `saved`).  packed_wt holds the transposed operand packs. */
 int ffn_mlp_backward_data(const ffn_mlp_chain* chain, const float* packed_wt,

@@ -4,7 +4,7 @@ mkdir -p gpurun_out/ab
 for rep in 1 2; do
   for lib in base new; do
     if [ $lib = base ]; then export FFN_HIP_LIBRARY=$PWD/scripts/probes/variants/libffn_base.so; else unset FFN_HIP_LIBRARY; fi
-    python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-config3 --no-config5 --no-skip-leg --no-target-shape --no-render > gpurun_out/ab/${lib}_${rep}.json 2> gpurun_out/ab/${lib}_${rep}.err
+    python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-config3 --no-config5 --no-skip-leg --no-bf16-leg --no-target-shape --no-render > gpurun_out/ab/${lib}_${rep}.json 2> gpurun_out/ab/${lib}_${rep}.err
     python - <<PY
 import json
 b = json.loads(open("gpurun_out/ab/${lib}_${rep}.json").read().strip().split("\n")[-1])

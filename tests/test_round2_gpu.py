@@ -702,3 +702,59 @@ def test_fused_focus_kernel_equals_the_five_launch_live_path(golden):
     smp = _quiet(ffn.RaySampler, data["bounds"], cams, 16, False, wide, 64, device=dev(), focus_mode="live")
     assert not smp._can_fuse_focus(8)
     assert smp.sample_t(idx, None).shape == (idx.numel(), 16)
+
+
+# ----------------------------------------------------------------------------------- split-bf16 inference
+@pytest.mark.parametrize("name", ["mlp", "basic", "positional", "gaussian", "nerf", "nerf_small"])
+def test_split_bf16_inference_mode(golden, name):
+    """OPT-IN `model.precision = "bf16x3"` (three bf16 matrix products per f32 product, f32
+    accumulation; inference calls only): logits within 2e-4 of the exact-f32 kernel AND of the
+    reference's outputs on the golden fixtures (f32 mode: 3e-5), bit-for-bit batch independent;
+    training calls keep using the f32 kernels."""
+    from tests.test_kernels_gpu import _load_fourier, _load_nerf
+    g = golden("models")
+    if name.startswith("nerf"):
+        model, _ = _load_nerf(g, name, [4] if name == "nerf" else [2], name == "nerf")
+        args = (_t(g["x"]).to(dev()), _t(g["v"]).to(dev()))
+    else:
+        model, _ = _load_fourier(g, name)
+        args = (_t(g["x"]).to(dev()),)
+    with torch.no_grad():
+        exact = model(*args)
+        model.precision = "bf16x3"
+        fast = model(*args)
+        scale = float(exact.abs().max())
+        err = float((fast - exact).abs().max())
+        assert err <= 2e-4 * max(scale, 1.0), (err, scale)
+        np.testing.assert_allclose(fast.cpu().numpy(), g[name + "/out"], rtol=2e-4, atol=2e-4 * max(scale, 1.0))
+        assert err > 0.0                                        # it IS a different arithmetic
+        # ragged sizes, batch independence
+        torch.manual_seed(3)
+        for n in (1, 33, 127, 129, 1000):
+            x = torch.rand(n, 3, device=dev()) * 2 - 1
+            extra = (torch.nn.functional.normalize(torch.randn(n, 3, device=dev()), dim=1),) if len(args) == 2 else ()
+            y = model(x, *extra)
+            assert y.shape == (n, 4) and bool(torch.isfinite(y).all())
+            pick = torch.tensor([0, n // 2, n - 1], device=dev())
+            sub = model(x[pick].contiguous(), *[e[pick].contiguous() for e in extra])
+            assert torch.equal(y[pick], sub)
+    # a gradient-tracking call goes through the exact kernels whatever the precision flag says
+    y = model(*args)
+    model.precision = "f32"
+    assert torch.equal(y.detach(), model(*args).detach())
+
+
+def test_split_bf16_render_psnr(golden):
+    """Frames rendered in the split-bf16 mode against the exact-f32 frames: > 60 dB."""
+    import fourier_feature_nets_amd as ffn
+    from tests.test_kernels_gpu import _load_fourier
+    model, _ = _load_fourier(golden("models"), "positional")
+    caster = ffn.Raycaster(model)
+    sampler = _scene_sampler(64)
+    exact = caster.render_image(sampler, 0, 4096).astype(np.float64)
+    model.precision = "bf16x3"
+    assert not caster._can_fuse(sampler)          # the fused render kernel is f32 only
+    fast = caster.render_image(sampler, 0, 4096).astype(np.float64)
+    model.precision = "f32"
+    mse = np.mean((exact - fast) ** 2)
+    assert 10 * np.log10(255.0 ** 2 / max(mse, 1e-12)) > 60.0
