@@ -166,8 +166,9 @@ __device__ __forceinline__ void step16(const ffn_mlp_chain& ch, const ffn_step& 
     // (g+5) & 7 (requested from L2 one block earlier).  ONE workgroup barrier per four K blocks: a block deposited at g is behind a barrier
     // by g+4, i.e. readable during g+4 for g+5, and slot (g+5) & 7 was last read during g-4.
     // Every layer has an even number of K blocks, so PAR is a compile-time property of the call site.
-    auto do_chunk = [&](const bf16x8& bh, const bf16x8& bl, auto par_tag) {
+    auto do_chunk = [&](const bf16x8& bh, const bf16x8& bl, auto par_tag, auto&& side_work, auto side_tag) {
         constexpr int PAR = decltype(par_tag)::value;
+        constexpr bool SIDE = decltype(side_tag)::value;      // vector work to run under the MFMAs
         // (the L2 request for block g+6 goes out now and is deposited at the end of block g+1:
         // two blocks of latency tolerance)
         int ahead = w.flat + 6;
@@ -192,6 +193,22 @@ __device__ __forceinline__ void step16(const ffn_mlp_chain& ch, const ffn_step& 
         f32x4* dst = w.wbuf + ((w.ring + 5u) & 7u) * kBlockVecs16 + w.tid;
 #pragma unroll
         for (int i = 0; i < 4; ++i) dst[256 * i] = stage[1 - PAR][i];
+        side_work();     // (the NEXT feature block's sincos + bf16 split, when there is one)
+        // issue order: one memory instruction behind each matrix instruction -- 16 operand reads
+        // (+ 4 table reads of the side work), 4 L2 requests, 4 deposits spread over the block's 24
+        // MFMAs -- and the side work's vector instructions in the gaps (the bf16 matrix pipe and
+        // the vector ALU run side by side, but an in-order wave only overlaps what is interleaved
+        // in program order).  Left to itself hipcc clusters the 16 ds_read_b128 in front of the
+        // MFMAs, and a wave that spends ~200 cycles issuing LDS reads lets the matrix pipe run dry.
+        constexpr int kDsReads = SIDE ? 20 : 16;
+#pragma unroll
+        for (int i = 0; i < 24; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (i < kDsReads) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            else __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            if (i >= 16 && i < 20) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            if (SIDE) __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+        }
         if ((w.ring & 3u) == 3u) lockstep_barrier();
         w.ring += 1u;
         w.flat = w.flat + 1 < w.total_kb ? w.flat + 1 : 0;
@@ -202,8 +219,8 @@ __device__ __forceinline__ void step16(const ffn_mlp_chain& ch, const ffn_step& 
 #pragma unroll
     for (int G = 0; G < 16; G += 2)
         if (G < kb_act) {
-            do_chunk(cur_hi[G], cur_lo[G], even{});
-            do_chunk(cur_hi[G + 1], cur_lo[G + 1], odd{});
+            do_chunk(cur_hi[G], cur_lo[G], even{}, [] {}, std::false_type{});
+            do_chunk(cur_hi[G + 1], cur_lo[G + 1], odd{}, [] {}, std::false_type{});
         }
     if (kb_feat > 0) {
         Enc16 enc;
@@ -219,6 +236,8 @@ __device__ __forceinline__ void step16(const ffn_mlp_chain& ch, const ffn_step& 
         // select-free feature code; the tail (raw inputs, padding) the generic one
         int g_trig = e.num_freq >> 3;
         g_trig = g_trig < kb_feat ? g_trig : kb_feat;
+        // (computing block G+1's features under block G's matrix instructions was measured: the
+        // interleaved issue made the block 4 % SLOWER on this compiler, so the features run between blocks)
         for (int G = 0; G < kb_feat; G += 2) {
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
@@ -227,8 +246,8 @@ __device__ __forceinline__ void step16(const ffn_mlp_chain& ch, const ffn_step& 
                 else features16<false>(enc, G + sub, w.h, p0, p1, p2, f);
                 bf16x8 fh, fl;
                 split8(f, fh, fl);
-                if (sub == 0) do_chunk(fh, fl, even{});
-                else do_chunk(fh, fl, odd{});
+                if (sub == 0) do_chunk(fh, fl, even{}, [] {}, std::false_type{});
+                else do_chunk(fh, fl, odd{}, [] {}, std::false_type{});
             }
         }
     }
