@@ -1,4 +1,4 @@
-"""Folds the two rocprofv3 PMC passes of scripts/pmc_traffic.sh into profiles/*.json:
+"""Folds the FETCH_SIZE / WRITE_SIZE passes of scripts/gpu/profile_round2.sh into profiles/*.json:
 
     python scripts/pmc_traffic_summary.py gpurun_out/traffic profiles/r02_hbm_traffic.json [commit]
 
