@@ -758,3 +758,51 @@ def test_split_bf16_render_psnr(golden):
     model.precision = "f32"
     mse = np.mean((exact - fast) ** 2)
     assert 10 * np.log10(255.0 ** 2 / max(mse, 1e-12)) > 60.0
+
+
+# ----------------------------------------------------------------------------------- edge cases
+def test_round2_edge_cases(golden, tmp_path):
+    """Empty ray lists, an all-empty occupancy grid in rendering and training, FrameSink argument
+    checks and error propagation."""
+    import fourier_feature_nets_amd as ffn
+    from tests.test_pipeline_gpu import _small_model
+    g = golden("training")
+    model = _small_model(g)
+    caster = ffn.Raycaster(model)
+    sampler = _scene_sampler(32)
+    none = torch.zeros((0,), dtype=torch.int64, device=dev())
+    with torch.no_grad():
+        out = caster.render_rays(sampler, none, include_depth=True)
+    assert out.color.shape == (0, 3) and out.alpha.shape == (0,) and out.depth.shape == (0,)
+    # a grid with no occupied cell: every ray is empty space -> black, alpha 0, depth = last t
+    data = np.load(SCENE)
+    centres = ffn.OccupancyGrid.cell_centres(data["bounds"], 8, dev())
+    logits = torch.full((centres.shape[0], 4), -50.0, device=dev())
+    empty = ffn.OccupancyGrid.from_logits(logits, data["bounds"], 8, 0.01, False)
+    assert empty.fraction_occupied() == 0.0
+    caster.occupancy = empty
+    rays = sampler.valid_index(torch.arange(0, sampler.num_rays, 5, device=dev()))
+    with torch.no_grad():
+        skipped = caster.render_rays(sampler, rays, include_depth=True)
+        t_last = sampler.sample_t(rays, None)[:, -1]
+    assert float(skipped.color.abs().max()) == 0.0 and float(skipped.alpha.abs().max()) == 0.0
+    assert torch.equal(skipped.depth, t_last)
+    assert caster.render_image(sampler, 0, 64).max() == 0
+    caster.occupancy = None
+    # training with nothing to evaluate: zero gradients, the weights stay put
+    train = _quiet(ffn.ImageDataset.load, SCENE, "train", 16, True, False, device=dev())
+    engine = ffn.TrainEngine(model)
+    before = engine.flat.clone()
+    engine.occupancy = empty
+    loss = float(engine.train_step(train, torch.arange(0, len(train), 4, device=dev()), None, 5e-4))
+    assert math.isfinite(loss) and engine.last_evaluated_fraction == 0.0
+    assert torch.equal(engine.flat, before)
+    # FrameSink
+    with pytest.raises(TypeError):
+        ffn.FrameSink().submit(torch.zeros((4, 4, 3), dtype=torch.uint8), str(tmp_path / "x.png"))
+    with pytest.raises(TypeError):
+        ffn.FrameSink().submit(torch.zeros((4, 4, 3), device=dev()), str(tmp_path / "x.png"))
+    sink = ffn.FrameSink(slots=1, workers=1)
+    sink.submit(torch.zeros((4, 4, 3), dtype=torch.uint8, device=dev()), str(tmp_path / "no_such_dir" / "x.png"))
+    with pytest.raises(Exception):
+        sink.close()
