@@ -110,6 +110,8 @@ int ffn_focus_sample_merge_rows(const float* near_far, int64_t num_rays_total,
  * Replaces fourier_feature_models.py:59-68 (scale = pi, optional a_values) and
  * nerf_model.py:97-102 (scale = 1, include_input appends x).  Output is (N, 2F[+3]),
  * cos block first.  b is (3,F); a is (F) or NULL.  F == 0 copies x (class MLP).
+ * `out` must be 16-byte aligned (rows are assembled in LDS and leave as whole float4 lines);
+ * F <= 2046.
  */
 int ffn_fourier_encode(const float* x, int64_t n, const float* b, const float* a,
                        int num_freq, float scale, int include_input, float* out,

@@ -56,6 +56,15 @@ def main():
     bn = bn.to(dev)
     sec = timed(lambda: ops.fourier_encode(x, bn, None, 1.0, True), iters=5)
     out["fourier_encode (NeRF: 63)"] = (n * (12 + 4 * 63), sec)
+    # what the memory system gives a pure write / a pure copy of the same size (reference points
+    # for the write-dominated encode kernels; not kernels of this library)
+    big = torch.empty(n * 2 * b.shape[1], device=dev)
+    sec = timed(lambda: big.zero_(), iters=5)
+    out["reference: write-only fill of the tiny encode output"] = (big.numel() * 4, sec)
+    half = big[: big.numel() // 2]
+    other = big[big.numel() // 2:]
+    sec = timed(lambda: other.copy_(half), iters=5)
+    out["reference: device copy (read + write)"] = (big.numel() * 4, sec)
     res = {k: {"algorithmic_bytes": v[0], "us": round(v[1] * 1e6, 1),
                "GB/s": round(v[0] / v[1] / 1e9, 1), "of_8TB/s": round(v[0] / v[1] / 8e12, 3)}
            for k, v in out.items()}

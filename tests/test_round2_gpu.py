@@ -806,3 +806,24 @@ def test_round2_edge_cases(golden, tmp_path):
     sink.submit(torch.zeros((4, 4, 3), dtype=torch.uint8, device=dev()), str(tmp_path / "no_such_dir" / "x.png"))
     with pytest.raises(Exception):
         sink.close()
+
+
+# ----------------------------------------------------------------------------------- K3
+@pytest.mark.parametrize("F,inc,n", [(0, True, 1000), (1, False, 77), (7, True, 513),
+                                     (255, False, 4099), (600, True, 301), (30, True, 65537)])
+def test_fourier_encode_shapes_and_tails(F, inc, n):
+    """Odd / even frequency counts, rows narrower than a wave and wider than a block, the
+    pass-through columns and ragged sample counts: every entry against the float64 formula
+    [a cos(s x.B), a sin(s x.B), x] (reference: fourier_feature_nets/fourier_feature_models.py:60-75)."""
+    from fourier_feature_nets_amd import ops
+    gen = torch.Generator().manual_seed(F * 7 + n)
+    x = torch.rand(n, 3, generator=gen) * 2 - 1
+    b = torch.randn(3, F, generator=gen) * 3
+    a = torch.rand(F, generator=gen) + 0.5
+    got = ops.fourier_encode(x.cuda(), b.contiguous().cuda(), a.cuda() if F else None, 1.5, inc)
+    assert got.shape == (n, 2 * F + (3 if inc or F == 0 else 0))
+    ang = (1.5 * x.double()) @ b.double()
+    exp = torch.cat([a.double() * torch.cos(ang), a.double() * torch.sin(ang)]
+                    + ([x.double()] if inc or F == 0 else []), dim=-1)
+    # |angle| up to ~25 rad in f32: half an ulp of the angle is 1e-6
+    np.testing.assert_allclose(got.cpu().double().numpy(), exp.numpy(), rtol=0, atol=6e-6)
