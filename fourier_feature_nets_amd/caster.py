@@ -146,6 +146,7 @@ class TrainEngine:
         per_launch = max(1, self.max_samples // sampler.num_samples)
         if count == 0:
             self.reduce_buf.zero_()
+        precision = getattr(self.model, "train_precision", "f32")
         for lo in range(0, count, per_launch):
             chunk = rays[lo:lo + per_launch]
             first = lo == 0
@@ -157,11 +158,11 @@ class TrainEngine:
                 pos, views, index = self.occupancy.compact(pos, views)
                 self.last_evaluated_fraction = pos.shape[0] / max(total, 1)
                 saved = self._saved_buffer(prog, max(pos.shape[0], 1))
-                packed = prog.forward(pos, views, saved)
+                packed = prog.forward(pos, views, saved, precision=precision)
                 logits = ops.scatter_logits(packed, index, total)
             else:
                 saved = self._saved_buffer(prog, pos.shape[0])
-                logits = prog.forward(pos, views, saved)
+                logits = prog.forward(pos, views, saved, precision=precision)
             color, alpha, _ = ops.composite_fwd(logits, t, False, self.nan_flag)
             part, d_color, d_alpha = ops.mse_loss(color, alpha, dataset.colors, alphas, chunk,
                                                   1.0 / (3 * global_count), aw / global_count,

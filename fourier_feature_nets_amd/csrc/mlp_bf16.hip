@@ -124,7 +124,20 @@ struct Ctx16 {
     int total_kb;             // K blocks of the whole chain
     int flat;                 // next K block of the chain (0 .. total_kb-1)
     unsigned ring;            // running K-block counter: ring slot = ring & 7
+    // training only: where this wave's block saves its activations / ReLU sign masks
+    int64_t block, num_blocks;
+    bool active;
+    float* saved;
+    uint4* masks;
 };
+
+// float4 index of (channel quad cq, sample s) inside a saved-activation block, and the block of
+// a slab slot: the layouts of mlp.hip (the f32 backward kernels read what this kernel saves)
+__device__ __forceinline__ int saved_index16(int cq, int s) { return cq * 32 + (s ^ (cq & 15)); }
+__device__ __forceinline__ f32x4* slab_block16(const ffn_mlp_chain& ch, int slot, const Ctx16& w) {
+    return reinterpret_cast<f32x4*>(w.saved + ch.slot_offset[slot] * w.num_blocks * 32) +
+           w.block * (int64_t)(ch.slot_channels[slot] * 8);
+}
 
 __device__ __forceinline__ void lockstep_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -137,7 +150,12 @@ __device__ __forceinline__ void lockstep_barrier() {
 // by the pack: one instantiation -- a second one costs hipcc 1.5 KB of scratch per lane -- and
 // 1/24 more matrix work on the full NeRF); the tiles past the layer's width get no bias, no
 // head terms, and are never consumed.
+//
+// TRAIN: the step also leaves what the backward pass needs, in the f32 kernels' formats -- the
+// encoding features it generated (step.save_enc_slot), its output (step.reserved = the output's
+// slab slot) and the ReLU sign mask (step.mask_slot).
 constexpr int OT = 8;
+template <bool TRAIN>
 __device__ __forceinline__ void step16(const ffn_mlp_chain& ch, const ffn_step& L, Ctx16& w,
                                        bf16x8 (&cur_hi)[16], bf16x8 (&cur_lo)[16], f32x4 (&stage)[2][4],
                                        bf16x8 (&wh)[2][8], bf16x8 (&wl)[2][8]) {
@@ -244,6 +262,15 @@ __device__ __forceinline__ void step16(const ffn_mlp_chain& ch, const ffn_step& 
                 float f[8];
                 if (G + sub < g_trig) features16<true>(enc, G + sub, w.h, p0, p1, p2, f);
                 else features16<false>(enc, G + sub, w.h, p0, p1, p2, f);
+                if (TRAIN && L.save_enc_slot >= 0 && w.active) {
+                    f32x4* fsave = slab_block16(ch, L.save_enc_slot, w);
+                    const int cq = 4 * (G + sub) + 2 * w.h;
+                    f32x4 f0, f1;
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) { f0[p] = f[p]; f1[p] = f[4 + p]; }
+                    fsave[saved_index16(cq, w.s)] = f0;
+                    fsave[saved_index16(cq + 1, w.s)] = f1;
+                }
                 bf16x8 fh, fl;
                 split8(f, fh, fl);
                 if (sub == 0) do_chunk(fh, fl, even{}, [] {}, std::false_type{});
@@ -260,6 +287,9 @@ __device__ __forceinline__ void step16(const ffn_mlp_chain& ch, const ffn_step& 
         for (int c = 0; c < 4; ++c) w.logit[c] += hb[c];
     }
     const int relu_floor = L.relu ? 0 : (int)0x80000000;
+    f32x4* save_out = nullptr;
+    if (TRAIN && L.reserved >= 0 && w.active) save_out = slab_block16(ch, L.reserved, w);
+    unsigned sign_bits[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int o = 0; o < OT; ++o) {
 #pragma unroll
@@ -268,7 +298,19 @@ __device__ __forceinline__ void step16(const ffn_mlp_chain& ch, const ffn_step& 
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float t = acc[o][8 * half + j];
+                // (mlp.hip's mask format: value (o&1, q, p) of word o/2 ends at bit 31 - (16(o&1)+4q+p))
+                if (TRAIN)
+                    sign_bits[o >> 1] = __builtin_amdgcn_alignbit(sign_bits[o >> 1],
+                                                                  __builtin_bit_cast(unsigned, 0.0f - t), 31);
                 y[j] = __builtin_bit_cast(float, __builtin_elementwise_max(__builtin_bit_cast(int, t), relu_floor));
+            }
+            if (TRAIN && save_out != nullptr && o < ot) {
+                f32x4 y0, y1;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) { y0[p] = y[p]; y1[p] = y[4 + p]; }
+                const int cq = 2 * (4 * o + 2 * half) + w.h;       // K group 4o + q, q = 2 half (+1)
+                save_out[saved_index16(cq, w.s)] = y0;
+                save_out[saved_index16(cq + 2, w.s)] = y1;
             }
             if (fused_head && o < ot) {
 #pragma unroll
@@ -283,12 +325,20 @@ __device__ __forceinline__ void step16(const ffn_mlp_chain& ch, const ffn_step& 
             split8(y, cur_hi[2 * o + half], cur_lo[2 * o + half]);
         }
     }
+    if (TRAIN && L.relu && L.mask_slot >= 0 && w.active) {
+        // (a one-tile layer's word holds 16 bits in the f32 kernels: right-aligned)
+        if (ot == 1) sign_bits[0] >>= 16;
+        w.masks[((int64_t)L.mask_slot * w.num_blocks + w.block) * 64 + w.lane] =
+            make_uint4(sign_bits[0], sign_bits[1], sign_bits[2], sign_bits[3]);
+    }
 }
 
+template <bool TRAIN>
 __global__ void __launch_bounds__(256, 1)
 mlp_forward_bf16_kernel(const ffn_mlp_chain ch, const uint16_t* __restrict__ packed,
                         const float* __restrict__ bias, const float* __restrict__ positions,
-                        const float* __restrict__ views, int64_t n, float* __restrict__ logits) {
+                        const float* __restrict__ views, int64_t n, float* __restrict__ logits,
+                        float* __restrict__ saved, uint32_t* __restrict__ masks) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* enc_table = reinterpret_cast<float*>(smem + (size_t)kRingBlocks16 * kBlockVecs16 * 16);
     float* bias_lds = reinterpret_cast<float*>(smem + (size_t)kRingBlocks16 * kBlockVecs16 * 16 + kEncTableBytes);
@@ -307,6 +357,9 @@ mlp_forward_bf16_kernel(const ffn_mlp_chain ch, const uint16_t* __restrict__ pac
     for (int li = 0; li < ch.num_steps; ++li) w.total_kb += (ch.step[li].act_groups + ch.step[li].aux_groups) >> 1;
     w.flat = 0;
     w.ring = 0u;
+    w.saved = saved;
+    w.masks = reinterpret_cast<uint4*>(masks);
+    w.num_blocks = (n + 31) / 32;
     // the first five K blocks of the chain go into ring slots 0..4; from then on every K block
     // requests the one five positions ahead (the weight stream is cyclic over the passes)
     for (int b = 0; b < 5; ++b) {
@@ -347,6 +400,8 @@ mlp_forward_bf16_kernel(const ffn_mlp_chain ch, const uint16_t* __restrict__ pac
         const int64_t block = pass * 4 + wave;
         const bool active = block < num_blocks;
         const int64_t sample = (active ? block : num_blocks - 1) * 32 + w.s;
+        w.block = active ? block : num_blocks - 1;
+        w.active = active;
         w.x0 = in_next[0]; w.x1 = in_next[1]; w.x2 = in_next[2];
         w.v0 = in_next[3]; w.v1 = in_next[4]; w.v2 = in_next[5];
         request_inputs(pass + gridDim.x < groups ? pass + gridDim.x : pass);
@@ -357,7 +412,7 @@ mlp_forward_bf16_kernel(const ffn_mlp_chain ch, const uint16_t* __restrict__ pac
 #pragma unroll
             for (int j = 0; j < 8; ++j) { cur_hi[G][j] = (__bf16)0.0f; cur_lo[G][j] = (__bf16)0.0f; }
         }
-        for (int li = 0; li < ch.num_steps; ++li) step16(ch, ch.step[li], w, cur_hi, cur_lo, stage, wh, wl);
+        for (int li = 0; li < ch.num_steps; ++li) step16<TRAIN>(ch, ch.step[li], w, cur_hi, cur_lo, stage, wh, wl);
         f32x4 out;
 #pragma unroll
         for (int c = 0; c < 4; ++c) out[c] = w.logit[c] + __shfl_xor(w.logit[c], 32);
@@ -380,22 +435,21 @@ extern "C" int ffn_mlp_pack_bf16(const float* src, int rows, int cols, int ld, c
     return check_launch("ffn_mlp_pack_bf16");
 }
 
-extern "C" int ffn_mlp_forward_bf16x3(const ffn_mlp_chain* chain, const uint16_t* packed_w,
-                                      const float* bias, const float* positions, const float* views,
-                                      int64_t n, float* logits, void* stream) {
+static int launch_forward16(const char* what, const ffn_mlp_chain* chain, const uint16_t* packed_w,
+                            const float* bias, const float* positions, const float* views,
+                            int64_t n, float* logits, float* saved, uint32_t* masks, void* stream) {
     if (n == 0) return 0;
     if (n < 0 || chain == nullptr || chain->num_steps < 1 || chain->num_steps > FFN_MAX_STEPS)
-        return fail_arg("ffn_mlp_forward_bf16x3: bad chain or size");
-    if (chain->wide || chain->bias_floats < 0 || chain->bias_floats > kBiasFloats16)
-        return fail_arg("ffn_mlp_forward_bf16x3: narrow chains only");
+        return fail_arg(what);
+    if (chain->wide || chain->bias_floats < 0 || chain->bias_floats > kBiasFloats16) return fail_arg(what);
     for (int i = 0; i < chain->num_steps; ++i) {
         const ffn_step& L = chain->step[i];
         const int ot = L.out_tiles;
+        // (slab-destination steps with fused heads only)
         if (!(ot == 1 || ot == 2 || ot == 4 || ot == 8) || L.dst != 0 || (L.act_groups & 3) ||
             (L.aux_groups & 3) || L.act_groups < 0 || L.act_groups > 32 || L.aux_groups < 0 ||
             L.act_groups + L.aux_groups == 0 || (L.aux_groups > 0 && (L.enc_id < 0 || L.enc_id > 1)))
-            return fail_arg("ffn_mlp_forward_bf16x3: unsupported step (slab-destination steps with "
-                            "fused heads only)");
+            return fail_arg(what);
     }
     const int64_t groups = ((n + 31) / 32 + 3) / 4;
     int cus = 256;
@@ -405,9 +459,32 @@ extern "C" int ffn_mlp_forward_bf16x3(const ffn_mlp_chain* chain, const uint16_t
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
     }
     const int64_t grid = groups < cus ? groups : cus;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_forward_bf16_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes16);
-    hipLaunchKernelGGL(mlp_forward_bf16_kernel, dim3((unsigned)grid), dim3(256), kLdsBytes16,
-                       (hipStream_t)stream, *chain, packed_w, bias, positions, views, n, logits);
-    return check_launch("ffn_mlp_forward_bf16x3");
+    if (saved != nullptr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_forward_bf16_kernel<true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes16);
+        hipLaunchKernelGGL(mlp_forward_bf16_kernel<true>, dim3((unsigned)grid), dim3(256), kLdsBytes16,
+                           (hipStream_t)stream, *chain, packed_w, bias, positions, views, n, logits, saved, masks);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_forward_bf16_kernel<false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes16);
+        hipLaunchKernelGGL(mlp_forward_bf16_kernel<false>, dim3((unsigned)grid), dim3(256), kLdsBytes16,
+                           (hipStream_t)stream, *chain, packed_w, bias, positions, views, n, logits, nullptr, nullptr);
+    }
+    return check_launch(what);
+}
+
+extern "C" int ffn_mlp_forward_bf16x3(const ffn_mlp_chain* chain, const uint16_t* packed_w,
+                                      const float* bias, const float* positions, const float* views,
+                                      int64_t n, float* logits, void* stream) {
+    return launch_forward16("ffn_mlp_forward_bf16x3: unsupported chain or size", chain, packed_w, bias,
+                            positions, views, n, logits, nullptr, nullptr, stream);
+}
+
+extern "C" int ffn_mlp_forward_bf16x3_train(const ffn_mlp_chain* chain, const uint16_t* packed_w,
+                                            const float* bias, const float* positions, const float* views,
+                                            int64_t n, float* logits, float* saved, uint32_t* masks,
+                                            void* stream) {
+    if (saved == nullptr || masks == nullptr) return fail_arg("ffn_mlp_forward_bf16x3_train: saved and masks are required");
+    return launch_forward16("ffn_mlp_forward_bf16x3_train: unsupported chain or size", chain, packed_w, bias,
+                            positions, views, n, logits, saved, masks, stream);
 }

@@ -374,6 +374,9 @@ class MlpProgram:
                         cmap.append(-1 if nat < 0 else spec.act_in + nat)
             kblocks = kb_act + kb_feat
             chain.step[self.step_of[i]].w_off = off
+            # training mode of the kernel: every step saves its own output (the f32 chain saves
+            # some of them on consumption by the next step)
+            chain.step[self.step_of[i]].reserved = self.slot_of.get(i, -1)
             self.pack16_jobs.append((i, kblocks, torch.tensor(cmap, dtype=torch.int32, device=self.device), off))
             off += kblocks * 8 * 1024            # 8 tiles x (hi, lo) x 64 lanes x 8 bf16
         self.fwd16 = chain
@@ -639,12 +642,28 @@ class MlpProgram:
         return saved[:acts], saved[acts:acts + self.fwd.num_slots * self.mask_words * blocks]
 
     def forward(self, positions: torch.Tensor, views: Optional[torch.Tensor],
-                saved: Optional[torch.Tensor] = None) -> torch.Tensor:
+                saved: Optional[torch.Tensor] = None, precision: str = "f32") -> torch.Tensor:
         """positions (N,3) [views (N,3)] -> raw logits (N,4).  ``saved`` (a flat float
-        buffer of ``saved_floats(N)`` elements) receives what the backward pass needs."""
+        buffer of ``saved_floats(N)`` elements) receives what the backward pass needs.
+        ``precision="bf16x3"`` (opt-in) runs the split-bf16 kernel."""
         n = positions.shape[0]
         logits = torch.empty((n, 4), dtype=torch.float32, device=self.device)
         acts, masks = (None, None) if saved is None else self._split_saved(saved, n)
+        if precision == "bf16x3":
+            if saved is None:
+                return self.forward16(positions, views)
+            if self.fwd16 is None:
+                raise NotImplementedError("the split-bf16 kernel covers chains of <= 256 channels "
+                                          "whose logits heads are fused")
+            if self._packed16_dirty:
+                self.pack16()
+            _call("ffn_mlp_forward_bf16x3_train", ctypes.byref(self.fwd16),
+                  _dev(self.packed16, torch.int16), _dev(self.bias_buf),
+                  _dev(positions, name="positions"), _dev(views, name="views"), c_i64(n),
+                  _dev(logits), _dev(acts), _dev(masks))
+            return logits
+        if precision != "f32":
+            raise ValueError("precision is 'f32' or 'bf16x3'")
         _call("ffn_mlp_forward", ctypes.byref(self.fwd), _dev(self.packed_fwd),
                   _dev(self.bias_buf), _dev(positions, name="positions"),
                   _dev(views, name="views"), c_i64(n), _dev(logits), _dev(acts), _dev(masks))

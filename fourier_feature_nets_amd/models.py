@@ -38,7 +38,8 @@ class _FusedChainFunction(torch.autograd.Function):
         if not track and module.precision == "bf16x3":
             logits = prog.forward16(positions, views)       # opt-in fast inference mode
         else:
-            logits = prog.forward(positions, views, saved)
+            logits = prog.forward(positions, views, saved,
+                                  precision=module.train_precision if track else "f32")
         ctx.module = module
         ctx.saved_acts = saved
         ctx.save_for_backward(positions, views)
@@ -74,6 +75,9 @@ class _FusedModel(nn.Module):
         # "f32": exact-f32 MFMA everywhere (the parity mode).  "bf16x3": OPT-IN split-bf16
         # matrix products for INFERENCE calls (no_grad / eval renders); training always runs f32.
         self.precision = "f32"
+        # "bf16x3": OPT-IN split-bf16 kernels for the TRAINING pass as well (forward with saved
+        # activations; see mlp_bf16.hip).  Separately labelled wherever it is reported.
+        self.train_precision = "f32"
 
     def _chain(self, device):   # -> (encodings, dense specs)
         raise NotImplementedError

@@ -373,6 +373,15 @@ int ffn_mlp_pack_bf16(const float* src, int rows, int cols, int ld, const int32_
 int ffn_mlp_forward_bf16x3(const ffn_mlp_chain* chain, const uint16_t* packed_w, const float* bias,
                            const float* positions, const float* views, int64_t n, float* logits,
                            void* stream);
+/* The same forward pass, leaving what the backward kernels need in the formats of
+ * ffn_mlp_forward's training mode (`saved` activation slabs, `masks`): every step saves the
+ * encoding features it generates (save_enc_slot), its output (step.reserved = the slab slot of
+ * the step's output, -1 = none) and its ReLU sign mask (mask_slot).  OPT-IN ("bf16x3" training
+ * precision): the saved values carry the ~1e-6 relative error of the split products. */
+int ffn_mlp_forward_bf16x3_train(const ffn_mlp_chain* chain, const uint16_t* packed_w,
+                                 const float* bias, const float* positions, const float* views,
+                                 int64_t n, float* logits, float* saved, uint32_t* masks,
+                                 void* stream);
 
 /* Backward-data chain: d_logits (N,4) + ReLU sign masks -> dZ slabs (same slab geometry as
  * `saved`).  packed_wt holds the transposed operand packs. */

@@ -827,3 +827,68 @@ def test_fourier_encode_shapes_and_tails(F, inc, n):
                     + ([x.double()] if inc or F == 0 else []), dim=-1)
     # |angle| up to ~25 rad in f32: half an ulp of the angle is 1e-6
     np.testing.assert_allclose(got.cpu().double().numpy(), exp.numpy(), rtol=0, atol=6e-6)
+
+
+# ----------------------------------------------------------------------------------- split-bf16 training
+@pytest.mark.parametrize("name", ["positional", "gaussian", "nerf", "nerf_small", "basic"])
+def test_split_bf16_training_mode(golden, name):
+    """OPT-IN `model.train_precision = "bf16x3"`: the split-bf16 forward kernel leaves the
+    activation slabs and ReLU sign masks in the f32 kernels' formats (compared buffer against
+    buffer: values within 2e-5 relative to the slab's scale, mask bits equal wherever the
+    pre-activation is not within rounding of zero), and the gradients of a loss through the whole
+    autograd path agree with the exact mode's to 1e-2 of each tensor's scale (4e-3 measured on
+    the eight-layer NeRF: with 1000 samples, ONE sample whose near-zero pre-activation lands on the
+    other side of a ReLU moves a gradient entry by 1e-3 of the scale; elsewhere ~1e-5)."""
+    from tests.test_kernels_gpu import _load_fourier, _load_nerf
+    g = golden("models")
+    if name.startswith("nerf"):
+        model, _ = _load_nerf(g, name, [4] if name == "nerf" else [2], name == "nerf")
+        args = (_t(g["x"]).to(dev()), _t(g["v"]).to(dev()))
+    else:
+        model, _ = _load_fourier(g, name)
+        args = (_t(g["x"]).to(dev()),)
+    torch.manual_seed(11)
+    n = 1000                                     # ragged: 31.25 blocks
+    x = torch.rand(n, 3, device=dev()) * 2 - 1
+    views = torch.nn.functional.normalize(torch.randn(n, 3, device=dev()), dim=1) if len(args) == 2 else None
+    prog = model.program()
+    saved = {}
+    logits = {}
+    for mode in ("f32", "bf16x3"):
+        buf = torch.zeros((prog.saved_floats(n),), dtype=torch.float32, device=dev())
+        logits[mode] = prog.forward(x, views, buf, precision=mode)
+        saved[mode] = buf
+    scale = float(logits["f32"].abs().max())
+    assert float((logits["bf16x3"] - logits["f32"]).abs().max()) <= 2e-4 * max(scale, 1.0)
+    acts_e, masks_e = prog._split_saved(saved["f32"], n)
+    acts_f, masks_f = prog._split_saved(saved["bf16x3"], n)
+    blocks = (n + 31) // 32
+    for slot in range(prog.fwd.num_slots + len(prog.enc_slot)):
+        ch, off = prog.fwd.slot_channels[slot], prog.fwd.slot_offset[slot]
+        a = acts_e[off * blocks * 32:(off + ch) * blocks * 32]
+        b = acts_f[off * blocks * 32:(off + ch) * blocks * 32]
+        # (the tail block's samples past n are clamped copies in both kernels)
+        tol = 2e-5 * max(float(a.abs().max()), 1.0)
+        assert float((a - b).abs().max()) <= tol, (slot, float((a - b).abs().max()), tol)
+    me = masks_e.view(torch.int32)
+    mf = masks_f.view(torch.int32)
+    differing = (me ^ mf) != 0
+    # a sign flips only where the pre-activation is within rounding of zero: a handful of bits
+    bits = sum(bin(int(v) & 0xffffffff).count("1") for v in (me ^ mf)[differing].cpu().tolist())
+    assert bits <= max(4, int(1e-5 * me.numel() * 32)), bits
+    # gradients through autograd
+    grads = {}
+    target = torch.randn(n, 4, device=dev())
+    for mode in ("f32", "bf16x3"):
+        model.train_precision = mode
+        model.zero_grad()
+        out = model(x, views) if views is not None else model(x)
+        ((out - target) ** 2).mean().backward()
+        grads[mode] = [p.grad.clone() for p in model.parameters() if p.grad is not None]
+    model.train_precision = "f32"
+    assert len(grads["f32"]) == len(grads["bf16x3"]) > 0
+    for a, b in zip(grads["f32"], grads["bf16x3"]):
+        tol = 1e-2 * max(float(a.abs().max()), 1e-6)
+        assert float((a - b).abs().max()) <= tol
+        assert float((a - b).abs().median()) <= 1e-4 * max(float(a.abs().max()), 1e-6)
+    assert any(not torch.equal(a, b) for a, b in zip(grads["f32"], grads["bf16x3"]))
