@@ -29,6 +29,7 @@ SOURCES = {
     "optim.hip": ["-ffp-contract=off"],
     "mlp.hip": [],
     "mlp_bf16.hip": [],
+    "mlp_bf16_bwd.hip": [],
     "wgrad.hip": [],
     "occupancy.hip": [],
 }

@@ -171,11 +171,11 @@ class TrainEngine:
             if index is not None:
                 d_logits = ops.gather_logits(d_logits, index)
             if first:
-                prog.backward(d_logits, pos, views, saved, self.grads)
+                prog.backward(d_logits, pos, views, saved, self.grads, precision=precision)
             else:
                 if getattr(self, "_grads_part", None) is None:
                     self._grads_part = torch.empty_like(self.grads)
-                prog.backward(d_logits, pos, views, saved, self._grads_part)
+                prog.backward(d_logits, pos, views, saved, self._grads_part, precision=precision)
                 self.grads.add_(self._grads_part)
                 sums.add_(part)
         if self.group is not None:

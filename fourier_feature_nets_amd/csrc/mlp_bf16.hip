@@ -18,18 +18,10 @@
 // of tile G/2, converted to (hi, lo) bf16 pairs.  The weight packs are permuted to that K order
 // on the host (ffn_mlp_pack_bf16).  Encoding features are generated per K block in registers
 // (four angles per lane), overlapping the previous block's matrix instructions.
-#include <type_traits>
-
-#include "common.h"
+#include "bf16_ring.h"
 
 namespace ffn {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-constexpr int kBlockVecs16 = 1024;                  // one K block of weights: 8 tiles x (hi, lo) x 64 lanes x 16 B
-constexpr int kRingBlocks16 = 8;                    // LDS ring: two chunks of four K blocks (128 KiB)
 constexpr int kBiasFloats16 = 4096;
 constexpr size_t kLdsBytes16 = (size_t)kRingBlocks16 * kBlockVecs16 * 16 + kEncTableBytes + kBiasFloats16 * 4;
 
@@ -37,9 +29,10 @@ constexpr size_t kLdsBytes16 = (size_t)kRingBlocks16 * kBlockVecs16 * 16 + kEncT
 // dst[(((G*tiles + o)*2 + part)*64 + lane)*8 + j] = part(src[32*o + (lane & 31)][col_map[16*G + 8*(lane >> 5) + j]])
 // (rows past the matrix are zero: the forward kernel always runs tiles = 8)
 // part 0 = bf16(v) (round to nearest even), part 1 = bf16(v - float(part 0)).
+// transpose: the operand is src^T -- tile rows walk src's columns, col_map maps K to src's rows.
 __global__ void __launch_bounds__(256)
 pack_bf16_kernel(const float* __restrict__ src, int rows, int cols, int ld,
-                 const int32_t* __restrict__ col_map, int kblocks, int tiles,
+                 const int32_t* __restrict__ col_map, int kblocks, int tiles, int transpose,
                  uint16_t* __restrict__ dst) {
     const int64_t total = (int64_t)kblocks * tiles * 64 * 8;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
@@ -52,7 +45,11 @@ pack_bf16_kernel(const float* __restrict__ src, int rows, int cols, int ld,
         const int r = 32 * o + (lane & 31);
         const int c = col_map[16 * G + 8 * (lane >> 5) + j];
         float v = 0.0f;
-        if (c >= 0 && r < rows && c < cols) v = src[(int64_t)r * ld + c];
+        if (!transpose) {
+            if (c >= 0 && r < rows && c < cols) v = src[(int64_t)r * ld + c];
+        } else if (c >= 0 && c < rows && r < cols) {
+            v = src[(int64_t)c * ld + r];
+        }
         const __bf16 hi = (__bf16)v;
         const __bf16 lo = (__bf16)(v - (float)hi);
         const int64_t base = ((go * 2) * 64 + lane) * 8 + j;
@@ -62,15 +59,6 @@ pack_bf16_kernel(const float* __restrict__ src, int rows, int cols, int ld,
 }
 
 // ---------------------------------------------------------------------------------- helpers
-__device__ __forceinline__ void split8(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const __bf16 h = (__bf16)x[j];
-        hi[j] = h;
-        lo[j] = (__bf16)(x[j] - (float)h);
-    }
-}
-
 struct Enc16 {
     const float* tab;   // LDS: rows b0 | b1 | b2 | a, kEncRowPitch floats each
     int F, raw;
@@ -113,17 +101,12 @@ __device__ __forceinline__ void features16(const Enc16& enc, int G, int h, float
     }
 }
 
-struct Ctx16 {
-    int lane, h, s, tid;
+struct Ctx16 : Ring16 {
+    int h, s;
     float x0, x1, x2, v0, v1, v2;
     float logit[4];
-    f32x4* wbuf;              // LDS: ring of kRingBlocks16 weight K blocks
     const float* enc_table;   // LDS
     const float* bias_lds;    // LDS
-    const f32x4* gweights;    // all K blocks of the chain, back to back (16 KiB each)
-    int total_kb;             // K blocks of the whole chain
-    int flat;                 // next K block of the chain (0 .. total_kb-1)
-    unsigned ring;            // running K-block counter: ring slot = ring & 7
     // training only: where this wave's block saves its activations / ReLU sign masks
     int64_t block, num_blocks;
     bool active;
@@ -131,17 +114,10 @@ struct Ctx16 {
     uint4* masks;
 };
 
-// float4 index of (channel quad cq, sample s) inside a saved-activation block, and the block of
-// a slab slot: the layouts of mlp.hip (the f32 backward kernels read what this kernel saves)
-__device__ __forceinline__ int saved_index16(int cq, int s) { return cq * 32 + (s ^ (cq & 15)); }
+// the block of a slab slot: the layout of mlp.hip (the backward kernels read what this kernel saves)
 __device__ __forceinline__ f32x4* slab_block16(const ffn_mlp_chain& ch, int slot, const Ctx16& w) {
     return reinterpret_cast<f32x4*>(w.saved + ch.slot_offset[slot] * w.num_blocks * 32) +
            w.block * (int64_t)(ch.slot_channels[slot] * 8);
-}
-
-__device__ __forceinline__ void lockstep_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
 }
 
 // One dense step.  cur_hi / cur_lo: the step's activation
@@ -154,7 +130,7 @@ __device__ __forceinline__ void lockstep_barrier() {
 // TRAIN: the step also leaves what the backward pass needs, in the f32 kernels' formats -- the
 // encoding features it generated (step.save_enc_slot), its output (step.reserved = the output's
 // slab slot) and the ReLU sign mask (step.mask_slot).
-constexpr int OT = 8;
+constexpr int OT = OT16;
 template <bool TRAIN>
 __device__ __forceinline__ void step16(const ffn_mlp_chain& ch, const ffn_step& L, Ctx16& w,
                                        bf16x8 (&cur_hi)[16], bf16x8 (&cur_lo)[16], f32x4 (&stage)[2][4],
@@ -176,69 +152,11 @@ __device__ __forceinline__ void step16(const ffn_mlp_chain& ch, const ffn_step& 
             }
     }
 
-    // One K block (ring position g).  Its weight operands were read from LDS into register set
-    // PAR one block ago; while its 24 matrix instructions run, (1) the operands of block g+1 stream
-    // from LDS into set 1-PAR -- four waves in lockstep read 64 KiB per block, ~500 cycles of LDS
-    // time that would otherwise sit in front of the matrix pipe -- and (2) the weights of block g+5
-    // (cyclically: the next pass starts over) come in from L2 and are deposited into ring slot
-    // (g+5) & 7 (requested from L2 one block earlier).  ONE workgroup barrier per four K blocks: a block deposited at g is behind a barrier
-    // by g+4, i.e. readable during g+4 for g+5, and slot (g+5) & 7 was last read during g-4.
-    // Every layer has an even number of K blocks, so PAR is a compile-time property of the call site.
-    auto do_chunk = [&](const bf16x8& bh, const bf16x8& bl, auto par_tag, auto&& side_work, auto side_tag) {
-        constexpr int PAR = decltype(par_tag)::value;
-        constexpr bool SIDE = decltype(side_tag)::value;      // vector work to run under the MFMAs
-        // (the L2 request for block g+6 goes out now and is deposited at the end of block g+1:
-        // two blocks of latency tolerance)
-        int ahead = w.flat + 6;
-        ahead = ahead < w.total_kb ? ahead : ahead - w.total_kb;
-        ahead = ahead < w.total_kb ? ahead : ahead - w.total_kb;
-        const f32x4* src = w.gweights + (int64_t)ahead * kBlockVecs16 + w.tid;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) stage[PAR][i] = src[256 * i];
-        const f32x4* nl = w.wbuf + ((w.ring + 1u) & 7u) * kBlockVecs16 + w.lane;
-#pragma unroll
-        for (int o = 0; o < OT; ++o) {
-            wh[1 - PAR][o] = __builtin_bit_cast(bf16x8, nl[(2 * o) * 64]);
-            wl[1 - PAR][o] = __builtin_bit_cast(bf16x8, nl[(2 * o + 1) * 64]);
-        }
-        // three products, tile-major: consecutive matrix instructions hit different accumulators
-#pragma unroll
-        for (int o = 0; o < OT; ++o) acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[PAR][o], bl, acc[o], 0, 0, 0);
-#pragma unroll
-        for (int o = 0; o < OT; ++o) acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[PAR][o], bh, acc[o], 0, 0, 0);
-#pragma unroll
-        for (int o = 0; o < OT; ++o) acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[PAR][o], bh, acc[o], 0, 0, 0);
-        f32x4* dst = w.wbuf + ((w.ring + 5u) & 7u) * kBlockVecs16 + w.tid;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) dst[256 * i] = stage[1 - PAR][i];
-        side_work();     // (the NEXT feature block's sincos + bf16 split, when there is one)
-        // issue order: one memory instruction behind each matrix instruction -- 16 operand reads
-        // (+ 4 table reads of the side work), 4 L2 requests, 4 deposits spread over the block's 24
-        // MFMAs -- and the side work's vector instructions in the gaps (the bf16 matrix pipe and
-        // the vector ALU run side by side, but an in-order wave only overlaps what is interleaved
-        // in program order).  Left to itself hipcc clusters the 16 ds_read_b128 in front of the
-        // MFMAs, and a wave that spends ~200 cycles issuing LDS reads lets the matrix pipe run dry.
-        constexpr int kDsReads = SIDE ? 20 : 16;
-#pragma unroll
-        for (int i = 0; i < 24; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (i < kDsReads) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            else __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-            if (i >= 16 && i < 20) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            if (SIDE) __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
-        }
-        if ((w.ring & 3u) == 3u) lockstep_barrier();
-        w.ring += 1u;
-        w.flat = w.flat + 1 < w.total_kb ? w.flat + 1 : 0;
-    };
-    using even = std::integral_constant<int, 0>;
-    using odd = std::integral_constant<int, 1>;
-
 #pragma unroll
     for (int G = 0; G < 16; G += 2)
         if (G < kb_act) {
-            do_chunk(cur_hi[G], cur_lo[G], even{}, [] {}, std::false_type{});
-            do_chunk(cur_hi[G + 1], cur_lo[G + 1], odd{}, [] {}, std::false_type{});
+            ring_kblock<0>(w, acc, cur_hi[G], cur_lo[G], stage, wh, wl);
+            ring_kblock<1>(w, acc, cur_hi[G + 1], cur_lo[G + 1], stage, wh, wl);
         }
     if (kb_feat > 0) {
         Enc16 enc;
@@ -273,8 +191,8 @@ __device__ __forceinline__ void step16(const ffn_mlp_chain& ch, const ffn_step& 
                 }
                 bf16x8 fh, fl;
                 split8(f, fh, fl);
-                if (sub == 0) do_chunk(fh, fl, even{}, [] {}, std::false_type{});
-                else do_chunk(fh, fl, odd{}, [] {}, std::false_type{});
+                if (sub == 0) ring_kblock<0>(w, acc, fh, fl, stage, wh, wl);
+                else ring_kblock<1>(w, acc, fh, fl, stage, wh, wl);
             }
         }
     }
@@ -355,31 +273,12 @@ mlp_forward_bf16_kernel(const ffn_mlp_chain ch, const uint16_t* __restrict__ pac
     w.gweights = reinterpret_cast<const f32x4*>(packed + ch.step[0].w_off);
     w.total_kb = 0;
     for (int li = 0; li < ch.num_steps; ++li) w.total_kb += (ch.step[li].act_groups + ch.step[li].aux_groups) >> 1;
-    w.flat = 0;
-    w.ring = 0u;
     w.saved = saved;
     w.masks = reinterpret_cast<uint4*>(masks);
     w.num_blocks = (n + 31) / 32;
-    // the first five K blocks of the chain go into ring slots 0..4; from then on every K block
-    // requests the one five positions ahead (the weight stream is cyclic over the passes)
-    for (int b = 0; b < 5; ++b) {
-        const int fb = b % w.total_kb;
-        for (int i = 0; i < 4; ++i)
-            w.wbuf[b * kBlockVecs16 + w.tid + 256 * i] = w.gweights[(int64_t)fb * kBlockVecs16 + w.tid + 256 * i];
-    }
-    __syncthreads();
-    // the first block deposits what "the block before it" requested: block 5's weights
     f32x4 stage[2][4];
-    {
-        const int fb = 5 % w.total_kb;
-        for (int i = 0; i < 4; ++i) stage[1][i] = w.gweights[(int64_t)fb * kBlockVecs16 + w.tid + 256 * i];
-    }
     bf16x8 wh[2][8], wl[2][8];          // weight operands: set (g & 1) belongs to ring position g
-#pragma unroll
-    for (int o = 0; o < 8; ++o) {
-        wh[0][o] = __builtin_bit_cast(bf16x8, w.wbuf[(2 * o) * 64 + w.lane]);
-        wl[0][o] = __builtin_bit_cast(bf16x8, w.wbuf[(2 * o + 1) * 64 + w.lane]);
-    }
+    ring_prime(w, stage, wh, wl);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t num_blocks = (n + 31) / 32;
     const int64_t groups = (num_blocks + 3) / 4;            // 4 blocks (one per wave) per pass
@@ -425,13 +324,13 @@ mlp_forward_bf16_kernel(const ffn_mlp_chain ch, const uint16_t* __restrict__ pac
 using namespace ffn;
 
 extern "C" int ffn_mlp_pack_bf16(const float* src, int rows, int cols, int ld, const int32_t* col_map,
-                                 int kblocks, int tiles, uint16_t* dst, void* stream) {
+                                 int kblocks, int tiles, int transpose, uint16_t* dst, void* stream) {
     if (kblocks <= 0 || tiles <= 0 || col_map == nullptr) return fail_arg("ffn_mlp_pack_bf16: shape");
     const int64_t total = (int64_t)kblocks * tiles * 512;
     int64_t grid = (total + 255) / 256;
     if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL(pack_bf16_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, src, rows,
-                       cols, ld, col_map, kblocks, tiles, dst);
+                       cols, ld, col_map, kblocks, tiles, transpose, dst);
     return check_launch("ffn_mlp_pack_bf16");
 }
 

@@ -203,6 +203,7 @@ class MlpProgram:
         self._build_backward()
         self._build_wgrad_jobs()
         self._build_forward16()
+        self._build_backward16()
 
     # ------------------------------------------------------------------ chains
     def _fill_encodings(self, chain):
@@ -435,6 +436,46 @@ class MlpProgram:
         self.bwd = bwd
         self.packed_bwd = torch.zeros((max(wt_off, 1),), dtype=torch.float32, device=self.device)
 
+    def _build_backward16(self):
+        """Chain + transposed operand buffer of the OPT-IN split-bf16 backward-data kernel
+        (mlp_bf16_bwd.hip).  ``self.bwd16`` stays None where the forward one does."""
+        self.bwd16 = None
+        self.packed16_bwd = None
+        self.pack16_bwd_jobs = []      # (consumer layer, kblocks, K map tensor, element offset)
+        if self.fwd16 is None or self.bwd.num_steps == 0:
+            return
+        chain = FfnMlpChain.from_buffer_copy(bytes(self.bwd))
+        consumers: Dict[int, List[int]] = {}
+        for i, prod in enumerate(self.producer_of):
+            if prod >= 0:
+                consumers.setdefault(prod, []).append(i)
+        off = 0
+        for k, j in enumerate(sorted(consumers.keys(), reverse=True)):
+            st = chain.step[k]
+            st.w_off = off
+            st.reserved = self.slot_of[j]
+            hidden = [c for c in consumers[j] if self.layers[c].to_logits is None]
+            heads = [c for c in consumers[j] if self.layers[c].to_logits is not None]
+            if hidden:
+                c = hidden[0]
+                kb = self.layers[c].out // 16
+                if self.layers[c].out % 32:
+                    return
+                # K order = the register hand-off order of the consumer's dZ
+                cmap = [16 * g + (4 * h + jj if jj < 4 else 8 + 4 * h + (jj - 4))
+                        for g in range(kb) for h in range(2) for jj in range(8)]
+                self.pack16_bwd_jobs.append((c, kb, torch.tensor(cmap, dtype=torch.int32, device=self.device), off))
+                off += kb * 8 * 1024
+            if heads:
+                c = heads[0]
+                rows = self.layers[c].to_logits[1]
+                cmap = [(jj if (g == 0 and h == 0 and jj < rows) else -1)
+                        for g in range(2) for h in range(2) for jj in range(8)]
+                self.pack16_bwd_jobs.append((c, 2, torch.tensor(cmap, dtype=torch.int32, device=self.device), off))
+                off += 2 * 8 * 1024
+        self.bwd16 = chain
+        self.packed16_bwd = torch.zeros((max(off, 1),), dtype=torch.int16, device=self.device)
+
     def _build_wgrad_jobs(self):
         """Weight-gradient work list: LDS-staged units of <=256 output x <=256 input channels
         for the hidden layers, head units (<=4 output rows) for the logits heads.  Inputs are
@@ -562,7 +603,14 @@ class MlpProgram:
             w = self.layers[i].weight.detach()
             dst = self.packed16[off:off + kblocks * 8 * 1024]
             _call("ffn_mlp_pack_bf16", _dev(w), c_i(w.shape[0]), c_i(w.shape[1]), c_i(w.stride(0)),
-                  _dev(cmap, torch.int32), c_i(kblocks), c_i(8), _dev(dst, torch.int16))
+                  _dev(cmap, torch.int32), c_i(kblocks), c_i(8), c_i(0), _dev(dst, torch.int16))
+        for (c, kblocks, cmap, off) in (self.pack16_bwd_jobs if self.bwd16 is not None else []):
+            w = self.layers[c].weight.detach()
+            dst = self.packed16_bwd[off:off + kblocks * 8 * 1024]
+            # operand rows = the consumer's input channels (its activation part), K = its rows
+            _call("ffn_mlp_pack_bf16", _dev(w), c_i(w.shape[0]), c_i(self.layers[c].act_in),
+                  c_i(w.stride(0)), _dev(cmap, torch.int32), c_i(kblocks), c_i(8), c_i(1),
+                  _dev(dst, torch.int16))
         self._packed16_dirty = False
 
     def forward16(self, positions: torch.Tensor, views: Optional[torch.Tensor]) -> torch.Tensor:
@@ -728,15 +776,23 @@ class MlpProgram:
         return t_io
 
     def backward(self, d_logits: torch.Tensor, positions: torch.Tensor,
-                 views: Optional[torch.Tensor], saved: torch.Tensor, grads: torch.Tensor):
+                 views: Optional[torch.Tensor], saved: torch.Tensor, grads: torch.Tensor,
+                 precision: str = "f32"):
         """Fills ``grads`` (flat, num_grad_floats) from d(loss)/d(logits) (N,4) and the
-        activations ``saved`` by the matching forward call."""
+        activations ``saved`` by the matching forward call.  ``precision="bf16x3"`` (opt-in)
+        runs the split-bf16 backward-data kernel."""
         n = positions.shape[0]
         if n == 0:                      # an empty batch contributes no gradient
             return grads.zero_()
         ws = self.workspace(n)
         saved, masks = self._split_saved(saved, n)
-        if self.bwd.num_steps > 0:
+        if precision == "bf16x3" and self.bwd16 is not None:
+            if self._packed16_dirty:
+                self.pack16()
+            _call("ffn_mlp_backward_data_bf16x3", ctypes.byref(self.bwd16),
+                  _dev(self.packed16_bwd, torch.int16), _dev(d_logits), c_i64(n), _dev(masks),
+                  _dev(ws.dz))
+        elif self.bwd.num_steps > 0:
             _call("ffn_mlp_backward_data", ctypes.byref(self.bwd), _dev(self.packed_bwd),
                       _dev(d_logits), c_i64(n), _dev(masks), _dev(ws.dz))
         _call("ffn_mlp_wgrad_units", ctypes.byref(self.fwd),

@@ -54,7 +54,8 @@ class _FusedChainFunction(torch.autograd.Function):
                                "supported -- run the forward again")
         prog = ctx.module.program()
         grads = torch.empty((prog.num_grad_floats,), dtype=torch.float32, device=positions.device)
-        prog.backward(d_logits.contiguous(), positions, views, ctx.saved_acts, grads)
+        prog.backward(d_logits.contiguous(), positions, views, ctx.saved_acts, grads,
+                      precision=ctx.module.train_precision)
         ctx.saved_acts = None
         outs = []
         for i, spec in enumerate(prog.layers):

@@ -367,9 +367,11 @@ int ffn_focus_fused(const ffn_mlp_chain* chain, const float* packed_w, const flo
  *   part(src[32*o + (lane & 31)][col_map[16*G + 8*(lane >> 5) + j]]), part 0 = bf16(v) rounded to
  *   nearest even, part 1 = bf16(v - part 0); col_map (int32, device, 16*kblocks entries) maps the
  *   operand K order to natural columns (-1 = zero): for activation K blocks the hand-off order
- *   16G + {4h+j | 8+4h+(j-4)}, for encoding K blocks the internal feature order 16G + 8h + j. */
+ *   16G + {4h+j | 8+4h+(j-4)}, for encoding K blocks the internal feature order 16G + 8h + j.
+ *   transpose = 1 packs src^T (backward data): tile rows walk src's first `cols` columns and
+ *   col_map maps K to src's rows. */
 int ffn_mlp_pack_bf16(const float* src, int rows, int cols, int ld, const int32_t* col_map,
-                      int kblocks, int tiles, uint16_t* dst, void* stream);
+                      int kblocks, int tiles, int transpose, uint16_t* dst, void* stream);
 int ffn_mlp_forward_bf16x3(const ffn_mlp_chain* chain, const uint16_t* packed_w, const float* bias,
                            const float* positions, const float* views, int64_t n, float* logits,
                            void* stream);
@@ -382,6 +384,15 @@ int ffn_mlp_forward_bf16x3_train(const ffn_mlp_chain* chain, const uint16_t* pac
                                  const float* bias, const float* positions, const float* views,
                                  int64_t n, float* logits, float* saved, uint32_t* masks,
                                  void* stream);
+
+/* Split-bf16 backward-data chain (OPT-IN "bf16x3" training precision): the chain of
+ * ffn_mlp_backward_data with w_off pointing into transposed ffn_mlp_pack_bf16 operands (hidden
+ * consumer's K blocks, then -- if the producer feeds a logits head -- two K blocks whose K rows
+ * 0..lg_n-1 are the head's rows) and step.reserved = the slab slot of the step's dZ (-1 = none).
+ * Reads the sign masks, writes every dZ slab in the f32 kernels' format. */
+int ffn_mlp_backward_data_bf16x3(const ffn_mlp_chain* chain, const uint16_t* packed_wt,
+                                 const float* d_logits, int64_t n, const uint32_t* masks,
+                                 float* dz, void* stream);
 
 /* Backward-data chain: d_logits (N,4) + ReLU sign masks -> dZ slabs (same slab geometry as
  * `saved`).  packed_wt holds the transposed operand packs. */

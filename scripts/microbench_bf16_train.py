@@ -48,7 +48,7 @@ def main():
     for mode in ("f32", "bf16x3"):
         out["forward_train_ms " + mode] = round(timed(lambda: prog.forward(x, views, saved, precision=mode)), 3)
         prog.forward(x, views, saved, precision=mode)
-        out["backward_ms after " + mode] = round(timed(lambda: prog.backward(d_logits, x, views, saved, grads)), 3)
+        out["backward_ms " + mode] = round(timed(lambda: prog.backward(d_logits, x, views, saved, grads, precision=mode)), 3)
     print(json.dumps(out, indent=1))
 
 

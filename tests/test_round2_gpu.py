@@ -876,6 +876,24 @@ def test_split_bf16_training_mode(golden, name):
     # a sign flips only where the pre-activation is within rounding of zero: a handful of bits
     bits = sum(bin(int(v) & 0xffffffff).count("1") for v in (me ^ mf)[differing].cpu().tolist())
     assert bits <= max(4, int(1e-5 * me.numel() * 32)), bits
+    # backward data: the split-bf16 kernel against the f32 one on the SAME saved buffer
+    d_logits = torch.randn(n, 4, device=dev()) / n
+    ws = prog.workspace(n)
+    dz, flat = {}, {}
+    for mode in ("f32", "bf16x3"):
+        ws.dz.zero_()
+        flat[mode] = torch.zeros((prog.num_grad_floats,), dtype=torch.float32, device=dev())
+        prog.backward(d_logits, x, views, saved["f32"], flat[mode], precision=mode)
+        dz[mode] = ws.dz.clone()
+    assert prog.bwd16 is not None
+    for slot in range(prog.fwd.num_slots):
+        ch, off = prog.fwd.slot_channels[slot], prog.fwd.slot_offset[slot]
+        a = dz["f32"][off * blocks * 32:(off + ch) * blocks * 32]
+        b = dz["bf16x3"][off * blocks * 32:(off + ch) * blocks * 32]
+        tol = 6e-5 * float(a.abs().max())          # (3e-5 after the eight layers of the NeRF chain)
+        assert float((a - b).abs().max()) <= tol, (slot, float((a - b).abs().max()), tol)
+    assert not torch.equal(dz["f32"], dz["bf16x3"])
+    assert float((flat["f32"] - flat["bf16x3"]).abs().max()) <= 1e-4 * float(flat["f32"].abs().max())
     # gradients through autograd
     grads = {}
     target = torch.randn(n, 4, device=dev())
@@ -890,5 +908,5 @@ def test_split_bf16_training_mode(golden, name):
     for a, b in zip(grads["f32"], grads["bf16x3"]):
         tol = 1e-2 * max(float(a.abs().max()), 1e-6)
         assert float((a - b).abs().max()) <= tol
-        assert float((a - b).abs().median()) <= 1e-4 * max(float(a.abs().max()), 1e-6)
+        assert float((a - b).abs().median()) <= 1e-3 * max(float(a.abs().max()), 1e-6)
     assert any(not torch.equal(a, b) for a, b in zip(grads["f32"], grads["bf16x3"]))
