@@ -31,6 +31,7 @@ SOURCES = {
     "mlp_bf16.hip": [],
     "mlp_bf16_bwd.hip": [],
     "wgrad.hip": [],
+    "wgrad_bf16.hip": [],
     "occupancy.hip": [],
 }
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC,

@@ -26,6 +26,13 @@ WGRAD_GROUPS = 256          # one persistent workgroup per CU for the LDS-staged
 # 16.4k are MFMA issue), and of a head unit (32 MFMAs per wave, bound by its memory instructions)
 UNIT_COST = {4: 24, 2: 13, 1: 8}
 HEAD_COST = 6
+# the split-bf16 kernel (wgrad_bf16.hip) is bound by the slab traffic: a full unit streams 64 KiB
+# per block (~9.4k cycles measured), the f32 head unit 32 KiB (~4.5k)
+UNIT_COST16 = {4: 24, 2: 15, 1: 12}
+HEAD_COST16 = 12
+if os.environ.get("FFN_UNIT_COST16"):
+    _c = [int(v) for v in os.environ["FFN_UNIT_COST16"].split(",")]
+    UNIT_COST16, HEAD_COST16 = {4: _c[0], 2: _c[1], 1: _c[2]}, _c[3]
 if os.environ.get("FFN_UNIT_COST"):       # "full,half,quarter,head" -- calibration experiments
     _c = [int(v) for v in os.environ["FFN_UNIT_COST"].split(",")]
     UNIT_COST, HEAD_COST = {4: _c[0], 2: _c[1], 1: _c[2]}, _c[3]
@@ -170,13 +177,31 @@ class Workspace:
         self.n = n
         blocks = (n + 31) // 32
         self.dz = torch.empty((prog.dz_channels * 32 * blocks,), dtype=torch.float32, device=dev)
-        plan = prog._plan_wgrad(blocks)
-        self.unit_segments = _struct_array_to_device(plan["unit_segments"], dev)
-        self.unit_seg_start = torch.tensor(plan["unit_starts"], dtype=torch.int32, device=dev)
-        self.reduce_jobs = _struct_array_to_device(plan["reduce_jobs"], dev)
-        self.num_reduce_jobs = len(plan["reduce_jobs"])
-        self.partials = torch.empty((plan["slots"] * prog.partial_floats,), dtype=torch.float32,
-                                    device=dev)
+        self._prog, self._blocks = prog, blocks
+        self._plans = {}
+        self.partials = None
+        self.use_plan("f32")
+
+    def use_plan(self, precision: str):
+        """Selects the weight-gradient plan (segments balanced with the kernel's cost model:
+        the exact-f32 and the split-bf16 kernel weigh head and hidden units differently)."""
+        plan = self._plans.get(precision)
+        if plan is None:
+            dev = self._prog.device
+            raw = self._prog._plan_wgrad(self._blocks, precision)
+            plan = dict(unit_segments=_struct_array_to_device(raw["unit_segments"], dev),
+                        unit_seg_start=torch.tensor(raw["unit_starts"], dtype=torch.int32, device=dev),
+                        reduce_jobs=_struct_array_to_device(raw["reduce_jobs"], dev),
+                        num_reduce_jobs=len(raw["reduce_jobs"]),
+                        partial_floats=raw["slots"] * self._prog.partial_floats)
+            self._plans[precision] = plan
+        self.unit_segments = plan["unit_segments"]
+        self.unit_seg_start = plan["unit_seg_start"]
+        self.reduce_jobs = plan["reduce_jobs"]
+        self.num_reduce_jobs = plan["num_reduce_jobs"]
+        if self.partials is None or self.partials.numel() < plan["partial_floats"]:
+            self.partials = torch.empty((plan["partial_floats"],), dtype=torch.float32,
+                                        device=self._prog.device)
 
 
 class MlpProgram:
@@ -548,18 +573,19 @@ class MlpProgram:
         """(m halves, n halves) of a unit: the 128x128 quadrants that exist."""
         return (2 if m_quads > 32 else 1), (2 if n_quads > 32 else 1)
 
-    def _plan_wgrad(self, blocks: int):
+    def _plan_wgrad(self, blocks: int, precision: str = "f32"):
         """Segments of the weight-gradient kernel + the reducer's job table.  One
         workgroup-segment = 4 consecutive partial slots (one per wave)."""
         slot = 0
         reduce_jobs = []
         unit_costs = []
+        unit_cost, head_cost = (UNIT_COST16, HEAD_COST16) if precision == "bf16x3" else (UNIT_COST, HEAD_COST)
         for u, meta in zip(self.wgrad_units, self.unit_meta):
             if u.kind == 1:
-                unit_costs.append(HEAD_COST)
+                unit_costs.append(head_cost)
             else:
                 mh, nh = self._quadrants(meta["m_quads"], meta["n_quads"])
-                unit_costs.append(UNIT_COST[mh * nh])
+                unit_costs.append(unit_cost[mh * nh])
         raw, unit_starts = self._split(unit_costs, blocks, WGRAD_GROUPS)
         unit_segments = []
         unit_slots = [[] for _ in self.wgrad_units]
@@ -785,6 +811,8 @@ class MlpProgram:
         if n == 0:                      # an empty batch contributes no gradient
             return grads.zero_()
         ws = self.workspace(n)
+        wgrad16 = precision == "bf16x3" and not self.wide
+        ws.use_plan("bf16x3" if wgrad16 else "f32")
         saved, masks = self._split_saved(saved, n)
         if precision == "bf16x3" and self.bwd16 is not None:
             if self._packed16_dirty:
@@ -795,7 +823,8 @@ class MlpProgram:
         elif self.bwd.num_steps > 0:
             _call("ffn_mlp_backward_data", ctypes.byref(self.bwd), _dev(self.packed_bwd),
                       _dev(d_logits), c_i64(n), _dev(masks), _dev(ws.dz))
-        _call("ffn_mlp_wgrad_units", ctypes.byref(self.fwd),
+        _call("ffn_mlp_wgrad_units_bf16x3" if wgrad16 else "ffn_mlp_wgrad_units",
+              ctypes.byref(self.fwd),
                   _dev(self.wgrad_units_dev, torch.uint8), _dev(ws.unit_segments, torch.uint8),
                   _dev(ws.unit_seg_start, torch.int32), c_i(WGRAD_GROUPS), _dev(saved),
                   _dev(ws.dz), _dev(d_logits), c_i64(n), _dev(ws.partials))

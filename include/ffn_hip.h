@@ -437,6 +437,12 @@ int ffn_mlp_wgrad_units(const ffn_mlp_chain* chain, const ffn_wgrad_unit* units,
                         const ffn_wgrad_segment* segments, const int32_t* seg_start,
                         int num_groups, const float* saved, const float* dz,
                         const float* d_logits, int64_t n, float* partials, void* stream);
+/* The same launch with every f32 product as three bf16 matrix products (OPT-IN "bf16x3" training
+ * precision): same units, segments, slabs and partial format; ffn_mlp_wgrad_reduce is shared. */
+int ffn_mlp_wgrad_units_bf16x3(const ffn_mlp_chain* chain, const ffn_wgrad_unit* units,
+                               const ffn_wgrad_segment* segments, const int32_t* seg_start,
+                               int num_groups, const float* saved, const float* dz,
+                               const float* d_logits, int64_t n, float* partials, void* stream);
 
 /* Fixed-order reduction of the partials of each job into the flat natural-layout
  * gradient buffer (nn.Linear weight (out,in) row-major, then bias). */
