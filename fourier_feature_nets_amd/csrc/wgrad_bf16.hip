@@ -12,8 +12,20 @@
 // and issues 48 matrix instructions per sixteen samples where the f32 kernel issues 128 at
 // four times the cost each.  At that rate the kernel is bound by the slab traffic (2 x 32 KiB per
 // block and unit), not by the matrix pipe.
+//
+// FEAT (regenerate_features, OFF by default): units whose input window is a slab of encoding
+// features do not read that slab -- each wave regenerates its share of the window (the feature
+// code of the forward kernels, fourier_features.h: same instructions, same bits) from the block's
+// 32 sample positions straight into the LDS image, and the forward pass need not save features
+// (2 of the 5 KiB per sample it writes, 2 of the 9 KiB this kernel reads, tiny model).  Built,
+// bit-identical, and measured SLOWER: the block's vector work (450 conversion + 280 feature
+// instructions, which this in-order wave does not overlap with its 96 matrix instructions)
+// then exceeds the 9.4k cycles the 64 KiB of slab traffic cost -- weight gradients 8.9 -> 11.9 ms
+// for 0.7 ms saved in the forward pass (knock-outs: no matrix instructions -3.2 ms, no feature
+// generation -2.6, no conversions -1.2, no contraction at all -3.1).
 #include <type_traits>
 
+#include "fourier_features.h"
 #include "wgrad_common.h"
 
 namespace ffn {
@@ -32,12 +44,21 @@ __device__ __forceinline__ void split_component(const f32x4 (&v)[8], bf16x8& hi,
     }
 }
 
-template <int CA, int CB, bool BIAS>
+// the encoding whose features fill a slab slot, -1 if the slot holds activations
+__device__ __forceinline__ int encoding_of_slot(const ffn_mlp_chain& ch, int slot) {
+    for (int i = 0; i < ch.num_steps; ++i)
+        if (ch.step[i].save_enc_slot == slot) return ch.step[i].enc_id;
+    return -1;
+}
+
+template <int CA, int CB, bool BIAS, bool FEAT>
 __device__ __forceinline__ void unit_segment16(const ffn_mlp_chain& ch, const ffn_wgrad_unit& unit,
                                                const ffn_wgrad_segment& seg, char* smem,
                                                const float* __restrict__ saved,
                                                const float* __restrict__ dz, int64_t num_blocks,
-                                               float* __restrict__ partials) {
+                                               float* __restrict__ partials,
+                                               const float* __restrict__ points, int64_t n,
+                                               int enc_id) {
     constexpr int NQ = (CA / 4) * (CB / 4);   // quadrants that exist: 4, 2 or 1
     constexpr int NCH = CA + CB;
     const int tid = threadIdx.x;
@@ -77,6 +98,47 @@ __device__ __forceinline__ void unit_segment16(const ffn_mlp_chain& ch, const ff
     // (wgrad.hip: chunks past the end of a window re-read its last chunk)
     f32x4 R[NCH];
     typedef const f32x4 __attribute__((address_space(1)))* gptr;
+    constexpr int NST = FEAT ? CA : NCH;      // chunks that are staged (FEAT: the A image only)
+
+    // FEAT: this lane's sample of a block, and the window's K groups generated into LDS image
+    // `buf`: wave w takes groups w, w+4, ... (group g = channel quads 2g and 2g+1 = lane halves)
+    const EncRegs enc = load_enc(ch.enc[FEAT ? enc_id : 0],
+                                 reinterpret_cast<const float*>(smem + kUnitLdsBytes) + (FEAT ? enc_id : 0) * kEncTablePitch);
+    const int groups = unit.n_quads >> 1, g_first = unit.n_cq0 >> 1;
+    float px = 0.0f, py = 0.0f, pz = 0.0f;
+    auto load_point = [&](int64_t blk) {
+        if (!FEAT) return;
+        blk = blk < num_blocks ? blk : num_blocks - 1;
+        int64_t sample = blk * 32 + li;
+        sample = sample < n ? sample : n - 1;             // the forward pass clamps the same way
+        px = points[sample * 3 + 0]; py = points[sample * 3 + 1]; pz = points[sample * 3 + 2];
+    };
+    // Trips of four K groups (two feature_oct calls = four independent packed sincos chains).
+    // Wave w owns the contiguous groups [w*per, (w+1)*per).
+    auto generate = [&](int buf) {
+        if (!FEAT) return;
+        const f32x2 s0 = (f32x2)(enc.scale * px), s1 = (f32x2)(enc.scale * py), s2 = (f32x2)(enc.scale * pz);
+        const f32x4 q0 = (f32x4)(enc.scale * px), q1 = (f32x4)(enc.scale * py), q2 = (f32x4)(enc.scale * pz);
+        const int per = ((groups + 15) >> 4) << 2;          // groups per wave, a multiple of 4
+        const int gl_end = (wave + 1) * per < groups ? (wave + 1) * per : groups;
+        for (int gl = wave * per; gl < gl_end; gl += 4) {
+            const int g = g_first + gl;
+            f32x4 v[4];
+            if (gl + 3 < gl_end && 4 * (g + 3) + 3 < enc.F) {
+                feature_oct(enc, g, hh, q0, q1, q2, v[0], v[1]);
+                feature_oct(enc, g + 2, hh, q0, q1, q2, v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = feature_quad<false>(enc, g + u, hh, px, py, pz, s0, s1, s2);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int cq = 2 * (gl + u) + hh;
+                if (gl + u < gl_end)
+                    *reinterpret_cast<f32x4*>(smem + image_b(buf) + (cq * 32 + (li ^ (cq & 15))) * 16) = v[u];
+            }
+        }
+    };
 #define FFN_REQUEST(j)                                                                         \
     do {                                                                                       \
         gptr chunk = (j) < CA ? (gptr)(a_s + ((j) < ca_last ? (j) : ca_last) * 4096)           \
@@ -89,15 +151,18 @@ __device__ __forceinline__ void unit_segment16(const ffn_mlp_chain& ch, const ff
                                                : image_b(cur) + ((j) - CA) * 4096) + t16) = R[j]
 
     // ---- prologue: first block -> LDS buffer 0, second block -> registers
+    load_point(seg.blk_begin);
 #pragma unroll
-    for (int j = 0; j < NCH; ++j) FFN_REQUEST(j);
+    for (int j = 0; j < NST; ++j) FFN_REQUEST(j);
 #pragma unroll
-    for (int j = 0; j < NCH; ++j) FFN_DEPOSIT(0, j);
+    for (int j = 0; j < NST; ++j) FFN_DEPOSIT(0, j);
+    generate(0);
+    load_point(seg.blk_begin + 1);
     a_s += a_stride;
     b_s += b_stride;
     if (seg.blk_begin + 1 < seg.blk_end) {
 #pragma unroll
-        for (int j = 0; j < NCH; ++j) FFN_REQUEST(j);
+        for (int j = 0; j < NST; ++j) FFN_REQUEST(j);
     }
     a_s += a_stride;       // from here on: the block after next
     b_s += b_stride;
@@ -111,7 +176,7 @@ __device__ __forceinline__ void unit_segment16(const ffn_mlp_chain& ch, const ff
     const char* a_row = smem + image_a(0) + (a_ok ? (32 * mp + li) * 512 : kImageBytes);
     const char* b_row = smem + image_b(0) + (b_ok ? (32 * np + li) * 512 : kImageBytes);
 
-    auto block_body = [&](auto cur_tag, bool has1, bool has2) {
+    auto block_body = [&](auto cur_tag, int64_t blk_of_body, bool has1, bool has2) {
         constexpr int CUR = decltype(cur_tag)::value;
         constexpr int kToggle = CUR * kImageStride;
         // The copy of the next block (registers -> free LDS buffer) comes first and the requests
@@ -120,11 +185,14 @@ __device__ __forceinline__ void unit_segment16(const ffn_mlp_chain& ch, const ff
         // 16k cycles per block, requests in the middle of the block).
         if (has1) {
 #pragma unroll
-            for (int j = 0; j < NCH; ++j) FFN_DEPOSIT(1 - CUR, j);
+            for (int j = 0; j < NST; ++j) FFN_DEPOSIT(1 - CUR, j);
+            generate(1 - CUR);               // (the point of block b+1 was requested a block ago)
         }
+        __builtin_amdgcn_sched_barrier(0);
         if (has2) {
 #pragma unroll
-            for (int j = 0; j < NCH; ++j) FFN_REQUEST(j);
+            for (int j = 0; j < NST; ++j) FFN_REQUEST(j);
+            load_point(blk_of_body + 2);
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -170,9 +238,9 @@ __device__ __forceinline__ void unit_segment16(const ffn_mlp_chain& ch, const ff
     };
 
     for (int64_t blk = seg.blk_begin; blk < seg.blk_end; blk += 2) {
-        block_body(std::integral_constant<int, 0>{}, blk + 1 < seg.blk_end, blk + 2 < seg.blk_end);
+        block_body(std::integral_constant<int, 0>{}, blk, blk + 1 < seg.blk_end, blk + 2 < seg.blk_end);
         if (blk + 1 < seg.blk_end)
-            block_body(std::integral_constant<int, 1>{}, blk + 2 < seg.blk_end, blk + 3 < seg.blk_end);
+            block_body(std::integral_constant<int, 1>{}, blk + 1, blk + 2 < seg.blk_end, blk + 3 < seg.blk_end);
     }
 #undef FFN_REQUEST
 #undef FFN_DEPOSIT
@@ -195,10 +263,12 @@ wgrad_unit_bf16_kernel(const ffn_mlp_chain ch, const ffn_wgrad_unit* __restrict_
                        const ffn_wgrad_segment* __restrict__ segments,
                        const int32_t* __restrict__ seg_start, const float* __restrict__ saved,
                        const float* __restrict__ dz, const float* __restrict__ d_logits, int64_t n,
-                       float* __restrict__ partials) {
+                       float* __restrict__ partials, const float* __restrict__ positions,
+                       const float* __restrict__ views, int regenerate) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     for (int k = threadIdx.x; k < 4 * 128; k += 256)      // the zero row behind each image
         reinterpret_cast<float*>(smem + (k >> 7) * kImageStride + kImageBytes)[k & 127] = 0.0f;
+    if (regenerate) stage_encoding_tables(ch.enc, reinterpret_cast<float*>(smem + kUnitLdsBytes), threadIdx.x, 256);
     __syncthreads();
     const int64_t num_blocks = (n + 31) / 32;
     const int seg_lo = seg_start[blockIdx.x], seg_hi = seg_start[blockIdx.x + 1];
@@ -218,10 +288,17 @@ wgrad_unit_bf16_kernel(const ffn_mlp_chain ch, const ffn_wgrad_unit* __restrict_
             const bool m_wide = unit.m_quads > 32, n_wide = unit.n_quads > 32;
             const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
             const bool bias = unit.want_bias != 0 && (!n_wide || (wave & 1) == 0);
+            const int enc_id = regenerate ? encoding_of_slot(ch, unit.n_slot) : -1;
+            const float* points = enc_id == 1 ? views : positions;
 #define FFN_UNIT(CA, CB)                                                                         \
     do {                                                                                         \
-        if (bias) unit_segment16<CA, CB, true>(ch, unit, seg, smem, saved, dz, num_blocks, partials);  \
-        else unit_segment16<CA, CB, false>(ch, unit, seg, smem, saved, dz, num_blocks, partials);      \
+        if (enc_id >= 0) {                                                                       \
+            if (bias) unit_segment16<CA, CB, true, true>(ch, unit, seg, smem, saved, dz, num_blocks, partials, points, n, enc_id);   \
+            else unit_segment16<CA, CB, false, true>(ch, unit, seg, smem, saved, dz, num_blocks, partials, points, n, enc_id);      \
+        } else {                                                                                 \
+            if (bias) unit_segment16<CA, CB, true, false>(ch, unit, seg, smem, saved, dz, num_blocks, partials, points, n, 0);     \
+            else unit_segment16<CA, CB, false, false>(ch, unit, seg, smem, saved, dz, num_blocks, partials, points, n, 0);        \
+        }                                                                                        \
     } while (0)
             if (m_wide && n_wide) FFN_UNIT(8, 8);
             else if (m_wide) FFN_UNIT(8, 4);
@@ -241,12 +318,16 @@ extern "C" int ffn_mlp_wgrad_units_bf16x3(const ffn_mlp_chain* chain, const ffn_
                                           const ffn_wgrad_segment* segments, const int32_t* seg_start,
                                           int num_groups, const float* saved, const float* dz,
                                           const float* d_logits, int64_t n, float* partials,
-                                          void* stream) {
+                                          const float* positions, const float* views,
+                                          int regenerate_features, void* stream) {
     if (n <= 0 || num_groups <= 0) return fail_arg("ffn_mlp_wgrad_units_bf16x3: shape");
-    const size_t lds = kUnitLdsBytes;
+    if (regenerate_features && positions == nullptr)
+        return fail_arg("ffn_mlp_wgrad_units_bf16x3: regenerating features needs the sample positions");
+    const size_t lds = kUnitLdsBytes + kEncTableBytes;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_unit_bf16_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(wgrad_unit_bf16_kernel, dim3(num_groups), dim3(256), lds, (hipStream_t)stream,
-                       *chain, units, segments, seg_start, saved, dz, d_logits, n, partials);
+                       *chain, units, segments, seg_start, saved, dz, d_logits, n, partials, positions, views,
+                       regenerate_features);
     return check_launch("ffn_mlp_wgrad_units_bf16x3");
 }

@@ -28,6 +28,10 @@ UNIT_COST = {4: 24, 2: 13, 1: 8}
 HEAD_COST = 6
 # the split-bf16 kernel (wgrad_bf16.hip) is bound by the slab traffic: a full unit streams 64 KiB
 # per block (~9.4k cycles measured), the f32 head unit 32 KiB (~4.5k)
+# FFN_BF16_REGENERATE_FEATURES=1: the split-bf16 forward does not save the encoding features and
+# the weight-gradient kernel regenerates them from the sample positions (bit-identical; measured
+# slower -- see wgrad_bf16.hip -- so the default is the f32 kernels' scheme)
+REGENERATE_FEATURES = os.environ.get("FFN_BF16_REGENERATE_FEATURES", "0") == "1"
 UNIT_COST16 = {4: 24, 2: 15, 1: 12}
 HEAD_COST16 = 12
 if os.environ.get("FFN_UNIT_COST16"):
@@ -403,6 +407,9 @@ class MlpProgram:
             # training mode of the kernel: every step saves its own output (the f32 chain saves
             # some of them on consumption by the next step)
             chain.step[self.step_of[i]].reserved = self.slot_of.get(i, -1)
+            # ... and, with REGENERATE_FEATURES, none saves encoding features
+            if REGENERATE_FEATURES:
+                chain.step[self.step_of[i]].save_enc_slot = -1
             self.pack16_jobs.append((i, kblocks, torch.tensor(cmap, dtype=torch.int32, device=self.device), off))
             off += kblocks * 8 * 1024            # 8 tiles x (hi, lo) x 64 lanes x 8 bf16
         self.fwd16 = chain
@@ -803,15 +810,19 @@ class MlpProgram:
 
     def backward(self, d_logits: torch.Tensor, positions: torch.Tensor,
                  views: Optional[torch.Tensor], saved: torch.Tensor, grads: torch.Tensor,
-                 precision: str = "f32"):
+                 precision: str = "f32", regenerate: Optional[bool] = None):
         """Fills ``grads`` (flat, num_grad_floats) from d(loss)/d(logits) (N,4) and the
         activations ``saved`` by the matching forward call.  ``precision="bf16x3"`` (opt-in)
-        runs the split-bf16 backward-data kernel."""
+        runs the split-bf16 backward-data and weight-gradient kernels; the latter regenerates
+        the encoding features from ``positions`` / ``views`` (``regenerate=False``: reads the
+        feature slabs of ``saved``, which only an f32 forward call fills)."""
         n = positions.shape[0]
         if n == 0:                      # an empty batch contributes no gradient
             return grads.zero_()
         ws = self.workspace(n)
         wgrad16 = precision == "bf16x3" and not self.wide
+        if regenerate is None:
+            regenerate = REGENERATE_FEATURES
         ws.use_plan("bf16x3" if wgrad16 else "f32")
         saved, masks = self._split_saved(saved, n)
         if precision == "bf16x3" and self.bwd16 is not None:
@@ -827,7 +838,9 @@ class MlpProgram:
               ctypes.byref(self.fwd),
                   _dev(self.wgrad_units_dev, torch.uint8), _dev(ws.unit_segments, torch.uint8),
                   _dev(ws.unit_seg_start, torch.int32), c_i(WGRAD_GROUPS), _dev(saved),
-                  _dev(ws.dz), _dev(d_logits), c_i64(n), _dev(ws.partials))
+                  _dev(ws.dz), _dev(d_logits), c_i64(n), _dev(ws.partials),
+                  *((_dev(positions, name="positions"), _dev(views, name="views"),
+                     c_i(1 if regenerate is None else int(regenerate))) if wgrad16 else ()))
         _call("ffn_mlp_wgrad_reduce", _dev(ws.reduce_jobs, torch.uint8),
                   c_i(ws.num_reduce_jobs), _dev(ws.partials), _dev(grads))
         return grads
