@@ -42,7 +42,7 @@ def main(src, out, commit=None, rays=65536, samples=64):
                          "WRITE_SIZE_KB": round(w_kb, 1),
                          "hbm_bytes": int((2 * f_kb + w_kb) * 1024)}
     doc = {"note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on "
-                   "`python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-render --no-target-shape`, MI355X; "
+                   "`python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-target-shape --no-config3 --no-config5 --no-skip-leg --no-bf16-leg` (scripts/gpu/profile_round2.sh: train steps + the fused-render leg), MI355X; "
                    "KB per launch averaged over launches; hbm_bytes = (2*FETCH_SIZE + "
                    "WRITE_SIZE)*1024 (gfx950: FETCH_SIZE counts 128-B requests as 64 B for wide "
                    "streaming reads, MI355X_MICROARCH.md section HBM)",
