@@ -31,6 +31,8 @@ TRAIN_COMMON = [
     ("--device", dict(default="cuda")),
     ("--anneal-start", dict(type=float, default=0.2)),
     ("--num-anneal-steps", dict(type=int, default=2000)),
+    # not a flag of the reference: the opt-in split-bf16 kernels, training and renders
+    ("--precision", dict(choices=["f32", "bf16x3"], default="f32")),
 ]
 NERF_ONLY = [
     ("--resolution", dict(type=int, default=400)),
@@ -64,6 +66,7 @@ ORBIT = [
     ("--alpha-thresh", dict(type=float, default=0.3)),
     ("--batch_size", dict(type=int, default=4096)),
     ("--device", dict(default="cuda")),
+    ("--precision", dict(choices=["f32", "bf16x3"], default="f32")),   # not a flag of the reference
 ]
 
 
@@ -106,6 +109,15 @@ def setup_device(requested: str, want_group: bool):
             dist.init_process_group(backend, rank=rank, world_size=world)
         group = dist.group.WORLD
     return device, rank, world, group
+
+
+def apply_precision(model, precision: str):
+    """--precision bf16x3: the opt-in split-bf16 kernels for training and inference calls of a
+    fused-MLP model (models without that switch, e.g. voxel grids, are left alone)."""
+    if precision != "f32" and hasattr(model, "train_precision"):
+        model.precision = precision
+        model.train_precision = precision
+    return model
 
 
 def axis_vector(code):

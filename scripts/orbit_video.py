@@ -29,7 +29,7 @@ def main():
     if args.opacity_model:
         opacity = ffn.load_model(args.opacity_model).to(device)
     mine = list(range(rank, args.num_frames, world))
-    caster = ffn.Raycaster(model)
+    caster = ffn.Raycaster(_cli.apply_precision(model, args.precision))
     sampler = ffn.RaySampler(bounds, [cameras[f] for f in mine], args.num_samples, False, opacity,
                              args.batch_size, device=device)
     os.makedirs(args.output_dir, exist_ok=True)

@@ -610,3 +610,22 @@ def test_driver_scripts_end_to_end(tmp_path):
                           "--num-samples", "16"], capture_output=True, text=True, cwd=root)
     assert res.returncode == 0, res.stderr[-2000:]
     assert sorted(os.listdir(frames)) == ["frame_00000.png", "frame_00001.png"]
+    # the opt-in --precision bf16x3 (not a flag of the reference): same run, same seed.  The
+    # evaluation renders take the three-pass route in this mode (the fused render kernel is f32
+    # only) and draw their stratified jitter in different chunks, so the logged PSNRs agree to
+    # the jitter's 1e-2 dB rather than to the arithmetic's 1e-5
+    fast = str(tmp_path / "run16")
+    res = subprocess.run([sys.executable, os.path.join(root, "scripts", "train_tiny_nerf.py"), SCENE,
+                          "positional", fast, "--num-steps", "4", "--report-interval", "2",
+                          "--image-interval", "2", "--batch-size", "64", "--num-samples", "16",
+                          "--crop-steps", "0", "--precision", "bf16x3"],
+                         capture_output=True, text=True, cwd=root)
+    assert res.returncode == 0, res.stderr[-2000:]
+
+    def psnrs(path):
+        rows = open(os.path.join(path, "log.txt")).read().strip().split("\n")
+        return np.array([[float(v) for v in row.split("\t")[2:]] for row in rows[3:]])
+
+    exact, split = psnrs(out), psnrs(fast)
+    assert exact.shape == split.shape and exact.size > 0
+    np.testing.assert_allclose(split, exact, rtol=0, atol=5e-2)
