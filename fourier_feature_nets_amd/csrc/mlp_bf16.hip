@@ -128,8 +128,7 @@ __device__ __forceinline__ f32x4* slab_block16(const ffn_mlp_chain& ch, int slot
 // head terms, and are never consumed.
 //
 // TRAIN: the step also leaves what the backward pass needs, in the f32 kernels' formats -- the
-// encoding features it generated (step.save_enc_slot), its output (step.reserved = the output's
-// slab slot) and the ReLU sign mask (step.mask_slot).
+// encoding features it generated (step.save_enc_slot), its output (step.out_slot) and the ReLU sign mask (step.mask_slot).
 constexpr int OT = OT16;
 template <bool TRAIN>
 __device__ __forceinline__ void step16(const ffn_mlp_chain& ch, const ffn_step& L, Ctx16& w,
@@ -206,7 +205,7 @@ __device__ __forceinline__ void step16(const ffn_mlp_chain& ch, const ffn_step& 
     }
     const int relu_floor = L.relu ? 0 : (int)0x80000000;
     f32x4* save_out = nullptr;
-    if (TRAIN && L.reserved >= 0 && w.active) save_out = slab_block16(ch, L.reserved, w);
+    if (TRAIN && L.out_slot >= 0 && w.active) save_out = slab_block16(ch, L.out_slot, w);
     unsigned sign_bits[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int o = 0; o < OT; ++o) {

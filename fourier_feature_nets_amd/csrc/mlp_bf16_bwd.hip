@@ -65,9 +65,9 @@ __device__ __forceinline__ void step16_bwd(const ffn_mlp_chain& ch, const ffn_st
     }
     // ---- epilogue: mask, save dZ, hand-off as bf16 pairs
     f32x4* save_out = nullptr;
-    if (L.reserved >= 0 && w.active)
-        save_out = reinterpret_cast<f32x4*>(w.dz + ch.slot_offset[L.reserved] * w.num_blocks * 32) +
-                   w.block * (int64_t)(ch.slot_channels[L.reserved] * 8);
+    if (L.out_slot >= 0 && w.active)
+        save_out = reinterpret_cast<f32x4*>(w.dz + ch.slot_offset[L.out_slot] * w.num_blocks * 32) +
+                   w.block * (int64_t)(ch.slot_channels[L.out_slot] * 8);
     const int top = ot == 1 ? 15 : 31;      // (a one-tile layer's mask word holds 16 bits)
 #pragma unroll
     for (int o = 0; o < OT16; ++o) {

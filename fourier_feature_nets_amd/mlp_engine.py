@@ -55,7 +55,7 @@ class FfnStep(ctypes.Structure):
                 ("out_col", ctypes.c_int32), ("out_n", ctypes.c_int32),
                 ("save_in_slot", ctypes.c_int32), ("save_out_slot", ctypes.c_int32),
                 ("mask_slot", ctypes.c_int32), ("save_enc_slot", ctypes.c_int32),
-                ("head_off", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("head_off", ctypes.c_int32), ("out_slot", ctypes.c_int32),
                 ("w_off", ctypes.c_int64), ("b_off", ctypes.c_int64)]
 
 
@@ -406,7 +406,7 @@ class MlpProgram:
             chain.step[self.step_of[i]].w_off = off
             # training mode of the kernel: every step saves its own output (the f32 chain saves
             # some of them on consumption by the next step)
-            chain.step[self.step_of[i]].reserved = self.slot_of.get(i, -1)
+            chain.step[self.step_of[i]].out_slot = self.slot_of.get(i, -1)
             # ... and, with REGENERATE_FEATURES, none saves encoding features
             if REGENERATE_FEATURES:
                 chain.step[self.step_of[i]].save_enc_slot = -1
@@ -485,7 +485,7 @@ class MlpProgram:
         for k, j in enumerate(sorted(consumers.keys(), reverse=True)):
             st = chain.step[k]
             st.w_off = off
-            st.reserved = self.slot_of[j]
+            st.out_slot = self.slot_of[j]
             hidden = [c for c in consumers[j] if self.layers[c].to_logits is None]
             heads = [c for c in consumers[j] if self.layers[c].to_logits is not None]
             if hidden:

@@ -234,7 +234,10 @@ typedef struct ffn_step {
                               channels*4 weights [channel][logits column], zero in the
                               columns the head does not write; the step's output is then
                               also stored into slab save_out_slot when training; -1 none */
-    int32_t reserved;
+    int32_t out_slot;      /* split-bf16 kernels only (the f32 kernels ignore it): the slab of the
+                              step's output -- its activations in a forward chain, its dZ in a
+                              backward chain -- which those kernels save from registers in
+                              every step's epilogue; -1 = none                            */
     int64_t w_off;         /* float offset of this step's packed operand weights       */
     int64_t b_off;         /* forward: float offset of the bias (padded to 32*tiles)   */
 } ffn_step;
@@ -377,9 +380,9 @@ int ffn_mlp_forward_bf16x3(const ffn_mlp_chain* chain, const uint16_t* packed_w,
                            void* stream);
 /* The same forward pass, leaving what the backward kernels need in the formats of
  * ffn_mlp_forward's training mode (`saved` activation slabs, `masks`): every step saves the
- * encoding features it generates (save_enc_slot), its output (step.reserved = the slab slot of
- * the step's output, -1 = none) and its ReLU sign mask (mask_slot).  OPT-IN ("bf16x3" training
- * precision): the saved values carry the ~1e-6 relative error of the split products. */
+ * encoding features it generates (save_enc_slot), its output (out_slot) and its ReLU sign mask
+ * (mask_slot).  OPT-IN ("bf16x3" training precision): the saved values carry the ~1e-6 relative
+ * error of the split products. */
 int ffn_mlp_forward_bf16x3_train(const ffn_mlp_chain* chain, const uint16_t* packed_w,
                                  const float* bias, const float* positions, const float* views,
                                  int64_t n, float* logits, float* saved, uint32_t* masks,
@@ -388,7 +391,7 @@ int ffn_mlp_forward_bf16x3_train(const ffn_mlp_chain* chain, const uint16_t* pac
 /* Split-bf16 backward-data chain (OPT-IN "bf16x3" training precision): the chain of
  * ffn_mlp_backward_data with w_off pointing into transposed ffn_mlp_pack_bf16 operands (hidden
  * consumer's K blocks, then -- if the producer feeds a logits head -- two K blocks whose K rows
- * 0..lg_n-1 are the head's rows) and step.reserved = the slab slot of the step's dZ (-1 = none).
+ * 0..lg_n-1 are the head's rows) and step.out_slot = the slab slot of the step's dZ.
  * Reads the sign masks, writes every dZ slab in the f32 kernels' format. */
 int ffn_mlp_backward_data_bf16x3(const ffn_mlp_chain* chain, const uint16_t* packed_wt,
                                  const float* d_logits, int64_t n, const uint32_t* masks,

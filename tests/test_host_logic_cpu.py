@@ -253,7 +253,8 @@ def test_data_parallel_step_equals_single_process_step(tmp_path):
 
 def test_driver_scripts_keep_the_reference_flags_and_defaults():
     """argparse surface of scripts/{train_nerf,train_tiny_nerf,orbit_video}.py == the
-    reference scripts' (captured into tests/golden/cli_defaults.json by make_goldens.py)."""
+    reference scripts' (captured into tests/golden/cli_defaults.json by make_goldens.py), plus
+    one documented extension."""
     import json
     from scripts import _cli
     with open(os.path.join(os.path.dirname(__file__), "golden", "cli_defaults.json")) as f:
@@ -268,6 +269,8 @@ def test_driver_scripts_keep_the_reference_flags_and_defaults():
         "orbit_video": vars(_cli.build_parser("t", _cli.ORBIT).parse_args(["m.pt", "400", "out"])),
     }
     for name in ref:
+        # the one extension: --precision (opt-in split-bf16 kernels), default = the exact mode
+        assert mine[name].pop("precision") == "f32"
         assert mine[name] == ref[name], name
 
 
