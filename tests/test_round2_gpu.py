@@ -920,3 +920,30 @@ def test_split_bf16_training_mode(golden, name):
         assert float((a - b).abs().max()) <= tol
         assert float((a - b).abs().median()) <= 1e-3 * max(float(a.abs().max()), 1e-6)
     assert any(not torch.equal(a, b) for a, b in zip(grads["f32"], grads["bf16x3"]))
+
+
+@pytest.mark.parametrize("n", [1, 31, 33, 129, 4097])
+def test_split_bf16_training_ragged_sizes(golden, n):
+    """The split-bf16 training kernels on batches that are not multiples of a 32-sample block or
+    of a four-block pass: gradients against the exact kernels' on the same samples, and batch
+    independence of the saved logits (sample i of a batch == the same sample alone)."""
+    from tests.test_kernels_gpu import _load_fourier
+    model, _ = _load_fourier(golden("models"), "positional")
+    prog = model.program()
+    torch.manual_seed(n)
+    x = torch.rand(n, 3, device=dev()) * 2 - 1
+    d_logits = torch.randn(n, 4, device=dev()) / n
+    grads, logits = {}, {}
+    for mode in ("f32", "bf16x3"):
+        saved = torch.zeros((prog.saved_floats(n),), dtype=torch.float32, device=dev())
+        logits[mode] = prog.forward(x, None, saved, precision=mode)
+        grads[mode] = torch.zeros((prog.num_grad_floats,), dtype=torch.float32, device=dev())
+        prog.backward(d_logits, x, None, saved, grads[mode], precision=mode)
+    scale = float(grads["f32"].abs().max())
+    assert scale > 0 and bool(torch.isfinite(grads["bf16x3"]).all())
+    # (one sample on the other side of a ReLU is worth 1/n of a gradient entry: see the test above)
+    assert float((grads["f32"] - grads["bf16x3"]).abs().max()) <= max(2e-4, 10.0 / n) * scale
+    assert float((logits["f32"] - logits["bf16x3"]).abs().max()) <= 2e-4 * max(float(logits["f32"].abs().max()), 1.0)
+    pick = torch.tensor(sorted({0, n // 2, n - 1}), device=dev())
+    alone = prog.forward(x[pick].contiguous(), None, None, precision="bf16x3")
+    assert torch.equal(logits["bf16x3"][pick], alone)
