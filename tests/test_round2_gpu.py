@@ -830,7 +830,7 @@ def test_fourier_encode_shapes_and_tails(F, inc, n):
 
 
 # ----------------------------------------------------------------------------------- split-bf16 training
-@pytest.mark.parametrize("name", ["positional", "gaussian", "nerf", "nerf_small", "basic"])
+@pytest.mark.parametrize("name", ["positional", "gaussian", "nerf", "nerf_small", "basic", "mlp"])
 def test_split_bf16_training_mode(golden, name):
     """OPT-IN `model.train_precision = "bf16x3"`: the split-bf16 forward kernel leaves the
     activation slabs and ReLU sign masks in the f32 kernels' formats (compared buffer against
