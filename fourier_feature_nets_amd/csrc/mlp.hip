@@ -336,6 +336,13 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
         for (int c = 0; c < 4; ++c) w.logit[c] += hb[c];
     }
     if (WIDE) team_barrier();        // every K loop of this step has finished reading the slab
+    // Wide mode: the epilogue's slab / save addresses are lane constants, and with the wide
+    // kernels' register budget hipcc computes them once per kernel, SPILLS them (106 dwords in the
+    // training forward) and reloads them here -- scratch reloads that wait, through the in-order
+    // vmcnt, for every global store issued before them.  Opaque lane terms keep them
+    // two-instruction recomputations.
+    int e_lane = w.lane, e_h = w.h, e_s = w.s;
+    if (WIDE) asm volatile("" : "+v"(e_lane), "+v"(e_h), "+v"(e_s));
     unsigned sign_bits[4] = {0u, 0u, 0u, 0u};
     // ReLU as a signed-integer max on the bit pattern: floats below +0 (and -0) are negative
     // integers, so max(bits, 0) is relu(t) in ONE instruction -- fmaxf costs three here (IEEE
@@ -365,8 +372,8 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
                     const float a = acc[o][4 * q + p];     // (a scalar copy: bit_cast of a vector
                     y[p] = __builtin_bit_cast(float, __builtin_bit_cast(int, a) & keep);   // element reads lane 0)
                 }
-                w.act[group * 64 + w.lane] = y;
-                if (save_y) save_out[saved_index(2 * group + w.h, w.s)] = y;
+                w.act[group * 64 + e_lane] = y;
+                if (save_y) save_out[saved_index(2 * group + e_h, e_s)] = y;
             } else {
                 // fused head: this quad's four weight rows are requested BEFORE its ReLU / sign-bit
                 // work and its slab write (which the compiler must keep them ordered against), so
@@ -387,14 +394,14 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
                     y[p] = __builtin_bit_cast(float, __builtin_elementwise_max(__builtin_bit_cast(int, t), relu_floor));
                 }
                 if (to_slab) {
-                    w.act[group * 64 + w.lane] = y;
+                    w.act[group * 64 + e_lane] = y;
                     if (fused_head) {
 #pragma unroll
                         for (int p = 0; p < 4; ++p) {
 #pragma unroll
                             for (int c = 0; c < 4; ++c) w.logit[c] = __builtin_fmaf(y[p], hw4[p][c], w.logit[c]);
                         }
-                        if (MODE == kTrainFwd && save_y) save_out[saved_index(2 * group + w.h, w.s)] = y;
+                        if (MODE == kTrainFwd && save_y) save_out[saved_index(2 * group + e_h, e_s)] = y;
                     }
                 } else if (!WIDE && o == 0 && q == 0) {
                     // real outputs = rows 0..out_n-1 of tile 0 = registers 0..3 of h == 0

@@ -206,6 +206,13 @@ __device__ __forceinline__ void step16(const ffn_mlp_chain& ch, const ffn_step& 
     const int relu_floor = L.relu ? 0 : (int)0x80000000;
     f32x4* save_out = nullptr;
     if (TRAIN && L.out_slot >= 0 && w.active) save_out = slab_block16(ch, L.out_slot, w);
+    // The 32 store addresses of this epilogue are lane constants (cq*32 + (s ^ (cq & 15))): left
+    // alone, hipcc computes them all once per kernel, SPILLS them, and reloads them here -- and a
+    // scratch reload waits (in-order vmcnt) for every global store issued before it, which cost
+    // the training variant ~3 ms.  Making the lane term opaque per step keeps them two-instruction
+    // recomputations.
+    int save_s = w.s, save_h = w.h;
+    if (TRAIN) asm volatile("" : "+v"(save_s), "+v"(save_h));
     unsigned sign_bits[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int o = 0; o < OT; ++o) {
@@ -225,9 +232,9 @@ __device__ __forceinline__ void step16(const ffn_mlp_chain& ch, const ffn_step& 
                 f32x4 y0, y1;
 #pragma unroll
                 for (int p = 0; p < 4; ++p) { y0[p] = y[p]; y1[p] = y[4 + p]; }
-                const int cq = 2 * (4 * o + 2 * half) + w.h;       // K group 4o + q, q = 2 half (+1)
-                save_out[saved_index16(cq, w.s)] = y0;
-                save_out[saved_index16(cq + 2, w.s)] = y1;
+                const int cq = 2 * (4 * o + 2 * half) + save_h;    // K group 4o + q, q = 2 half (+1)
+                save_out[saved_index16(cq, save_s)] = y0;
+                save_out[saved_index16(cq + 2, save_s)] = y1;
             }
             if (fused_head && o < ot) {
 #pragma unroll
