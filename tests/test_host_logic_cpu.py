@@ -86,8 +86,10 @@ def test_chain_and_wgrad_plans(make):
     last = prog.bwd.step[prog.bwd.num_steps - 1]
     assert last.save_out_slot == 0
     # every (row, col) of every weight gradient is produced by exactly one reduce job
-    for blocks in (1, 7, 4096):
-        plan = prog._plan_wgrad(blocks)
+    for blocks, precision in ((1, "f32"), (7, "f32"), (4096, "f32"), (5, "bf16x3"), (4096, "bf16x3"),
+                              (131072, "bf16x3"), (4099, "bf16x3")):
+        # (the split-bf16 plan has its own unit costs)
+        plan = prog._plan_wgrad(blocks, precision)
         cover = {}
         for seg in plan["unit_segments"]:
             cover.setdefault(("u", seg.job), []).append((seg.blk_begin, seg.blk_end))
@@ -120,6 +122,13 @@ def test_chain_and_wgrad_plans(make):
             assert not (mine & slots)
             slots |= mine
         assert max(slots) < plan["slots"]
+        # every partial slot a unit's segments write is read by exactly that unit's reduce jobs
+        written = {}
+        for seg in plan["unit_segments"]:
+            for wave in range(4):
+                written[seg.slot + wave] = seg.job
+        assert slots <= set(written)       # (a narrow head leaves the partials of its idle waves unread)
+        assert len(plan["unit_starts"]) == 257 and plan["unit_starts"][-1] == len(plan["unit_segments"])
 
 
 def test_unsupported_shapes_raise_not_fall_back():
