@@ -360,10 +360,11 @@ def config3_leg(device, cams, images, bounds, rays_per_step=65536, steps=3):
     step_ms = 1e3 * elapsed / steps
     mlp_ms = sum(k["avg_ms"] for k in fine_kernels.values())
     flop = sum(k["flop_per_sample"] for k in fine_kernels.values()) * rays_per_step * 128
-    out = {"workload": "lego_400-shaped full NeRF train step: NeRF(8,256,9,10,3,4,[4],True), "
+    side = cams[0].resolution.width
+    out = {"workload": "lego_%d-shaped full NeRF train step: NeRF(8,256,9,10,3,4,[4],True), "
                        "S = 128 = 64 stratified uniform + 64 opacity-guided samples, live coarse "
                        "model PositionalFourierMLP(3,4,5.5) on 64 probe points per ray, %d rays/step, "
-                       "100 cams x 400x400, exact-f32 MFMA" % rays_per_step,
+                       "%d cams x %dx%d, exact-f32 MFMA" % (side, rays_per_step, len(cams), side, side),
            "step_ms": round(step_ms, 2), "rays_per_s": round(rays_per_step / (step_ms * 1e-3), 1),
            "steps": steps, "final_loss": float(loss), "sampler_startup_s": round(startup_s, 3),
            "cdf_table_bytes": 0, "sampling_incl_coarse_pass_ms": round(coarse_ms, 3),
@@ -402,9 +403,26 @@ def config3_leg(device, cams, images, bounds, rays_per_step=65536, steps=3):
     for f in range(2):
         caster.render_image_device(orbit, f, 32768)
     torch.cuda.synchronize()
-    out["render_fps_400x400_128_samples"] = round(2 / (time.perf_counter() - r0), 3)
+    out["render_fps_%dx%d_128_samples" % (side, side)] = round(2 / (time.perf_counter() - r0), 3)
     caster.check_finite()
     return out
+
+
+def config4_leg(device, bounds, cameras=100, size=800):
+    """BASELINE configs[3] on one GPU (the 8-GPU run is the driver's): the config-3 step on
+    800x800 frames -- 64 M rays of sampler state (2.1 GB), no CDF table (the reference's would be
+    16 GB), the same 65 536-ray optimisation step, and the 800x800 frame rate."""
+    import fourier_feature_nets_amd as ffn
+    torch.cuda.empty_cache()
+    intr, poses = synthetic_rig(cameras, size)
+    cams = [ffn.CameraInfo.create("train%03d" % i, ffn.Resolution(size, size), intr, p)
+            for i, p in enumerate(poses)]
+    with contextlib.redirect_stdout(io.StringIO()):
+        probe = ffn.RaySampler(bounds, cams, 128, device=device)
+        images = analytic_images(probe)
+        del probe
+    torch.cuda.empty_cache()
+    return config3_leg(device, cams, images, bounds, steps=2)
 
 
 def skip_leg(device, dataset, bounds, rays_per_step, steps=4):
@@ -856,6 +874,8 @@ def main():
         torch.cuda.empty_cache()
         result["north_star_shape"] = target_shape_leg(device) if solo and not args.no_target_shape else None
         result["config3_step"] = (config3_leg(device, cams, images, bounds)
+                                  if solo and not args.no_config3 and args.size == 400 else None)
+        result["config4_step"] = (config4_leg(device, bounds)
                                   if solo and not args.no_config3 and args.size == 400 else None)
         result["empty_space_skipping"] = (skip_leg(device, dataset, bounds, args.rays)
                                           if solo and not args.no_skip_leg else None)
