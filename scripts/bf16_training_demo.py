@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--cameras", type=int, default=48)
     ap.add_argument("--size", type=int, default=200)
     ap.add_argument("--report", type=int, default=300)
+    ap.add_argument("--model", choices=["tiny", "nerf"], default="tiny")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     intr, poses = B.synthetic_rig(args.cameras + 4, args.size)
@@ -56,7 +57,8 @@ def main():
     runs, weights = {}, {}
     for mode in ("f32", "bf16x3"):
         torch.manual_seed(20080524)
-        model = ffn.PositionalFourierMLP(3, 4, 5.5).to(dev)
+        model = (ffn.PositionalFourierMLP(3, 4, 5.5) if args.model == "tiny"
+                 else ffn.NeRF(8, 256, 9, 10, 3, 4, [4], True)).to(dev)
         model.train_precision = mode
         engine = ffn.TrainEngine(model, 0.0, None)
         gen = torch.Generator(device=dev).manual_seed(1)
@@ -79,8 +81,9 @@ def main():
         weights[mode] = torch.cat([p.detach().flatten() for p in model.parameters()])
     rel = float((weights["f32"] - weights["bf16x3"]).norm() / weights["f32"].norm())
     out = {"scene": "synthetic shaded sphere r=0.6, %d train / %d held-out cameras %dx%d, 64 samples/ray, "
-                    "%d rays/step, %d steps, tiny NeRF; same initial weights, batches and jitter"
-                    % (len(train_ids), len(held), args.size, args.size, args.rays, args.steps),
+                    "%d rays/step, %d steps, %s; same initial weights, batches and jitter"
+                    % (len(train_ids), len(held), args.size, args.size, args.rays, args.steps,
+                       "tiny NeRF" if args.model == "tiny" else "full NeRF (8x256, skip, view branch)"),
            "note": "opt-in split-bf16 training kernels against the exact-f32 ones; validation frames "
                    "rendered by the exact-f32 fused kernel in both runs",
            "runs": runs,
