@@ -19,6 +19,7 @@ import torch.nn as nn
 
 from . import ops
 from .dataset import RayDataset
+from .occupancy import OccupancyGrid
 from .sampler import RaySampler, RaySamples
 from .utils import RenderResult, learning_rate_at
 
@@ -241,6 +242,12 @@ class Raycaster(nn.Module):
         self.process_group = None         # set to a torch.distributed group for data parallel
         self.occupancy = None             # an OccupancyGrid switches on empty-space skipping (no_grad renders)
         self.fused_render = True          # render_image / render_rays through the one-launch kernel
+        # OPT-IN empty-space skipping DURING `fit` (new semantics, DESIGN K9; BASELINE config 5):
+        # (warm-up steps, refresh interval) -- after the warm-up of exact steps the training
+        # engine gets an occupancy grid derived from the model itself, rebuilt every interval
+        self.train_occupancy_schedule = None
+        self.train_occupancy_resolution = 128
+        self.train_occupancy_threshold = 0.01
 
     # ------------------------------------------------------------------ rendering
     def _flag(self, device):
@@ -448,6 +455,13 @@ class Raycaster(nn.Module):
                     break
                 lr = learning_rate_at(learning_rate, step, decay_rate, decay_steps)
                 batch = order[start:min(start + batch_size, num_rays)]
+                if self.train_occupancy_schedule is not None:
+                    warm, every = self.train_occupancy_schedule
+                    if step >= warm and (step - warm) % max(int(every), 1) == 0:
+                        # (data parallel: identical weights on every rank give identical grids)
+                        engine.occupancy = OccupancyGrid.from_model(
+                            self.model, train_dataset.sampler.bounds, self.train_occupancy_resolution,
+                            self.train_occupancy_threshold, True)
                 engine.train_step(train_dataset, batch, step, lr,
                                   rays=epoch_rays[bounds[bi]:bounds[bi + 1]])
 

@@ -33,6 +33,12 @@ TRAIN_COMMON = [
     ("--num-anneal-steps", dict(type=int, default=2000)),
     # not a flag of the reference: the opt-in split-bf16 kernels, training and renders
     ("--precision", dict(choices=["f32", "bf16x3"], default="f32")),
+    # not flags of the reference either: opt-in empty-space skipping during training (DESIGN K9):
+    # exact steps for --skip-warmup steps, then an occupancy grid derived from the model and
+    # rebuilt every --skip-refresh steps
+    ("--skip-empty-space", dict(action="store_true")),
+    ("--skip-warmup", dict(type=int, default=1000)),
+    ("--skip-refresh", dict(type=int, default=500)),
 ]
 NERF_ONLY = [
     ("--resolution", dict(type=int, default=400)),
@@ -118,6 +124,13 @@ def apply_precision(model, precision: str):
         model.precision = precision
         model.train_precision = precision
     return model
+
+
+def apply_skipping(caster, args):
+    """--skip-empty-space: the opt-in occupancy-grid schedule of Raycaster.fit."""
+    if getattr(args, "skip_empty_space", False):
+        caster.train_occupancy_schedule = (args.skip_warmup, args.skip_refresh)
+    return caster
 
 
 def axis_vector(code):

@@ -45,7 +45,7 @@ def main():
     if args.mode == "dilate":
         train.mode = ffn.RayDataset.Mode.Dilate
     os.makedirs(args.results_dir, exist_ok=True)
-    caster = ffn.Raycaster(_cli.apply_precision(model.to(args.device), args.precision))
+    caster = _cli.apply_skipping(ffn.Raycaster(_cli.apply_precision(model.to(args.device), args.precision)), args)
     caster.process_group = group      # data parallel under torch.distributed.run
     if world > 1:                     # distinct jitter streams; weights are broadcast by fit
         torch.cuda.manual_seed(args.seed + rank)

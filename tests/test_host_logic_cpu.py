@@ -263,7 +263,7 @@ def test_data_parallel_step_equals_single_process_step(tmp_path):
 def test_driver_scripts_keep_the_reference_flags_and_defaults():
     """argparse surface of scripts/{train_nerf,train_tiny_nerf,orbit_video}.py == the
     reference scripts' (captured into tests/golden/cli_defaults.json by make_goldens.py), plus
-    one documented extension."""
+    the documented extensions."""
     import json
     from scripts import _cli
     with open(os.path.join(os.path.dirname(__file__), "golden", "cli_defaults.json")) as f:
@@ -278,8 +278,12 @@ def test_driver_scripts_keep_the_reference_flags_and_defaults():
         "orbit_video": vars(_cli.build_parser("t", _cli.ORBIT).parse_args(["m.pt", "400", "out"])),
     }
     for name in ref:
-        # the one extension: --precision (opt-in split-bf16 kernels), default = the exact mode
+        # the extensions: --precision (opt-in split-bf16 kernels) and the opt-in empty-space
+        # skipping schedule; the defaults are the exact mode
         assert mine[name].pop("precision") == "f32"
+        if name != "orbit_video":
+            assert mine[name].pop("skip_empty_space") is False
+            assert (mine[name].pop("skip_warmup"), mine[name].pop("skip_refresh")) == (1000, 500)
         assert mine[name] == ref[name], name
 
 

@@ -947,3 +947,50 @@ def test_split_bf16_training_ragged_sizes(golden, n):
     pick = torch.tensor(sorted({0, n // 2, n - 1}), device=dev())
     alone = prog.forward(x[pick].contiguous(), None, None, precision="bf16x3")
     assert torch.equal(logits["bf16x3"][pick], alone)
+
+
+def test_fit_with_the_opt_in_occupancy_schedule(golden, tmp_path):
+    """Raycaster.train_occupancy_schedule = (warm-up, refresh): `fit` runs exact steps first, then
+    hands the training engine an occupancy grid derived from the model and rebuilds it on
+    schedule; without the schedule `fit` never builds one.  Also reachable from the driver
+    (`--skip-empty-space`, not a flag of the reference)."""
+    import subprocess
+    import fourier_feature_nets_amd as ffn
+    from tests.test_pipeline_gpu import _small_model
+    g = golden("training")
+    results = {}
+    for schedule in (None, (2, 2)):
+        torch.manual_seed(5)
+        np.random.seed(5)
+        model = _small_model(g)
+        train = _quiet(ffn.ImageDataset.load, SCENE, "train", 16, True, True, device=dev())
+        val = _quiet(ffn.ImageDataset.load, SCENE, "val", 16, True, False, device=dev())
+        caster = ffn.Raycaster(model)
+        caster.train_occupancy_schedule = schedule
+        caster.train_occupancy_resolution = 16
+        built = []
+        original = ffn.OccupancyGrid.from_model
+
+        def counting(*args, **kwargs):
+            built.append(1)
+            return original(*args, **kwargs)
+
+        ffn.OccupancyGrid.from_model = counting
+        try:
+            log = _quiet(caster.fit, train, val, 64, 5e-4, 6, 0, 3, 0.1, 25000, 0.0, [])
+        finally:
+            ffn.OccupancyGrid.from_model = original
+        assert len(log) == 3 and all(np.isfinite(e.val_psnr) for e in log)
+        results[schedule] = (len(built), caster.engine.occupancy, caster.engine.last_evaluated_fraction)
+    assert results[None][0] == 0 and results[None][1] is None
+    count, grid, fraction = results[(2, 2)]
+    assert count == 3 and grid is not None              # steps 2, 4, 6
+    assert 0.0 <= fraction <= 1.0
+    out = str(tmp_path / "skip")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "train_tiny_nerf.py"), SCENE,
+                          "positional", out, "--num-steps", "4", "--report-interval", "2",
+                          "--image-interval", "2", "--batch-size", "64", "--num-samples", "16",
+                          "--crop-steps", "0", "--skip-empty-space", "--skip-warmup", "1",
+                          "--skip-refresh", "2"], capture_output=True, text=True, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert os.path.exists(os.path.join(out, "tiny_nerf.pt"))
