@@ -371,8 +371,11 @@ def config3_leg(device, cams, images, bounds, rays_per_step=65536, steps=3):
            "fine_mlp_ms": round(mlp_ms, 3), "kernels": fine_kernels,
            "fine_mlp_frac_of_f32_mfma_peak": round(flop / (mlp_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
            "whole_step_frac_of_f32_mfma_peak": round(flop / (step_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)}
-    # the same step in the OPT-IN split-bf16 training mode (labelled; see bf16_train_leg)
+    # the same step in the OPT-IN split-bf16 mode (labelled; see bf16_train_leg): training kernels
+    # of the fine model, and the coarse model's probe pass through the split-bf16 inference kernel
+    # (five launches instead of the fused exact-f32 coarse-pass kernel)
     fine.train_precision = "bf16x3"
+    coarse.precision = "bf16x3"
     try:
         run_step(steps + 1)
         torch.cuda.synchronize()
@@ -383,12 +386,14 @@ def config3_leg(device, cams, images, bounds, rays_per_step=65536, steps=3):
         fast_ms = 1e3 * (time.perf_counter() - t0) / steps
         engine.check_finite()
         out["split_bf16_training"] = {
-            "label": "opt-in split-bf16 training kernels for the fine model (not the exact-f32 "
-                     "parity mode; reported separately)",
+            "label": "opt-in split-bf16 kernels: training kernels of the fine model, inference kernel "
+                     "for the coarse model's probe pass (not the exact-f32 parity mode; reported "
+                     "separately)",
             "step_ms": round(fast_ms, 2), "rays_per_s": round(rays_per_step / (fast_ms * 1e-3), 1),
             "speedup_vs_exact_f32_step": round(step_ms / fast_ms, 2)}
     finally:
         fine.train_precision = "f32"
+        coarse.precision = "f32"
     del engine
     prog._workspaces.clear()
     torch.cuda.empty_cache()

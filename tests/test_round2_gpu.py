@@ -566,6 +566,15 @@ def test_live_focus_sampler_equals_the_table(golden):
     coarse.invalidate_packed()
     t1 = live2.sample(idx, None).t_values
     assert not torch.equal(t0, t1)
+    # an opacity model in the opt-in split-bf16 inference mode takes the five-launch live path (the
+    # fused coarse-pass kernel is exact-f32 only); its t-values follow the exact ones closely
+    assert live2._can_fuse_focus(8)
+    coarse.precision = "bf16x3"
+    assert not live2._can_fuse_focus(8)
+    t2 = live2.sample(idx, None).t_values
+    coarse.precision = "f32"
+    assert t2.shape == t1.shape and bool((t2[:, 1:] >= t2[:, :-1]).all())
+    assert float((t2 - t1).abs().max()) <= 1e-3 and not torch.equal(t1, t2)
 
 
 def test_live_focus_sampler_with_voxels_and_golden(golden):
