@@ -462,6 +462,17 @@ def skip_leg(device, dataset, bounds, rays_per_step, steps=4):
     step_ms = 1e3 * (time.perf_counter() - t0) / steps
     engine.check_finite()
     frac = engine.last_evaluated_fraction
+    # both opt-in modes together: the occupied samples through the split-bf16 training kernels
+    model.train_precision = "bf16x3"
+    run_step(1 + steps)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for step in range(2 + steps, 2 + 2 * steps):
+        run_step(step)
+    torch.cuda.synchronize()
+    both_ms = 1e3 * (time.perf_counter() - t0) / steps
+    engine.check_finite()
+    model.train_precision = "f32"
     del engine
     caster = ffn.Raycaster(model)
     caster.occupancy = grid
@@ -478,6 +489,8 @@ def skip_leg(device, dataset, bounds, rays_per_step, steps=4):
             "grid": "128^3 bits, %.1f %% of the cells occupied" % (100 * grid.fraction_occupied()),
             "train_step_ms": round(step_ms, 3),
             "train_rays_per_s": round(rays_per_step / (step_ms * 1e-3), 1),
+            "train_step_ms_with_split_bf16_kernels": round(both_ms, 3),
+            "train_rays_per_s_with_split_bf16_kernels": round(rays_per_step / (both_ms * 1e-3), 1),
             "evaluated_sample_fraction": round(frac, 4),
             "render_fps_kernels_only": round(fps, 2)}
 

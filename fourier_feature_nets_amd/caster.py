@@ -109,7 +109,13 @@ class TrainEngine:
         need = prog.saved_floats(n)
         buf = self._saved.get("buf")
         if buf is None or buf.numel() < need:
-            buf = torch.empty((need,), dtype=torch.float32, device=self.device)
+            # grown with headroom (the batch's sample count wobbles from step to step when rays
+            # are filtered or empty space is skipped, and every multi-GB allocation costs ~100 ms
+            # of page-table work); the old buffer is released first
+            self._saved["buf"] = buf = None
+            blocks = prog.plan_blocks(n)
+            buf = torch.empty((prog.saved_floats(32 * (blocks + blocks // 16 + 1)),),
+                              dtype=torch.float32, device=self.device)
             self._saved["buf"] = buf
         return buf
 
