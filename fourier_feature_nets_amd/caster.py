@@ -21,7 +21,7 @@ from . import ops
 from .dataset import RayDataset
 from .occupancy import OccupancyGrid
 from .sampler import RaySampler, RaySamples
-from .utils import RenderResult, learning_rate_at
+from .utils import RenderResult, check_color_space, learning_rate_at
 
 LogEntry = NamedTuple("LogEntry", [("step", int), ("timestamp", float),
                                    ("state", OrderedDict[str, torch.Tensor]),
@@ -345,10 +345,13 @@ class Raycaster(nn.Module):
             nan_flag=self._flag(sampler.device), image=image, pixel_offset=pixel_offset)
         return RenderResult(color, alpha, depth)
 
-    def render_image_device(self, sampler: RaySampler, index: int, batch_size: int) -> torch.Tensor:
-        """(H,W,3) uint8 frame of camera ``index % num_cameras`` as a DEVICE tensor, enqueued
+    def render_image_device(self, sampler: RaySampler, index: int, batch_size: int,
+                            color_space="RGB") -> torch.Tensor:
+        """(H,W,3) uint8 RGB frame of camera ``index % num_cameras`` as a DEVICE tensor, enqueued
         without any host synchronisation (callers overlap the copy-out / encoding, see
-        ``frames.FrameSink``)."""
+        ``frames.FrameSink``).  ``color_space`` names the space the MODEL predicts in ("YCrCb":
+        the u8 frame goes through kernel K8b like ray_sampler.py:197-198)."""
+        check_color_space(color_space)
         camera = index % sampler.num_cameras
         self.model.eval()
         with torch.no_grad():
@@ -366,15 +369,15 @@ class Raycaster(nn.Module):
                     colors[start:start + batch_size] = self.render(chunk, False).color
                 image = ops.to_image(colors, (rays - camera * sampler.rays_per_camera).contiguous(),
                                      sampler.image_width, sampler.image_height)
+        if color_space == "YCrCb":
+            ops.ycrcb_to_rgb_u8(image)
         self.model.train()
         return image
 
     def render_image(self, sampler: RaySampler, index: int, batch_size: int,
                      color_space="RGB") -> np.ndarray:
         """(H,W,3) uint8 frame of camera ``index % num_cameras`` (ray_caster.py:140-159)."""
-        if color_space != "RGB":
-            raise NotImplementedError("only the RGB colour space is supported (YCrCb needs OpenCV)")
-        image = self.render_image_device(sampler, index, batch_size)
+        image = self.render_image_device(sampler, index, batch_size, color_space)
         self.check_finite()
         return image.cpu().numpy()
 

@@ -124,6 +124,30 @@ to_image_kernel(const float* __restrict__ colors, const int64_t* __restrict__ pi
     }
 }
 
+// ---------------------------------------------------------------------------------- K8b
+// 8-bit YCrCb -> RGB in place, one thread per pixel (ray_sampler.py:197-198, ray_dataset.py:180-181
+// call cv2.cvtColor(pixels, COLOR_YCrCb2RGB) on the truncated u8 frame).  OpenCV's 8-bit path is
+// 14-bit fixed point: R = Y + round(1.403 (Cr - 128)), G = Y + round(-0.714 (Cr - 128) - 0.344
+// (Cb - 128)), B = Y + round(1.773 (Cb - 128)) with the coefficients scaled by 2^14 and rounded
+// (22987, -11698, -5636, 29049), "round" = add 2^13, arithmetic shift right by 14, and a
+// saturating cast to u8.  cv2 is not in this image: restated from OpenCV's documented
+// constants, parity unpinned (like the Dilate-mode ellipse).
+__device__ __forceinline__ int descale14(int v) { return (v + (1 << 13)) >> 14; }
+__device__ __forceinline__ uint8_t saturate_u8(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+
+__global__ void __launch_bounds__(256)
+ycrcb_to_rgb_kernel(uint8_t* __restrict__ image, int64_t pixels) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < pixels;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int y = image[i * 3 + 0];
+        const int cr = (int)image[i * 3 + 1] - 128;
+        const int cb = (int)image[i * 3 + 2] - 128;
+        image[i * 3 + 0] = saturate_u8(y + descale14(cr * 22987));
+        image[i * 3 + 1] = saturate_u8(y + descale14(cb * -5636 + cr * -11698));
+        image[i * 3 + 2] = saturate_u8(y + descale14(cb * 29049));
+    }
+}
+
 static inline int grid_for(int64_t n, int block = 256, int cap = 256 * 8) {
     int64_t g = (n + block - 1) / block;
     if (g > cap) g = cap;
@@ -182,4 +206,12 @@ extern "C" int ffn_to_image(const float* colors, const int64_t* pixel_index, int
     hipLaunchKernelGGL(to_image_kernel, dim3(grid_for(n * 3)), dim3(256), 0, (hipStream_t)stream,
                        colors, pixel_index, n, image);
     return check_launch("ffn_to_image");
+}
+
+extern "C" int ffn_ycrcb_to_rgb_u8(uint8_t* image, int64_t pixels, void* stream) {
+    if (pixels == 0) return 0;
+    if (pixels < 0 || image == nullptr) return fail_arg("ffn_ycrcb_to_rgb_u8: shape");
+    hipLaunchKernelGGL(ycrcb_to_rgb_kernel, dim3(grid_for(pixels)), dim3(256), 0,
+                       (hipStream_t)stream, image, pixels);
+    return check_launch("ffn_ycrcb_to_rgb_u8");
 }

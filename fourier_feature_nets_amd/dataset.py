@@ -16,7 +16,7 @@ import torch.nn as nn
 from . import ops
 from .cameras import CameraInfo, Resolution
 from .sampler import RaySampler, RaySamples
-from .utils import ETABar, RenderResult
+from .utils import ETABar, RenderResult, check_color_space, rgb_to_ycrcb_u8
 
 
 class _MseLoss(torch.autograd.Function):
@@ -62,6 +62,8 @@ class RayDataset(ABC):
         dev = self.sampler.device
         image = ops.to_image(torch.from_numpy(colors).to(dev).contiguous(),
                              pixel.to(dev).contiguous(), res.width, res.height)
+        if self.color_space == "YCrCb":     # ray_dataset.py:180-181
+            ops.ycrcb_to_rgb_u8(image)
         return image.cpu().numpy()
 
     def sample_cameras(self, num_cameras: int, num_samples: int, stratified: bool) -> "RayDataset":
@@ -106,9 +108,7 @@ class ImageDataset(RayDataset):
         assert len(images.shape) == 4
         assert len(images) == len(cameras)
         assert images.dtype == np.uint8
-        if color_space != "RGB":
-            raise NotImplementedError("only the RGB colour space is supported (YCrCb needs OpenCV)")
-        self._color_space = color_space
+        self._color_space = check_color_space(color_space)
         self._mode = RayDataset.Mode.Full
         self.image_height, self.image_width = images.shape[1:3]
         self._images = images
@@ -140,8 +140,11 @@ class ImageDataset(RayDataset):
 
         # u8 -> float32 / 255 on the host with numpy, bit-identical to the reference's
         # ground truth (a GPU division by a constant may differ in the last ulp)
+        rgb = images[..., :3]
+        if color_space == "YCrCb":          # image_dataset.py:114-115, on the u8 image
+            rgb = rgb_to_ycrcb_u8(rgb)
         self.colors = torch.from_numpy(
-            (images[..., :3].astype(np.float32) / 255).reshape(-1, 3)).to(dev).contiguous()
+            (rgb.astype(np.float32) / 255).reshape(-1, 3)).to(dev).contiguous()
         has_alpha = images.shape[-1] == 4
         self._has_alpha = has_alpha
         self._dilate = None        # (index, ranges), built on first use of Mode.Dilate

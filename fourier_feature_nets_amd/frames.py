@@ -40,9 +40,13 @@ class FrameSink:
             if buf.shape == like.shape:
                 return buf
             self._allocated -= 1                  # frame size changed: drop the old buffer
-        if self._allocated >= self._slots:        # ring full: wait for the oldest frame
+        if self._allocated >= self._slots and self._busy:   # ring full: wait for the oldest frame
             future, buf = self._busy.popleft()
-            future.result()
+            try:
+                future.result()
+            except BaseException:
+                self._free.append(buf)            # the buffer stays in the ring when a write failed
+                raise
             if buf.shape == like.shape:
                 return buf
             self._allocated -= 1
@@ -52,8 +56,8 @@ class FrameSink:
     def _reap(self):
         while self._busy and self._busy[0][0].done():
             future, buf = self._busy.popleft()
+            self._free.append(buf)                # recycled whether or not the write succeeded
             future.result()                       # surfaces encoder errors
-            self._free.append(buf)
 
     def submit(self, image: torch.Tensor, path: str):
         """Queues ``image`` (uint8, on a GPU; produced on torch's current stream) for writing
@@ -82,15 +86,25 @@ class FrameSink:
         self.frames += 1
 
     def drain(self):
-        """Blocks until every submitted frame is on disk."""
+        """Blocks until every submitted frame is on disk (or has failed): every future is
+        joined and every buffer recycled before the FIRST failure is re-raised."""
+        first_error = None
         while self._busy:
             future, buf = self._busy.popleft()
-            future.result()
             self._free.append(buf)
+            try:
+                future.result()
+            except BaseException as err:          # noqa: B902 -- re-raised below
+                if first_error is None:
+                    first_error = err
+        if first_error is not None:
+            raise first_error
 
     def close(self):
-        self.drain()
-        self._pool.shutdown(wait=True)
+        try:
+            self.drain()
+        finally:
+            self._pool.shutdown(wait=True)
 
     def __enter__(self):
         return self

@@ -779,6 +779,16 @@ class MlpProgram:
             return color, alpha, depth
         if t_values is not None and tuple(t_values.shape) != (rays, num_samples):
             raise ValueError("t_values must be (num_rays, num_samples)")
+        # the struct fields below are raw integers, which the same-device check of ops._call
+        # cannot see: a sampler / grid / output on another GPU than the model must fail HERE,
+        # not as an illegal access inside the kernel
+        named = dict(starts=starts, directions=directions, near_far=near_far, ray_index=ray_index,
+                     valid=valid, unit=unit, t_values=t_values, nan_flag=nan_flag, image=image,
+                     occupancy=None if occupancy is None else occupancy.bits)
+        for name, tensor in named.items():
+            if tensor is not None and tensor.device != dev:
+                raise RuntimeError("ffn_render_fused_fwd: %s lives on %s but the model is on %s"
+                                   % (name, tensor.device, dev))
         ptr = lambda t, dtype=torch.float32: _dev(t, dtype).value or 0     # noqa: E731
         rr = FfnRenderRays(ptr(starts), ptr(directions), ptr(near_far), int(near_far.shape[1]),
                            ptr(ray_index, torch.int64), base, ptr(valid, torch.uint8), rays,
@@ -840,7 +850,7 @@ class MlpProgram:
                   _dev(ws.unit_seg_start, torch.int32), c_i(WGRAD_GROUPS), _dev(saved),
                   _dev(ws.dz), _dev(d_logits), c_i64(n), _dev(ws.partials),
                   *((_dev(positions, name="positions"), _dev(views, name="views"),
-                     c_i(1 if regenerate is None else int(regenerate))) if wgrad16 else ()))
+                     c_i(int(bool(regenerate)))) if wgrad16 else ()))
         _call("ffn_mlp_wgrad_reduce", _dev(ws.reduce_jobs, torch.uint8),
                   c_i(ws.num_reduce_jobs), _dev(ws.partials), _dev(grads))
         return grads

@@ -35,12 +35,13 @@ class _FusedChainFunction(torch.autograd.Function):
         if track:
             saved = torch.empty((prog.saved_floats(positions.shape[0]),), dtype=torch.float32,
                                 device=positions.device)
+        precision = module.train_precision if track else "f32"
         if not track and module.precision == "bf16x3":
             logits = prog.forward16(positions, views)       # opt-in fast inference mode
         else:
-            logits = prog.forward(positions, views, saved,
-                                  precision=module.train_precision if track else "f32")
+            logits = prog.forward(positions, views, saved, precision=precision)
         ctx.module = module
+        ctx.precision = precision     # backward runs in the mode its forward ran in
         ctx.saved_acts = saved
         ctx.save_for_backward(positions, views)
         return logits
@@ -55,7 +56,7 @@ class _FusedChainFunction(torch.autograd.Function):
         prog = ctx.module.program()
         grads = torch.empty((prog.num_grad_floats,), dtype=torch.float32, device=positions.device)
         prog.backward(d_logits.contiguous(), positions, views, ctx.saved_acts, grads,
-                      precision=ctx.module.train_precision)
+                      precision=ctx.precision)
         ctx.saved_acts = None
         outs = []
         for i, spec in enumerate(prog.layers):
@@ -91,17 +92,14 @@ class _FusedModel(nn.Module):
         parameter's autograd version changes.  Writes that bypass the version counter --
         ``p.data.copy_()`` / ``layer.weight.data.uniform_()``, raw-pointer updates such as the
         fused optimiser kernel -- must be followed by this call, or the next forward uses stale
-        copies.  ``load_state_dict`` and ``train()`` / ``eval()`` switches call it themselves."""
+        copies.  ``load_state_dict`` calls it itself.  (``train()`` / ``eval()`` do not: the mode
+        never changes a weight, and ``render_image`` flips it around every frame.)"""
         self._packed_key = None
 
     def load_state_dict(self, *args, **kwargs):
         out = super().load_state_dict(*args, **kwargs)
         self.invalidate_packed()
         return out
-
-    def train(self, mode: bool = True):
-        self.invalidate_packed()
-        return super().train(mode)
 
     def program(self) -> MlpProgram:
         params = self._dense_params()

@@ -138,6 +138,12 @@ def to_image(colors: torch.Tensor, pixel_index: torch.Tensor, width: int, height
     return img
 
 
+def ycrcb_to_rgb_u8(image: torch.Tensor) -> torch.Tensor:
+    """K8b.  (H,W,3) uint8 YCrCb frame -> RGB, in place (OpenCV's 8-bit COLOR_YCrCb2RGB)."""
+    _call("ffn_ycrcb_to_rgb_u8", _dev(image, torch.uint8, "image"), c_i64(image.numel() // 3))
+    return image
+
+
 # --------------------------------------------------------------------------------- encode
 def fourier_encode(x: torch.Tensor, b: Optional[torch.Tensor], a: Optional[torch.Tensor],
                    scale: float, include_input: bool) -> torch.Tensor:

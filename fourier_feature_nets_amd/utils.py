@@ -59,6 +59,33 @@ def learning_rate_at(initial_learning_rate: float, step: int, decay_rate: float,
     return initial_learning_rate * decay_rate ** (step / decay_steps)
 
 
+def rgb_to_ycrcb_u8(rgb):
+    """(…,3) uint8 RGB -> uint8 YCrCb as cv2.cvtColor(image, cv2.COLOR_RGB2YCrCb) does for 8-bit
+    images (image_dataset.py:114-115): OpenCV's 14-bit fixed-point path -- Y = round(0.299 R +
+    0.587 G + 0.114 B), Cr = round(0.713 (R - Y)) + 128, Cb = round(0.564 (B - Y)) + 128 with the
+    coefficients scaled by 2^14 and rounded (4899, 9617, 1868, 11682, 9241), "round" = add 2^13
+    and shift right by 14 (arithmetic), saturating cast.  One-time host work at dataset
+    construction, like the reference's.  cv2 is not in this image: restated from OpenCV's
+    documented constants, parity unpinned."""
+    import numpy as np
+    v = np.asarray(rgb).astype(np.int32)
+    r, g, b = v[..., 0], v[..., 1], v[..., 2]
+    half = 1 << 13
+    y = (r * 4899 + g * 9617 + b * 1868 + half) >> 14
+    cr = ((r - y) * 11682 + (128 << 14) + half) >> 14
+    cb = ((b - y) * 9241 + (128 << 14) + half) >> 14
+    return np.clip(np.stack([y, cr, cb], -1), 0, 255).astype(np.uint8)
+
+
+COLOR_SPACES = ("RGB", "YCrCb")
+
+
+def check_color_space(color_space: str) -> str:
+    if color_space not in COLOR_SPACES:
+        raise NotImplementedError("Unsupported color space: {}".format(color_space))
+    return color_space
+
+
 class RenderResult(NamedTuple("RenderResult", [("color", torch.Tensor), ("alpha", torch.Tensor),
                                                ("depth", torch.Tensor)])):
     """Per-ray colour, alpha and (optionally) depth."""

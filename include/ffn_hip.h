@@ -180,6 +180,15 @@ int ffn_to_image(const float* colors, const int64_t* pixel_index, int64_t n, int
                  int height, uint8_t* image, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * K8b  8-bit YCrCb -> RGB, in place on a (pixels,3) u8 frame.  Replaces
+ * cv2.cvtColor(pixels, cv2.COLOR_YCrCB2RGB) at ray_sampler.py:197-198 and
+ * ray_dataset.py:180-181 (color_space == "YCrCb").  OpenCV's 8-bit fixed-point path
+ * (coefficients x 2^14, rounded shift, saturating cast), restated from its documented
+ * constants -- cv2 is not available where this library is built: parity unpinned.
+ */
+int ffn_ycrcb_to_rgb_u8(uint8_t* image, int64_t pixels, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * K4  fused Fourier-feature MLP (sigma + view-dependent RGB), exact-f32 MFMA.
  * Replaces FourierFeatureMLP.forward (fourier_feature_models.py:57-78), NeRF.forward
  * (nerf_model.py:86-124) and their autograd backward.

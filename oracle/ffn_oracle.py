@@ -418,6 +418,52 @@ def to_image(valid_local: np.ndarray, colors: np.ndarray, width: int,
     return (px.reshape(height, width, 3) * 255).astype(np.uint8)
 
 
+def rgb_to_ycrcb_u8(rgb: np.ndarray) -> np.ndarray:
+    """8-bit RGB -> YCrCb the way ``cv2.cvtColor(color, cv2.COLOR_RGB2YCrCb)`` computes it
+    (call site image_dataset.py:114-115).
+
+    Third-party algorithm: OpenCV (``opencv-python`` is unpinned in requirements.txt:3 and
+    absent from this image), restated from its published 8-bit fixed-point path
+    (imgproc colour conversions, ``yuv_shift = 14``):
+        Y  = descale(R*4899 + G*9617 + B*1868)          # 0.299, 0.587, 0.114
+        Cr = descale((R - Y)*11682 + 128*2^14)          # 0.713, delta = 128
+        Cb = descale((B - Y)*9241  + 128*2^14)          # 0.564
+    with ``descale(x) = (x + 2^13) >> 14`` and a saturating cast to uint8.
+    **Parity unpinned**: the reference's tests hold no vector for it and cv2 cannot be
+    imported here; pinned only against the known answers OpenCV's documentation implies
+    (tests/test_oracle_golden.py::test_ycrcb_known_answers).  Written with plain Python
+    integers per pixel channel on purpose: an independent statement from the product's
+    vectorised host code.
+    """
+    flat = np.asarray(rgb, np.uint8).reshape(-1, 3)
+    out = np.empty_like(flat)
+    for i, (r, g, b) in enumerate(flat.tolist()):
+        y = (r * 4899 + g * 9617 + b * 1868 + 8192) >> 14
+        cr = ((r - y) * 11682 + 128 * 16384 + 8192) >> 14
+        cb = ((b - y) * 9241 + 128 * 16384 + 8192) >> 14
+        out[i] = [min(max(v, 0), 255) for v in (y, cr, cb)]
+    return out.reshape(np.asarray(rgb).shape)
+
+
+def ycrcb_to_rgb_u8(ycrcb: np.ndarray) -> np.ndarray:
+    """8-bit YCrCb -> RGB like ``cv2.cvtColor(pixels, cv2.COLOR_YCrCB2RGB)`` (call sites
+    ray_sampler.py:197-198, ray_dataset.py:180-181).  OpenCV's published fixed-point inverse:
+        R = Y + descale((Cr-128)*22987)                          # 1.403
+        G = Y + descale((Cb-128)*(-5636) + (Cr-128)*(-11698))    # -0.344, -0.714
+        B = Y + descale((Cb-128)*29049)                          # 1.773
+    saturated to uint8.  Parity unpinned (see ``rgb_to_ycrcb_u8``)."""
+    flat = np.asarray(ycrcb, np.uint8).reshape(-1, 3)
+    out = np.empty_like(flat)
+    for i, (y, cr, cb) in enumerate(flat.tolist()):
+        cr -= 128
+        cb -= 128
+        r = y + ((cr * 22987 + 8192) >> 14)
+        g = y + ((cb * -5636 + cr * -11698 + 8192) >> 14)
+        b = y + ((cb * 29049 + 8192) >> 14)
+        out[i] = [min(max(v, 0), 255) for v in (r, g, b)]
+    return out.reshape(np.asarray(ycrcb).shape)
+
+
 def crop_points(width: int, height: int) -> np.ndarray:
     """Pixel ids of the central half-size crop.  Restates image_dataset.py:77-90."""
     res = np.array([width, height], np.float32)

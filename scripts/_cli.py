@@ -7,6 +7,12 @@ import os
 
 import numpy as np
 
+# not a flag of the reference: how --opacity-model drives the focus samples.  "table" = the
+# reference's per-ray CDF table built at start-up (ray_sampler.py:148-166); "live" = no table, the
+# coarse model is evaluated per batch inside the sampling kernel -- bit-identical t-values for a
+# frozen opacity model, which a checkpoint loaded by these drivers always is, so "auto" means live
+FOCUS_MODE = ("--focus-mode", dict(choices=["auto", "table", "live"], default="auto"))
+
 # (flag, kwargs) -- names/defaults follow train_nerf.py:14-71, train_tiny_nerf.py:14-66 and
 # orbit_video.py:16-40 of the reference so that command lines carry over unchanged
 TRAIN_COMMON = [
@@ -39,6 +45,7 @@ TRAIN_COMMON = [
     ("--skip-empty-space", dict(action="store_true")),
     ("--skip-warmup", dict(type=int, default=1000)),
     ("--skip-refresh", dict(type=int, default=500)),
+    FOCUS_MODE,
 ]
 NERF_ONLY = [
     ("--resolution", dict(type=int, default=400)),
@@ -73,6 +80,7 @@ ORBIT = [
     ("--batch_size", dict(type=int, default=4096)),
     ("--device", dict(default="cuda")),
     ("--precision", dict(choices=["f32", "bf16x3"], default="f32")),   # not a flag of the reference
+    FOCUS_MODE,
 ]
 
 
@@ -124,6 +132,12 @@ def apply_precision(model, precision: str):
         model.precision = precision
         model.train_precision = precision
     return model
+
+
+def focus_mode(args) -> str:
+    """--focus-mode for samplers whose opacity model is a frozen checkpoint: auto -> live."""
+    mode = getattr(args, "focus_mode", "auto")
+    return "live" if mode == "auto" else mode
 
 
 def apply_skipping(caster, args):

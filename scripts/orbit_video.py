@@ -31,7 +31,7 @@ def main():
     mine = list(range(rank, args.num_frames, world))
     caster = ffn.Raycaster(_cli.apply_precision(model, args.precision))
     sampler = ffn.RaySampler(bounds, [cameras[f] for f in mine], args.num_samples, False, opacity,
-                             args.batch_size, device=device)
+                             args.batch_size, device=device, focus_mode=_cli.focus_mode(args))
     os.makedirs(args.output_dir, exist_ok=True)
     bar = ffn.ETABar("Rendering", max=len(mine))
     # frames stay on the GPU until the sink's side stream copies them out; PNG encoding runs on

@@ -27,9 +27,11 @@ def main():
     train = ffn.ImageDataset.load(args.data_path, "train", args.num_samples, with_alpha, True,
                                   opacity, args.batch_size, args.color_space,
                                   anneal_start=args.anneal_start,
-                                  num_anneal_steps=args.num_anneal_steps, device=args.device)
+                                  num_anneal_steps=args.num_anneal_steps, device=args.device,
+                                  focus_mode=_cli.focus_mode(args))
     val = ffn.ImageDataset.load(args.data_path, "val", args.num_samples, with_alpha, False,
-                                opacity, args.batch_size, args.color_space, device=args.device)
+                                opacity, args.batch_size, args.color_space, device=args.device,
+                                focus_mode=_cli.focus_mode(args))
     if train is None or val is None:
         return 1
     if args.mode == "dilate":

@@ -281,6 +281,7 @@ def test_driver_scripts_keep_the_reference_flags_and_defaults():
         # the extensions: --precision (opt-in split-bf16 kernels) and the opt-in empty-space
         # skipping schedule; the defaults are the exact mode
         assert mine[name].pop("precision") == "f32"
+        assert mine[name].pop("focus_mode") == "auto"        # extension: table / live CDFs
         if name != "orbit_video":
             assert mine[name].pop("skip_empty_space") is False
             assert (mine[name].pop("skip_warmup"), mine[name].pop("skip_refresh")) == (1000, 500)
@@ -333,3 +334,18 @@ def test_wgrad_split_is_balanced_and_plan_buckets_are_tight():
         planned = MlpProgram.plan_blocks(n)
         assert blocks <= planned <= blocks + max(0, blocks // 32)
         assert MlpProgram.plan_blocks(planned * 32) == planned          # idempotent
+
+
+def test_host_ycrcb_conversion_equals_the_oracle():
+    """The vectorised host conversion used at dataset construction (utils.rgb_to_ycrcb_u8)
+    against the oracle's per-pixel restatement, incl. every corner of the colour cube."""
+    from fourier_feature_nets_amd.utils import check_color_space, rgb_to_ycrcb_u8
+    rng = np.random.default_rng(11)
+    corners = np.array([[r, g, b] for r in (0, 255) for g in (0, 255) for b in (0, 255)], np.uint8)
+    rgb = np.concatenate([corners, rng.integers(0, 256, (3000, 3), dtype=np.uint8)])
+    assert np.array_equal(rgb_to_ycrcb_u8(rgb), orc.rgb_to_ycrcb_u8(rgb))
+    image = rng.integers(0, 256, (5, 7, 3), dtype=np.uint8)          # keeps the array shape
+    assert rgb_to_ycrcb_u8(image).shape == image.shape
+    assert check_color_space("YCrCb") == "YCrCb"
+    with pytest.raises(NotImplementedError):
+        check_color_space("HSV")

@@ -258,6 +258,30 @@ def test_to_image_truncates(golden):
     assert np.array_equal(img, g["to_image"])
 
 
+def test_ycrcb_known_answers():
+    """a6, colour space "YCrCb" (image_dataset.py:114-115, ray_sampler.py:197-198).  cv2 is not
+    importable here, so the restatement is pinned only against the triples OpenCV's documented
+    8-bit conversion gives for the primaries / greys (parity UNPINNED otherwise), plus the
+    properties of the pair: greys map to (v, 128, 128) and back exactly, and the round trip
+    stays within the fixed-point error (<= 2 levels) wherever no channel saturated."""
+    prim = np.array([[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 255], [0, 0, 0],
+                     [128, 128, 128]], np.uint8)
+    expect = np.array([[76, 255, 85], [150, 21, 43], [29, 107, 255], [255, 128, 128],
+                       [0, 128, 128], [128, 128, 128]], np.uint8)
+    assert np.array_equal(orc.rgb_to_ycrcb_u8(prim), expect)
+    greys = np.repeat(np.arange(256, dtype=np.uint8)[:, None], 3, 1)
+    ycc = orc.rgb_to_ycrcb_u8(greys)
+    assert np.array_equal(ycc[:, 0], greys[:, 0]) and np.all(ycc[:, 1:] == 128)
+    assert np.array_equal(orc.ycrcb_to_rgb_u8(ycc), greys)
+    rng = np.random.default_rng(5)
+    rgb = rng.integers(0, 256, (4000, 3), dtype=np.uint8)
+    ycc = orc.rgb_to_ycrcb_u8(rgb)
+    back = orc.ycrcb_to_rgb_u8(ycc).astype(np.int32)
+    inside = ((ycc > 0) & (ycc < 255)).all(1)
+    assert inside.sum() > 3000
+    assert np.abs(back - rgb.astype(np.int32))[inside].max() <= 2
+
+
 # ----------------------------------------------------------------------------- a14
 def test_lr_decay_table(golden):
     g = golden("training")
