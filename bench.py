@@ -287,8 +287,6 @@ def target_shape_leg(device):
     total_ms = sum(k["avg_ms"] for k in kernels.values())
     all_flops = sum(k["flop_per_sample"] for k in kernels.values()) * n
     del saved, pos, view, d_logits
-    prog._workspaces.clear()
-    torch.cuda.empty_cache()
     tf = all_flops / (total_ms * 1e-3) / 1e12
     return {"workload": "NeRF(8,256,9,10,3,4,[4],True), one launch of 65536 rays x 128 samples "
                         "(fused Fourier-MLP kernels only)",
@@ -395,7 +393,7 @@ def config3_leg(device, cams, images, bounds, rays_per_step=65536, steps=3):
         fine.train_precision = "f32"
         coarse.precision = "f32"
     del engine
-    prog._workspaces.clear()
+    prog.release_workspaces()
     torch.cuda.empty_cache()
     # frames/sec of the full NeRF, 128 samples/ray, fused render (a plain uniform sampler like
     # orbit_video without an opacity model: every pixel ray of the frame)
@@ -554,7 +552,7 @@ def config5_leg(device, bounds, rays_per_step=32768, samples=128, cameras=25, si
             entry["label"] = "opt-in empty-space skipping: not the reference's semantics"
         out[label] = entry
         del engine
-        prog._workspaces.clear()
+        prog.release_workspaces()
         torch.cuda.empty_cache()
     return out
 
@@ -888,7 +886,7 @@ def main():
         state = {k: v.detach().clone() for k, v in model.state_dict().items()}
         # free the headline leg's buffers before the large reporting-only legs
         del engine, caster
-        prog._workspaces.clear()
+        prog.release_workspaces()
         torch.cuda.empty_cache()
         result["north_star_shape"] = target_shape_leg(device) if solo and not args.no_target_shape else None
         result["config3_step"] = (config3_leg(device, cams, images, bounds)

@@ -53,11 +53,14 @@ class TrainEngine:
     """One optimisation step as a straight line of kernel launches over flat buffers."""
 
     def __init__(self, model: nn.Module, weight_decay: float = 0.0, process_group=None,
-                 max_samples_per_launch: int = 1 << 23):
+                 max_samples_per_launch: int = 1 << 22):
         """``max_samples_per_launch`` bounds the activation slabs kept for backward (saved
-        activations + dZ: 8.3 KB per sample for the tiny NeRF, 21 KB for the full one): larger batches run as several
-        forward/backward launches whose gradients are summed before the (single) all-reduce
-        and optimiser step -- numerically the same step."""
+        activations + dZ: 8.3 KB per sample for the tiny NeRF, 21 KB for the full one, i.e.
+        34 / 88 GB at the default of 2^22 samples -- whatever the batch size): larger batches
+        run as several forward/backward launches whose gradients are summed before the (single)
+        all-reduce and optimiser step -- numerically the same step.  2^22 samples are 128 blocks
+        of 32 per wavefront of the persistent kernels: launch and tail effects stay under 1 %
+        (the headline batch, 65 536 rays x 64 samples, is exactly one launch)."""
         self.model = model
         self.max_samples = int(max_samples_per_launch)
         params = model._dense_params()
@@ -216,6 +219,34 @@ class TrainEngine:
             e1.record()
             events.append((e0, e1))
 
+    def reduce_small(self, values: torch.Tensor) -> torch.Tensor:
+        """Sum of a few device floats over the ranks (sharded validation): in place."""
+        if self.group is None:
+            return values
+        import torch.distributed as dist
+        if self._host_staged:
+            host = values.cpu()
+            dist.all_reduce(host, group=self.group)
+            values.copy_(host)
+        else:
+            dist.all_reduce(values, group=self.group)
+        return values
+
+    def shared_seed(self, draw) -> int:
+        """``draw()`` evaluated on rank 0 (a non-negative int < 2^62) and made known to every
+        rank with one 8-byte broadcast -- what data parallel needs to walk ONE permutation
+        without shipping it ("the shuffle permutation must be generated from a
+        shared seed")."""
+        if self.group is None:
+            return int(draw())
+        import torch.distributed as dist
+        root = dist.get_global_rank(self.group, 0)
+        value = int(draw()) if dist.get_rank(self.group) == 0 else 0
+        seed = torch.tensor([value], dtype=torch.int64,
+                            device="cpu" if self._host_staged else self.device)
+        dist.broadcast(seed, root, group=self.group)
+        return int(seed.item())
+
     def eval_loss(self, dataset, batch, step: Optional[int]) -> torch.Tensor:
         """Forward-only loss of a batch (the body of ``_validate``)."""
         sampler = dataset.sampler
@@ -244,7 +275,12 @@ class Raycaster(nn.Module):
         nn.Module.__init__(self)
         self.model = model
         self._nan_flag = None
-        self.shuffle_source = "numpy"     # epoch permutations from np.random like the reference
+        # epoch permutations: "numpy" = np.random.shuffle on the host like the reference
+        # (ray_caster.py:312-313); "device" = torch.randperm on the GPU from torch's generator;
+        # "seeded" = one seed drawn from np.random per epoch, permutation by a device randperm
+        # from that seed.  Data parallel always runs "seeded" with rank 0's seed (8 bytes
+        # broadcast per epoch instead of the 128-512 MB permutation itself).
+        self.shuffle_source = "numpy"
         self.process_group = None         # set to a torch.distributed group for data parallel
         self.occupancy = None             # an OccupancyGrid switches on empty-space skipping (no_grad renders)
         self.fused_render = True          # render_image / render_rays through the one-launch kernel
@@ -401,17 +437,44 @@ class Raycaster(nn.Module):
         else:
             index = np.arange(num_rays)
         index = torch.from_numpy(np.asarray(index, np.int64)).to(engine.device)
-        losses = []
+        starts = [s for s in range(0, num_validate, batch_size) if s + batch_size <= len(index)]
         self.model.eval()
-        for start in range(0, num_validate, batch_size):
-            if start + batch_size > len(index):
-                break
-            losses.append(engine.eval_loss(dataset, index[start:start + batch_size], step))
+        if not starts:                       # tiny dataset: one short batch instead of a crash
+            mean = float(engine.eval_loss(dataset, index, step).item())
+        else:
+            # data parallel: the batches are dealt round-robin to the ranks and the partial sums
+            # meet in one tiny all-reduce (every rank reports the same PSNR)
+            mine = starts
+            if engine.group is not None:
+                import torch.distributed as dist
+                mine = starts[dist.get_rank(engine.group)::dist.get_world_size(engine.group)]
+            losses = [engine.eval_loss(dataset, index[s:s + batch_size], step) for s in mine]
+            total = torch.stack(losses).sum().reshape(1) if losses else \
+                torch.zeros((1,), dtype=torch.float32, device=engine.device)
+            mean = float(engine.reduce_small(total).item()) / len(starts)
         self.model.train()
-        if not losses:                       # tiny dataset: one short batch instead of a crash
-            losses.append(engine.eval_loss(dataset, index, step))
-        mean = float(torch.stack(losses).mean().item())
         return float(-10. * np.log10(mean))
+
+    def _epoch_order(self, num_rays: int, engine: TrainEngine) -> torch.Tensor:
+        """One epoch's permutation of the dataset-local indices, on the device."""
+        source = self.shuffle_source
+        if self.process_group is not None and source == "numpy":
+            source = "seeded"                # every rank must walk the same permutation
+        if source == "numpy":
+            order = np.arange(num_rays)
+            np.random.shuffle(order)
+            return torch.from_numpy(order).to(engine.device)
+        if source == "device" and self.process_group is None:
+            return torch.randperm(num_rays, device=engine.device)
+        if source == "device":
+            draw = lambda: int(torch.randint(0, 2 ** 62, (1,)).item())        # noqa: E731
+        elif source == "seeded":
+            draw = lambda: int(np.random.randint(0, 2 ** 62, dtype=np.int64))  # noqa: E731
+        else:
+            raise ValueError("shuffle_source is 'numpy', 'device' or 'seeded'")
+        generator = torch.Generator(device=engine.device)
+        generator.manual_seed(engine.shared_seed(draw))
+        return torch.randperm(num_rays, generator=generator, device=engine.device)
 
     def fit(self, train_dataset: RayDataset, val_dataset: RayDataset, batch_size: int,
             learning_rate: float, num_steps: int, crop_steps: int, report_interval: int,
@@ -422,9 +485,14 @@ class Raycaster(nn.Module):
                                                         val_dataset.num_samples, False)
         engine = TrainEngine(self.model, weight_decay, self.process_group)
         self.engine = engine
-        if self.process_group is not None:
-            torch.distributed.broadcast(engine.flat, torch.distributed.get_global_rank(self.process_group, 0),
-                                        group=self.process_group)
+        if self.process_group is not None:       # every rank starts from rank 0's weights
+            root = torch.distributed.get_global_rank(self.process_group, 0)
+            if engine._host_staged:
+                host = engine.flat.cpu()
+                torch.distributed.broadcast(host, root, group=self.process_group)
+                engine.flat.copy_(host)
+            else:
+                torch.distributed.broadcast(engine.flat, root, group=self.process_group)
             self.model.invalidate_packed()
         step = 0
         start_time = time.time()
@@ -446,17 +514,7 @@ class Raycaster(nn.Module):
         is_main = self.process_group is None or torch.distributed.get_rank(self.process_group) == 0
         while step <= num_steps:
             num_rays = len(train_dataset)
-            if self.shuffle_source == "numpy":
-                order = np.arange(num_rays)
-                np.random.shuffle(order)
-                order = torch.from_numpy(order).to(engine.device)
-            else:
-                order = torch.randperm(num_rays, device=engine.device)
-            if self.process_group is not None:
-                # data parallel: every rank walks rank 0's permutation (and must hold the same
-                # initial weights: broadcast once, below)
-                torch.distributed.broadcast(order, torch.distributed.get_global_rank(self.process_group, 0),
-                                            group=self.process_group)
+            order = self._epoch_order(num_rays, engine)
             # valid-ray filter of the whole epoch in one go (one sync per epoch, not per step)
             epoch_rays, bounds = train_dataset.epoch_ray_ids(order, batch_size)
             for bi, start in enumerate(range(0, num_rays, batch_size)):

@@ -174,17 +174,22 @@ def _tiles(channels: int, wide: bool = False) -> int:
 
 
 class Workspace:
-    """Per-batch-size device buffers of the training path."""
+    """Per-batch-size plans of the training path.  The dZ slabs themselves are ONE grow-only
+    buffer per program shared by every batch size (3 KiB per sample for the tiny NeRF, 9.5 KiB
+    for the full one: a buffer per size would multiply tens of GB by the number of sizes seen)."""
 
     def __init__(self, prog: "MlpProgram", n: int):
-        dev = prog.device
         self.n = n
         blocks = (n + 31) // 32
-        self.dz = torch.empty((prog.dz_channels * 32 * blocks,), dtype=torch.float32, device=dev)
+        self._dz_floats = prog.dz_channels * 32 * blocks
         self._prog, self._blocks = prog, blocks
         self._plans = {}
         self.partials = None
         self.use_plan("f32")
+
+    @property
+    def dz(self) -> torch.Tensor:
+        return self._prog._dz_buffer(self._dz_floats)
 
     def use_plan(self, precision: str):
         """Selects the weight-gradient plan (segments balanced with the kernel's cost model:
@@ -233,6 +238,21 @@ class MlpProgram:
         self._build_wgrad_jobs()
         self._build_forward16()
         self._build_backward16()
+
+    def _dz_buffer(self, floats: int) -> torch.Tensor:
+        """The shared dZ workspace, grown (old buffer released first) when a larger batch shows up."""
+        buf = getattr(self, "_dz", None)
+        if buf is None or buf.numel() < floats:
+            self._dz = buf = None
+            self._dz = buf = torch.empty((floats + floats // 16,), dtype=torch.float32,
+                                         device=self.device)
+        return buf[:floats]
+
+    def release_workspaces(self):
+        """Drops the dZ buffer and the per-size plans (they are rebuilt on demand): for callers
+        that switch from one large workload to another inside one process."""
+        self._dz = None
+        self._workspaces.clear()
 
     # ------------------------------------------------------------------ chains
     def _fill_encodings(self, chain):

@@ -60,3 +60,41 @@ def dp_train_worker(rank, world, port, out_path, steps, max_samples):
         dist.barrier()
     finally:
         dist.destroy_process_group()
+
+
+def run_fit(group, steps=12, report=4):
+    """`Raycaster.fit` for ``steps`` optimisation steps with a report (two validations, a log
+    entry) every ``report`` steps, crop curriculum included, on a non-stratified training set so
+    that sharded and unsharded runs see the same samples.  Epoch permutations come from ONE seed
+    per epoch (np.random on rank 0).  Returns (printed lines, log psnrs, flat weights)."""
+    import fourier_feature_nets_amd as ffn
+    device = torch.device("cuda:0")
+    np.random.seed(5)
+    torch.manual_seed(5)
+    model = small_model(device)
+    with contextlib.redirect_stdout(io.StringIO()):
+        train = ffn.ImageDataset.load(SCENE, "train", 16, True, False, anneal_start=0.2,
+                                      num_anneal_steps=6, device=device)
+        val = ffn.ImageDataset.load(SCENE, "val", 16, True, False, device=device)
+    caster = ffn.Raycaster(model)
+    caster.process_group = group
+    caster.shuffle_source = "seeded"
+    out = io.StringIO()
+    with contextlib.redirect_stdout(out):
+        log = caster.fit(train, val, 96, 5e-4, steps, 4, report, 0.1, 25000, 0.0, [])
+    psnr = [(e.step, e.train_psnr, e.val_psnr) for e in log]
+    return out.getvalue().splitlines(), psnr, caster.engine.flat.detach().cpu().clone()
+
+
+def dp_fit_worker(rank, world, port, out_path):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lines, psnr, flat = run_fit(dist.group.WORLD)
+        torch.save({"lines": lines, "psnr": psnr, "flat": flat}, out_path + ".%d" % rank)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
