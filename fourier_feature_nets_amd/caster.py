@@ -458,7 +458,8 @@ class Raycaster(nn.Module):
     def _epoch_order(self, num_rays: int, engine: TrainEngine) -> torch.Tensor:
         """One epoch's permutation of the dataset-local indices, on the device."""
         source = self.shuffle_source
-        if self.process_group is not None and source == "numpy":
+        if source == "numpy" and self.process_group is not None and \
+                torch.distributed.get_world_size(self.process_group) > 1:
             source = "seeded"                # every rank must walk the same permutation
         if source == "numpy":
             order = np.arange(num_rays)

@@ -168,51 +168,87 @@ def test_subsample_index_filter_matches_the_list_filter(mode):
 
 
 # ----------------------------------------------------------------------------------- split-bf16 vs the reference
+def _golden_grad_errors(g, name, named, flat, prog, check_sums=True):
+    """(worst per-tensor max error / tensor scale, relative L2 over all compared entries) of the
+    flat gradient buffer ``flat`` against models.npz:<name>/grad/* (full tensors, or the first
+    512 entries + sum for the big ones)."""
+    worst = num = den = 0.0
+    for (key, par), spec, w0, b0 in zip(named[0::2], prog.layers, prog.grad_w_off, prog.grad_b_off):
+        assert key.endswith("weight") and tuple(par.shape) == (spec.out, spec.ld)
+        for suffix, got in ((key, flat[w0:w0 + spec.out * spec.ld]),
+                            (key[:-len("weight")] + "bias", flat[b0:b0 + spec.out])):
+            got = got.detach().cpu().double().reshape(-1)
+            scale = max(float(got.abs().max()), 1e-12)
+            full = "%s/grad/%s" % (name, suffix)
+            if full in g.files:
+                ref = _t(g[full]).double().reshape(-1)
+            else:
+                ref = _t(g["%s/gradhead/%s" % (name, suffix)]).double()
+                total = float(g["%s/gradsum/%s" % (name, suffix)])
+                mass = float(g["%s/gradabs/%s" % (name, suffix)])
+                if check_sums:
+                    assert abs(float(got.sum()) - total) <= 1e-4 * mass, suffix
+                got = got[:512]
+            err = (got - ref).abs()
+            worst = max(worst, float(err.max()) / scale)
+            num += float((err ** 2).sum())
+            den += float((ref ** 2).sum())
+    return worst, (num / den) ** 0.5
+
+
 @pytest.mark.parametrize("name", ["mlp", "basic", "positional", "gaussian", "nerf", "nerf_small"])
 def test_split_bf16_gradients_against_the_reference_goldens(golden, name):
-    """`train_precision = "bf16x3"` pinned DIRECTLY against the reference's gradients
+    """The split-bf16 TRAINING kernels pinned directly against the reference's gradients
     (tests/golden/models.npz:*/grad/*, captured from the reference's autograd), not only against
-    the f32 twin: every parameter gradient within 1e-3 of its tensor's scale, relative L2 over
-    all compared entries <= 1e-4 (exact-f32 kernels: 5e-4 abs; the split products carry 16
-    mantissa bits per operand)."""
+    their f32 twins:
+    (a) backward-data + weight-gradient kernels in bf16x3 on the activations / ReLU decisions of
+        the exact forward: every parameter gradient within 2e-4 of its tensor's scale, relative
+        L2 over all compared entries <= 1e-4 (measured 8e-5 / 3.6e-5; exact kernels 4e-5 / 7e-6);
+    (b) the whole bf16x3 path (its own forward): logits within 2e-4 of the reference's; its ReLU
+        decisions differ from the exact forward's in at most a handful of (unit, sample) pairs --
+        pre-activations within ~1e-5 relative of zero -- and where NONE differs the gradients
+        meet (a)'s bound.  A differing decision is a discontinuity of the function being
+        differentiated, not an arithmetic error: ONE flip among the 257 golden samples moves
+        entries of the layers below by up to 5e-2 of their scale (measured: positional 1 flip,
+        full NeRF 3), which is why round 2's twin test had to allow 1e-2."""
     from tests.test_kernels_gpu import _load_fourier, _load_nerf
     g = golden("models")
     if name.startswith("nerf"):
         model, _ = _load_nerf(g, name, [4] if name == "nerf" else [2], name == "nerf")
-        args = (_t(g["x"]).to(dev()), _t(g["v"]).to(dev()))
+        x, v = _t(g["x"]).to(dev()), _t(g["v"]).to(dev())
     else:
         model, _ = _load_fourier(g, name)
-        args = (_t(g["x"]).to(dev()),)
-    model.train_precision = "bf16x3"
-    y = model(*args)
-    probe = torch.linspace(-1, 1, y.numel()).reshape(y.shape).to(dev())
-    (y * probe).sum().backward()
-    np.testing.assert_allclose(y.detach().cpu().numpy(), g[name + "/out"], rtol=2e-4,
-                               atol=2e-4 * max(float(np.abs(g[name + "/out"]).max()), 1.0))
-    num = den = 0.0
-    compared = 0
-    for key, par in model.named_parameters():
-        if not par.requires_grad:
-            continue
-        got = par.grad.detach().cpu().double().reshape(-1)
-        full = "%s/grad/%s" % (name, key)
-        if full in g.files:
-            ref = _t(g[full]).double().reshape(-1)
-        else:                       # big tensors: the golden keeps the first 512 entries + sums
-            ref = _t(g["%s/gradhead/%s" % (name, key)]).double()
-            got_all = got
-            got = got[:512]
-            total = float(g["%s/gradsum/%s" % (name, key)])
-            mass = float(g["%s/gradabs/%s" % (name, key)])
-            assert abs(float(got_all.sum()) - total) <= 1e-4 * max(mass, 1e-6), key
-            assert abs(float(got_all.abs().sum()) - mass) <= 1e-4 * max(mass, 1e-6), key
-        scale = max(float(ref.abs().max()), 1e-6)
-        assert float((got - ref).abs().max()) <= 1e-3 * scale, (key, float((got - ref).abs().max()), scale)
-        num += float(((got - ref) ** 2).sum())
-        den += float((ref ** 2).sum())
-        compared += 1
-    assert compared >= 4
-    assert (num / den) ** 0.5 <= 1e-4, (num / den) ** 0.5
+        x, v = _t(g["x"]).to(dev()), None
+    prog = model.program()
+    named = [(k, p) for k, p in model.named_parameters() if p.requires_grad]
+    assert len(named) == 2 * len(prog.layers)
+    n = x.shape[0]
+    probe = torch.linspace(-1, 1, n * 4).reshape(n, 4).to(dev())      # d(loss)/d(logits) of the golden loss
+    saved = {}
+    logits = {}
+    for mode in ("f32", "bf16x3"):
+        saved[mode] = torch.zeros((prog.saved_floats(n),), dtype=torch.float32, device=dev())
+        logits[mode] = prog.forward(x, v, saved[mode], precision=mode)
+    out_scale = max(float(np.abs(g[name + "/out"]).max()), 1.0)
+    np.testing.assert_allclose(logits["bf16x3"].cpu().numpy(), g[name + "/out"], rtol=2e-4, atol=2e-4 * out_scale)
+    # (a) bf16x3 backward on the exact forward's state
+    flat = torch.zeros((prog.num_grad_floats,), dtype=torch.float32, device=dev())
+    prog.backward(probe, x, v, saved["f32"], flat, precision="bf16x3")
+    worst, rel = _golden_grad_errors(g, name, named, flat, prog)
+    assert worst <= 2e-4 and rel <= 1e-4, (worst, rel)
+    # (b) the whole bf16x3 path
+    _, masks_e = prog._split_saved(saved["f32"], n)
+    _, masks_f = prog._split_saved(saved["bf16x3"], n)
+    diff = (masks_e.view(torch.int32) ^ masks_f.view(torch.int32)).cpu().numpy().astype(np.uint32)
+    flips = int(sum(bin(int(w)).count("1") for w in diff[diff != 0]))
+    assert flips <= 8, flips
+    flat16 = torch.zeros_like(flat)
+    prog.backward(probe, x, v, saved["bf16x3"], flat16, precision="bf16x3")
+    worst16, rel16 = _golden_grad_errors(g, name, named, flat16, prog, check_sums=flips == 0)
+    if flips == 0:
+        assert worst16 <= 2e-4 and rel16 <= 1e-4, (worst16, rel16)
+    else:
+        assert worst16 <= 0.1 * flips and rel16 <= 2e-2 * flips, (flips, worst16, rel16)
 
 
 # ----------------------------------------------------------------------------------- data parallel fit
