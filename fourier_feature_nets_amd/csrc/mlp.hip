@@ -87,7 +87,7 @@ __device__ __forceinline__ void generate_features(const EncRegs& enc, int c0, in
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             act[(g + u) * 64 + lane] = v[u];
-            if (SAVE) fsave[(2 * (c0 + g + u) + h) * 32 + (s ^ ((2 * (c0 + g + u) + h) & 15))] = v[u];
+            if (SAVE) __builtin_nontemporal_store(v[u], &fsave[(2 * (c0 + g + u) + h) * 32 + (s ^ ((2 * (c0 + g + u) + h) & 15))]);
         }
     }
 }
@@ -258,8 +258,8 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
         const unsigned save_lane = (unsigned)(w.h * 512 + ((w.s ^ w.h) << 4));
         char* save_s = reinterpret_cast<char*>(save);
 #define FFN_SAVE(g, value)                                                                     \
-    *reinterpret_cast<f32x4*>(save_s + (int64_t)(g) * 1024 +                                   \
-                              (save_lane ^ (unsigned)((((g) * 2) & 15) << 4))) = (value)
+    __builtin_nontemporal_store((value), reinterpret_cast<f32x4*>(save_s + (int64_t)(g) * 1024 +   \
+                              (save_lane ^ (unsigned)((((g) * 2) & 15) << 4))))
         const f32x4* xa = w.act + w.lane;
         x0 = xa[0];
         x1 = xa[64];
@@ -373,7 +373,7 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
                     y[p] = __builtin_bit_cast(float, __builtin_bit_cast(int, a) & keep);   // element reads lane 0)
                 }
                 w.act[group * 64 + e_lane] = y;
-                if (save_y) save_out[saved_index(2 * group + e_h, e_s)] = y;
+                if (save_y) __builtin_nontemporal_store(y, &save_out[saved_index(2 * group + e_h, e_s)]);
             } else {
                 // fused head: this quad's four weight rows are requested BEFORE its ReLU / sign-bit
                 // work and its slab write (which the compiler must keep them ordered against), so
@@ -401,7 +401,7 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
 #pragma unroll
                             for (int c = 0; c < 4; ++c) w.logit[c] = __builtin_fmaf(y[p], hw4[p][c], w.logit[c]);
                         }
-                        if (MODE == kTrainFwd && save_y) save_out[saved_index(2 * group + e_h, e_s)] = y;
+                        if (MODE == kTrainFwd && save_y) __builtin_nontemporal_store(y, &save_out[saved_index(2 * group + e_h, e_s)]);
                     }
                 } else if (!WIDE && o == 0 && q == 0) {
                     // real outputs = rows 0..out_n-1 of tile 0 = registers 0..3 of h == 0

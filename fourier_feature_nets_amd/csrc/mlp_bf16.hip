@@ -185,8 +185,8 @@ __device__ __forceinline__ void step16(const ffn_mlp_chain& ch, const ffn_step& 
                     f32x4 f0, f1;
 #pragma unroll
                     for (int p = 0; p < 4; ++p) { f0[p] = f[p]; f1[p] = f[4 + p]; }
-                    fsave[saved_index16(cq, w.s)] = f0;
-                    fsave[saved_index16(cq + 1, w.s)] = f1;
+                    __builtin_nontemporal_store(f0, &fsave[saved_index16(cq, w.s)]);
+                    __builtin_nontemporal_store(f1, &fsave[saved_index16(cq + 1, w.s)]);
                 }
                 bf16x8 fh, fl;
                 split8(f, fh, fl);
@@ -233,8 +233,8 @@ __device__ __forceinline__ void step16(const ffn_mlp_chain& ch, const ffn_step& 
 #pragma unroll
                 for (int p = 0; p < 4; ++p) { y0[p] = y[p]; y1[p] = y[4 + p]; }
                 const int cq = 2 * (4 * o + 2 * half) + save_h;    // K group 4o + q, q = 2 half (+1)
-                save_out[saved_index16(cq, save_s)] = y0;
-                save_out[saved_index16(cq + 2, save_s)] = y1;
+                __builtin_nontemporal_store(y0, &save_out[saved_index16(cq, save_s)]);
+                __builtin_nontemporal_store(y1, &save_out[saved_index16(cq + 2, save_s)]);
             }
             if (fused_head && o < ot) {
 #pragma unroll

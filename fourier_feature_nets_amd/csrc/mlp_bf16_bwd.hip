@@ -87,8 +87,8 @@ __device__ __forceinline__ void step16_bwd(const ffn_mlp_chain& ch, const ffn_st
 #pragma unroll
                 for (int p = 0; p < 4; ++p) { y0[p] = y[p]; y1[p] = y[4 + p]; }
                 const int cq = 2 * (4 * o + 2 * half) + w.h;
-                save_out[saved_index16(cq, w.s)] = y0;
-                save_out[saved_index16(cq + 2, w.s)] = y1;
+                __builtin_nontemporal_store(y0, &save_out[saved_index16(cq, w.s)]);
+                __builtin_nontemporal_store(y1, &save_out[saved_index16(cq + 2, w.s)]);
             }
             split8(y, cur_hi[2 * o + half], cur_lo[2 * o + half]);
         }

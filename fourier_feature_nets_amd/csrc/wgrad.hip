@@ -74,7 +74,7 @@ __device__ __forceinline__ void unit_segment(const ffn_mlp_chain& ch, const ffn_
         gptr chunk = (j) < CA ? (gptr)(a_s + ((j) < ca_last ? (j) : ca_last) * 4096)           \
                               : (gptr)(b_s + ((j) - CA < cb_last ? (j) - CA : cb_last) * 4096);  \
         asm volatile("" : "+s"(chunk));    /* its own scalar base: no per-lane 64-bit adds */  \
-        R[j] = chunk[tid];                                                                     \
+        R[j] = __builtin_nontemporal_load(&chunk[tid]);                                                                     \
     } while (0)
 #define FFN_DEPOSIT(cur, j)                                                                    \
     *reinterpret_cast<f32x4*>(smem + ((j) < CA ? image_a(cur) + (j) * 4096                     \
