@@ -689,6 +689,66 @@ def render_leg(args, caster, sampler, world, rank, barrier):
         barrier()
         out[mode] = 8 * world / (time.perf_counter() - r0)
     caster.check_finite()
+    # rays that hit the volume, per rendered frame (the kernel skips the others after one byte)
+    per_cam = sampler.valid.view(sampler.num_cameras, -1).sum(1, dtype=torch.int64)
+    out["rays_per_frame"] = float(per_cam[[f % sampler.num_cameras for f in frames]].double().mean().item())
+    return out
+
+
+def render_roofline(prog, render, samples, world):
+    """The fused render launch against the f32-MFMA peak: algorithmic FLOP per frame = valid rays
+    x samples x forward FLOP per sample (no padding, no skipped rays), at the kernels-only rate
+    (per GPU: frames are dealt round-robin to the ranks)."""
+    fwd = 2 * sum(sp.out * sp.ld for sp in prog.layers)
+    flop_per_frame = render["rays_per_frame"] * samples * fwd
+    achieved = flop_per_frame * render["device"] / world / 1e12
+    return {"bound": "mfma", "kernel": "render_fused_kernel", "achieved": round(achieved, 2),
+            "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
+            "algorithmic_flop_per_launch": flop_per_frame, "flop_per_sample": fwd}
+
+
+def default_batch_leg(device, cams, images, bounds, rays=1024, samples=128, steps=60):
+    """The reference drivers' DEFAULT batch (train_nerf.py:21-27 / train_tiny_nerf.py: 1024 rays x
+    128 samples per step) through TrainEngine.train_step the way `fit` drives it (epoch-level
+    validity filter, no per-step host sync), for the tiny and the full NeRF, next to the same
+    step at a 32 768-ray batch: the small batch leaves each of the 1024 resident wavefronts
+    ~3.1 blocks of 32 samples, which the persistent kernels can only run as 4 rounds."""
+    import fourier_feature_nets_amd as ffn
+    out = {"workload": "%d rays x %d samples per step (the reference's defaults), 20 cameras 400x400" % (rays, samples)}
+    with contextlib.redirect_stdout(io.StringIO()):
+        ds = ffn.ImageDataset("train", images[:20], bounds, cams[:20], samples, True, True, anneal_start=0.2,
+                              num_anneal_steps=2000, device=device)
+    perm = torch.randperm(len(ds), device=device, generator=torch.Generator(device=device).manual_seed(3))
+    for name in ("tiny", "nerf"):
+        torch.manual_seed(20080524)
+        model = (ffn.PositionalFourierMLP(3, 4, 5.5) if name == "tiny"
+                 else ffn.NeRF(8, 256, 9, 10, 3, 4, [4], True)).to(device)
+        engine = ffn.TrainEngine(model, 0.0, None)
+
+        def run(first, count, batch):
+            ids, cuts = ds.epoch_ray_ids(perm[first * batch:(first + count) * batch], batch)
+            for i in range(count):
+                engine.train_step(ds, perm[(first + i) * batch:(first + i + 1) * batch], first + i, 5e-4,
+                                  rays=ids[cuts[i]:cuts[i + 1]])
+            return int(ids.numel())
+
+        timings = {}
+        for label, batch, count in (("default", rays, steps), ("large", 32768, 4)):
+            run(0, 3, batch)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            traced = run(3, count, batch)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            timings[label] = (dt / count, dt / traced, traced / count)
+        engine.check_finite()
+        out[name] = {"ms_per_step": round(1e3 * timings["default"][0], 4),
+                     "valid_rays_per_step": round(timings["default"][2], 1),
+                     "rays_per_s": round(1.0 / timings["default"][1], 1),
+                     "large_batch_ms_per_step": round(1e3 * timings["large"][0], 3),
+                     "large_batch_rays_per_s": round(1.0 / timings["large"][1], 1),
+                     "per_ray_rate_vs_large_batch": round(timings["large"][1] / timings["default"][1], 4)}
+        del engine, model
     return out
 
 
@@ -866,6 +926,8 @@ def main():
                 "path": "fused render kernel: one launch per frame (sampling + encoding + MLP + "
                         "compositing + u8 pixels)",
                 "kernels_only_fps": render["device"],
+                "rays_per_frame": render["rays_per_frame"],
+                "roofline": render_roofline(model.program(), render, args.samples, world),
                 "with_sync_d2h_fps": render["host"],
                 "with_async_d2h_and_png_fps": render["png"],
                 "includes": "value = with_sync_d2h_fps: every frame copied to the host before the "
@@ -893,6 +955,8 @@ def main():
                                   if solo and not args.no_config3 and args.size == 400 else None)
         result["config4_step"] = (config4_leg(device, bounds)
                                   if solo and not args.no_config3 and args.size == 400 else None)
+        result["default_batch_step"] = (default_batch_leg(device, cams, images, bounds)
+                                        if solo and not args.no_config3 and args.size == 400 else None)
         result["empty_space_skipping"] = (skip_leg(device, dataset, bounds, args.rays)
                                           if solo and not args.no_skip_leg else None)
         result["split_bf16_inference"] = (bf16_leg(device, bounds, cams, args.samples)

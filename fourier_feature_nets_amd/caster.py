@@ -196,7 +196,7 @@ class TrainEngine:
                       norm_out=self.grad_norm)
         self.model.invalidate_packed()
         # (a fresh tensor: the reduce buffer is overwritten by the next step)
-        loss = sums[0] / (3 * global_count) + aw * (sums[1] / global_count)
+        loss = ops.loss_value(sums, max(global_count, 0), aw)
         if self.loss_history is not None:
             self.loss_history.append(loss)
         return loss
@@ -261,7 +261,7 @@ class TrainEngine:
         color, alpha, _ = ops.composite_fwd(logits, t, False, self.nan_flag)
         sums, _, _ = ops.mse_loss(color, alpha, dataset.colors, alphas, rays, 1.0, 1.0,
                                   want_grad=False)
-        return sums[0] / (3 * count) + aw * (sums[1] / count)
+        return ops.loss_value(sums, count, aw)
 
     def check_finite(self):
         """Raises like the asserts at ray_caster.py:73-74 (checked lazily: one sync)."""

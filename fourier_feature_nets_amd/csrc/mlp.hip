@@ -62,6 +62,43 @@ pack_kernel(const float* __restrict__ src, int rows, int cols, int ld, int trans
     }
 }
 
+// Every operand pack, bias block and fused-head block of a model in ONE launch (blockIdx.y = job):
+// what MlpProgram.pack() used to issue as one pack launch + one device copy per layer and head
+// -- a dozen ~5 us launches in front of every optimisation step, 6 % of the step at the
+// reference's default batch of 1024 rays.
+__global__ void __launch_bounds__(256)
+pack_jobs_kernel(const ffn_pack_job* __restrict__ jobs) {
+    const ffn_pack_job job = jobs[blockIdx.y];
+    if (job.kind == 1) {          // strided copy: dst[c*dst_cs + r*dst_rs] = src[r*ld + c]
+        const int64_t total = (int64_t)job.rows * job.cols;
+        for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+             e += (int64_t)gridDim.x * blockDim.x) {
+            const int r = (int)(e / job.cols), c = (int)(e % job.cols);
+            job.dst[(int64_t)c * job.dst_cs + (int64_t)r * job.dst_rs] = job.src[(int64_t)r * job.ld + c];
+        }
+        return;
+    }
+    const int64_t total = (int64_t)job.groups * job.tiles * 256;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int p = (int)(e & 3);
+        const int lane = (int)((e >> 2) & 63);
+        const int64_t go = e >> 8;
+        const int o = (int)(go % job.tiles);
+        const int g = (int)(go / job.tiles);
+        const int r = 32 * o + (lane & 31);
+        int c = 8 * g + 4 * (lane >> 5) + p;
+        if (job.col_map != nullptr) c = job.col_map[c];
+        float v = 0.0f;
+        if (c >= 0) {
+            const int sr = job.transpose ? c : r;
+            const int sc = job.transpose ? r : c;
+            if (sr < job.rows && sc < job.cols) v = job.src[(int64_t)sr * job.ld + sc];
+        }
+        job.dst[e] = v;
+    }
+}
+
 // K groups [c0, c0+count) of an encoding into the wave's slab (and, when training, into the
 // saved-feature slab `fsave`).  Four independent groups per trip give the in-order wave the
 // instruction-level parallelism that hides the packed-FMA latency.
@@ -813,6 +850,13 @@ extern "C" int ffn_mlp_pack(const float* src, int rows, int cols, int ld, int tr
     hipLaunchKernelGGL(pack_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, src, rows,
                        cols, ld, transpose, row_map, col_map, groups, tiles, dst);
     return check_launch("ffn_mlp_pack");
+}
+
+extern "C" int ffn_mlp_pack_jobs(const ffn_pack_job* jobs, int num_jobs, void* stream) {
+    if (num_jobs == 0) return 0;
+    if (num_jobs < 0 || jobs == nullptr) return fail_arg("ffn_mlp_pack_jobs: no jobs");
+    hipLaunchKernelGGL(pack_jobs_kernel, dim3(64, num_jobs), dim3(256), 0, (hipStream_t)stream, jobs);
+    return check_launch("ffn_mlp_pack_jobs");
 }
 
 static int validate_chain(const ffn_mlp_chain* ch, bool backward) {

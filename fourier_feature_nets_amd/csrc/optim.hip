@@ -68,6 +68,17 @@ norm_adam_kernel(float* __restrict__ params, float* __restrict__ grads, float* _
     }
 }
 
+// loss = sum_colour / colour_count + alpha_weight * (sum_alpha / alpha_count): the four scalar ATen
+// launches of `sums[0] / (3 n) + w * (sums[1] / n)` as one (image_dataset.py:237-242)
+__global__ void loss_value_kernel(const float* __restrict__ sums, float colour_count,
+                                  float alpha_count, float alpha_weight, float* __restrict__ out) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const float colour = sums[0] / colour_count;
+        const float alpha = alpha_weight != 0.0f ? alpha_weight * (sums[1] / alpha_count) : 0.0f;
+        out[0] = colour + alpha;
+    }
+}
+
 }  // namespace ffn
 
 using namespace ffn;
@@ -85,4 +96,12 @@ extern "C" int ffn_clip_adam(float* params, float* grads, float* exp_avg, float*
                        grads, exp_avg, exp_avg_sq, n, blocks, scratch, max_norm, step_size,
                        inv_sqrt_bc2, beta1, beta2, eps, weight_decay, grad_norm_out);
     return check_launch("ffn_clip_adam");
+}
+
+extern "C" int ffn_loss_value(const float* sums, float colour_count, float alpha_count,
+                              float alpha_weight, float* loss_out, void* stream) {
+    if (sums == nullptr || loss_out == nullptr) return fail_arg("ffn_loss_value: null argument");
+    hipLaunchKernelGGL(loss_value_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums,
+                       colour_count, alpha_count, alpha_weight, loss_out);
+    return check_launch("ffn_loss_value");
 }

@@ -302,7 +302,10 @@ extern "C" int ffn_mlp_wgrad_units(const ffn_mlp_chain* chain, const ffn_wgrad_u
 extern "C" int ffn_mlp_wgrad_reduce(const ffn_reduce_job* jobs, int num_jobs,
                                     const float* partials, float* grads, void* stream) {
     if (num_jobs <= 0) return fail_arg("ffn_mlp_wgrad_reduce: no jobs");
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(17, num_jobs), dim3(256), 0, (hipStream_t)stream,
+    // one element per thread: with ~20 jobs that is ~1300 workgroups, enough loads in flight to
+    // pull the partials (64 MiB for 256 segments) at the HBM rate -- 17 blocks per job left the
+    // kernel latency-bound (65 us where the traffic is worth ~20)
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(66, num_jobs), dim3(256), 0, (hipStream_t)stream,
                        jobs, partials, grads);
     return check_launch("ffn_mlp_wgrad_reduce");
 }

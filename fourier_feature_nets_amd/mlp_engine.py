@@ -88,6 +88,14 @@ class FfnReduceJob(ctypes.Structure):
                 ("col_map", ctypes.c_void_p)]
 
 
+class FfnPackJob(ctypes.Structure):
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("col_map", ctypes.c_void_p),
+                ("kind", ctypes.c_int32), ("rows", ctypes.c_int32), ("cols", ctypes.c_int32),
+                ("ld", ctypes.c_int32), ("transpose", ctypes.c_int32), ("groups", ctypes.c_int32),
+                ("tiles", ctypes.c_int32), ("dst_rs", ctypes.c_int32), ("dst_cs", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
+
+
 class FfnRenderRays(ctypes.Structure):
     _fields_ = [("starts", ctypes.c_void_p), ("directions", ctypes.c_void_p),
                 ("near_far", ctypes.c_void_p), ("num_rays_total", ctypes.c_int64),
@@ -683,33 +691,53 @@ class MlpProgram:
               c_i64(n), _dev(logits))
         return logits
 
-    def pack(self):
-        """Re-derives the MFMA-operand copies from the current nn.Linear weights."""
-        self._packed16_dirty = True
+    def _pack_jobs(self):
+        """Device table of everything ``pack`` derives from the nn.Linear tensors: operand packs
+        for the forward and backward-data chains, bias blocks, fused-head blocks.  Built once
+        per program: the parameters' storage is fixed for its lifetime (``_FusedModel.program``
+        rebuilds the program when a parameter's data pointer changes)."""
+        jobs = []
+        f32 = 4
+
+        def copy(src, src_ld, rows, cols, dst, dst_rs, dst_cs):
+            jobs.append(FfnPackJob(src, dst, 0, 1, rows, cols, src_ld, 0, 0, 0, dst_rs, dst_cs, 0))
+
         for i, spec in enumerate(self.layers):
             if self.step_of[i] is None:
                 continue
             L = self.fwd.step[self.step_of[i]]
             groups, tiles = self.fwd_shapes[i]
             w = spec.weight.detach()
-            dst = self.packed_fwd[L.w_off:L.w_off + groups * tiles * 256]
-            _call("ffn_mlp_pack", _dev(w), c_i(w.shape[0]), c_i(w.shape[1]), c_i(w.stride(0)),
-                      c_i(0), c_p(0), _dev(self.col_maps[i], torch.int32), c_i(groups), c_i(tiles),
-                      _dev(dst))
-            self.bias_buf[L.b_off:L.b_off + spec.out].copy_(spec.bias.detach())
+            assert w.stride(1) == 1
+            jobs.append(FfnPackJob(w.data_ptr(), self.packed_fwd.data_ptr() + f32 * L.w_off,
+                                   self.col_maps[i].data_ptr(), 0, w.shape[0], w.shape[1],
+                                   w.stride(0), 0, groups, tiles, 0, 0, 0))
+            copy(spec.bias.detach().data_ptr(), spec.out, 1, spec.out,
+                 self.bias_buf.data_ptr() + f32 * L.b_off, 0, 1)
         for (i, off, channels) in self.fused_heads:
             spec = self.layers[i]
             col, cnt = spec.to_logits
-            self.bias_buf[off + col:off + col + cnt].copy_(spec.bias.detach())
-            self.bias_buf[off + 4:off + 4 + 4 * channels].view(channels, 4)[:, col:col + cnt].copy_(
-                spec.weight.detach().t())
+            w = spec.weight.detach()
+            copy(spec.bias.detach().data_ptr(), cnt, 1, cnt, self.bias_buf.data_ptr() + f32 * (off + col), 0, 1)
+            # head rows as [channel][column]: dst[c*4 + r] = W[r][c]
+            copy(w.data_ptr(), w.stride(0), cnt, channels,
+                 self.bias_buf.data_ptr() + f32 * (off + 4 + col), 1, 4)
         for (c, groups, tiles, off) in self.bwd_packs:
             w = self.layers[c].weight.detach()
-            dst = self.packed_bwd[off:off + groups * tiles * 256]
             # operand rows = input channels (act part), operand K = output rows of layer c
-            _call("ffn_mlp_pack", _dev(w), c_i(w.shape[0]), c_i(self.layers[c].act_in),
-                      c_i(w.stride(0)), c_i(1), c_p(0), c_p(0), c_i(groups), c_i(tiles),
-                      _dev(dst))
+            jobs.append(FfnPackJob(w.data_ptr(), self.packed_bwd.data_ptr() + f32 * off, 0, 0,
+                                   w.shape[0], self.layers[c].act_in, w.stride(0), 1, groups,
+                                   tiles, 0, 0, 0))
+        self._pack_job_count = len(jobs)
+        self._pack_jobs_dev = _struct_array_to_device(jobs, self.device)
+
+    def pack(self):
+        """Re-derives the MFMA-operand copies (and the bias / fused-head blocks) from the current
+        nn.Linear weights: one launch over the job table."""
+        self._packed16_dirty = True
+        if getattr(self, "_pack_jobs_dev", None) is None:
+            self._pack_jobs()
+        _call("ffn_mlp_pack_jobs", _dev(self._pack_jobs_dev, torch.uint8), c_i(self._pack_job_count))
 
     # ------------------------------------------------------------------ launches
     @staticmethod

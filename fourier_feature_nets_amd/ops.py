@@ -215,6 +215,13 @@ def mse_loss(color, alpha, gt_colors, gt_alphas, ray_index, color_scale, alpha_s
     return sums, d_color, d_alpha
 
 
+def loss_value(sums: torch.Tensor, rays: int, alpha_weight: float) -> torch.Tensor:
+    """sums[0] / (3 rays) + alpha_weight * sums[1] / rays as a fresh device scalar (one launch)."""
+    out = torch.empty((), dtype=torch.float32, device=sums.device)
+    _call("ffn_loss_value", _dev(sums), c_f(3.0 * rays), c_f(float(rays)), c_f(alpha_weight), _dev(out))
+    return out
+
+
 # --------------------------------------------------------------------------------- optimiser
 def clip_adam(params, grads, exp_avg, exp_avg_sq, step: int, lr: float, weight_decay=0.0,
               clip_value=0.1, max_norm=0.1, beta1=0.9, beta2=0.999, eps=1e-8,

@@ -172,6 +172,13 @@ int ffn_clip_adam(float* params, float* grads, float* exp_avg, float* exp_avg_sq
                   float inv_sqrt_bc2, float beta1, float beta2, float eps,
                   float weight_decay, float* scratch, float* grad_norm_out, void* stream);
 
+/* The scalar loss from K6's two sums (possibly all-reduced over the ranks in between):
+ *   loss = sums[0] / colour_count + alpha_weight * (sums[1] / alpha_count)
+ * (image_dataset.py:237-242: colour_count = 3 * rays, alpha_count = rays); one launch instead
+ * of four scalar tensor ops per optimisation step. */
+int ffn_loss_value(const float* sums, float colour_count, float alpha_count, float alpha_weight,
+                   float* loss_out, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * K8  image assembly (ray_sampler.py:191-196): zeros, scatter, (x*255) truncated to u8.
  *   colors (n,3); pixel_index (n) int64 pixel id inside the frame; image (H*W*3) u8
@@ -282,6 +289,19 @@ typedef struct ffn_mlp_chain {
 int ffn_mlp_pack(const float* src, int rows, int cols, int ld, int transpose,
                  const int32_t* row_map, const int32_t* col_map, int groups, int tiles,
                  float* dst, void* stream);
+
+/* The same gather for a whole model in one launch: a device array of jobs, one per operand
+ * pack (kind 0: ffn_mlp_pack's formula with row_map = identity) or per bias / fused-head block
+ * (kind 1: the strided copy dst[c*dst_cs + r*dst_rs] = src[r*ld + c], r < rows, c < cols).
+ * The optimiser step rewrites the weights in place, so a training loop re-packs after every
+ * step; this keeps that at one launch. */
+typedef struct {
+    const float* src;
+    float* dst;
+    const int32_t* col_map;   /* kind 0: internal K index -> natural column, or NULL */
+    int32_t kind, rows, cols, ld, transpose, groups, tiles, dst_rs, dst_cs, reserved;
+} ffn_pack_job;
+int ffn_mlp_pack_jobs(const ffn_pack_job* jobs, int num_jobs, void* stream);
 
 /* Forward chain.  positions (N,3), views (N,3) or NULL, logits out (N,4).  Training: when
  * `saved` and `masks` are non-NULL, every step writes what the backward pass needs into

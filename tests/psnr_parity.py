@@ -153,9 +153,16 @@ def run_oracle(args):
     rows = []
     t0 = time.time()
     loss = None
+    if args.ckpt_dir:
+        os.makedirs(args.ckpt_dir, exist_ok=True)
     for step in range(args.steps + 1):
         if step % args.every == 0 or step == args.steps:
             rows.append({"step": step, "val_psnr": validate(), "train_loss": loss})
+            if args.ckpt_dir:       # weights + Adam moments: the state a re-synchronised run starts from
+                flat = lambda ts: torch.cat([t.detach().reshape(-1) for t in ts])      # noqa: E731
+                torch.save({"step": step, "count": trainer.count, "params": flat(ref.parameters()),
+                            "m": flat(trainer.m), "v": flat(trainer.v)},
+                           os.path.join(args.ckpt_dir, "step_%06d.pt" % step))
             print(rows[-1], "%.0f s" % (time.time() - t0), flush=True)
             with open(args.out, "w") as f:
                 json.dump({"half": "oracle", "args": vars(args), "rows": rows, "complete": False}, f, indent=1)
@@ -176,6 +183,15 @@ def run_oracle(args):
            "weights_abs_sum": checksum, "seconds": time.time() - t0,
            "threads": torch.get_num_threads(), "torch": torch.__version__, "numpy": np.__version__,
            "valid_val_rays": int(len(vids))}
+    if args.oracle:             # control: drift between two oracle runs
+        with open(args.oracle) as f:
+            other = json.load(f)
+        theirs = {r["step"]: r["val_psnr"] for r in other["rows"] if "val_psnr" in r}
+        diffs = [{"step": r["step"], "this": r["val_psnr"], "other": theirs[r["step"]],
+                  "delta_db": r["val_psnr"] - theirs[r["step"]]}
+                 for r in rows if "val_psnr" in r and r["step"] in theirs]
+        doc["control_against"] = {"file": args.oracle, "threads": other.get("threads"), "comparison": diffs,
+                                  "max_abs_delta_db": max(abs(d["delta_db"]) for d in diffs)}
     with open(args.out, "w") as f:
         json.dump(doc, f, indent=1)
     return doc
@@ -223,6 +239,46 @@ def run_hip(args):
         model.train()
         return float(-10.0 * np.log10(total / n))
 
+    def load_state(path):
+        blob = torch.load(path)
+        engine.flat.copy_(blob["params"].to(device))
+        engine.exp_avg.copy_(blob["m"].to(device))
+        engine.exp_avg_sq.copy_(blob["v"].to(device))
+        engine.count = int(blob["count"])
+        model.invalidate_packed()
+        return int(blob["step"])
+
+    def train_range(first, last):
+        for step in range(first, last):
+            ids = torch.from_numpy(step_rays(step, train.sampler.num_rays, args.rays)).to(device)
+            torch.manual_seed(args.noise_seed + step)
+            engine.train_step(train, ids, None, lr_at(step))
+
+    resync = None
+    if args.ckpt_dir and ref is not None:
+        # (1) the SAME model rendered by both paths: the oracle's weights at every checkpoint,
+        # validation PSNR of the HIP path against the oracle's own number
+        # (2) re-synchronised segments: from the oracle's weights + Adam moments at checkpoint k the
+        # HIP path trains to checkpoint k+1 on the same batches and noise
+        theirs = {r["step"]: r["val_psnr"] for r in ref["rows"] if "val_psnr" in r}
+        steps_sorted = sorted(theirs)
+        same_weights, segments = [], []
+        for a, b in zip(steps_sorted, steps_sorted[1:] + [None]):
+            path = os.path.join(args.ckpt_dir, "step_%06d.pt" % a)
+            if not os.path.exists(path):
+                continue
+            assert load_state(path) == a
+            mine = validate()
+            same_weights.append({"step": a, "hip": mine, "oracle": theirs[a], "delta_db": mine - theirs[a]})
+            if b is not None:
+                train_range(a, b)
+                mine = validate()
+                segments.append({"from": a, "to": b, "hip": mine, "oracle": theirs[b], "delta_db": mine - theirs[b]})
+        resync = {"same_weights": same_weights, "segments": segments,
+                  "same_weights_max_abs_delta_db": max(abs(r["delta_db"]) for r in same_weights),
+                  "segments_max_abs_delta_db": max(abs(r["delta_db"]) for r in segments)}
+        load_state(os.path.join(args.ckpt_dir, "step_%06d.pt" % steps_sorted[0]))
+
     rows, mismatched = [], 0
     expect = {r["step"]: r for r in (ref["rows"] if ref else []) if "batch" in r}
     torch.cuda.synchronize()
@@ -264,7 +320,11 @@ def run_hip(args):
         doc["batches_mismatched"] = mismatched
         doc["oracle_valid_val_rays"] = ref.get("valid_val_rays")
         doc["bound_db"] = 0.05
-        doc["within_bound"] = bool(doc["max_abs_delta_db"] < 0.05)
+        doc["free_running_within_bound"] = bool(doc["max_abs_delta_db"] < 0.05)
+        if resync is not None:
+            doc["resynchronised"] = resync
+            doc["within_bound"] = bool(resync["same_weights_max_abs_delta_db"] < 0.05 and
+                                       resync["segments_max_abs_delta_db"] < 0.05)
     if args.out:
         os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
         with open(args.out, "w") as f:
@@ -286,7 +346,12 @@ def main(argv=None):
     ap.add_argument("--noise-seed", type=int, default=1000)
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3"])
-    ap.add_argument("--oracle", help="(hip) trajectory written by the oracle half")
+    ap.add_argument("--oracle", help="(hip) trajectory written by the oracle half (or, for the oracle half: a "
+                                     "previous oracle trajectory to report the divergence from -- the control "
+                                     "for how far two runs of the SAME arithmetic drift apart when only the "
+                                     "summation order changes, e.g. --threads 4 against --threads 8)")
+    ap.add_argument("--ckpt-dir", help="oracle: write weights + Adam moments at every checkpoint; hip: "
+                                       "replay re-synchronised segments from them")
     ap.add_argument("--out", required=True)
     args = ap.parse_args(argv)
     if args.half == "oracle":

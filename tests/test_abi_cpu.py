@@ -43,6 +43,8 @@ def test_plan_struct_sizes_match_header():
              offsetof(ffn_mlp_chain, slot_offset), offsetof(ffn_step, w_off),
              offsetof(ffn_step, save_enc_slot), sizeof(ffn_wgrad_unit), sizeof(ffn_wgrad_segment),
              sizeof(ffn_reduce_job));
+      printf("%zu %zu %zu\n", sizeof(ffn_pack_job), offsetof(ffn_pack_job, kind),
+             offsetof(ffn_pack_job, dst_cs));
       return 0; }'''
     with tempfile.TemporaryDirectory() as tmp:
         c_path = os.path.join(tmp, "probe.c")
@@ -61,7 +63,8 @@ def test_plan_struct_sizes_match_header():
            me.FfnMlpChain.step.offset, me.FfnMlpChain.num_steps.offset,
            me.FfnMlpChain.bias_floats.offset, me.FfnMlpChain.slot_offset.offset,
            me.FfnStep.w_off.offset, me.FfnStep.save_enc_slot.offset, ctypes.sizeof(me.FfnWgradUnit),
-           ctypes.sizeof(me.FfnWgradSegment), ctypes.sizeof(me.FfnReduceJob)]
+           ctypes.sizeof(me.FfnWgradSegment), ctypes.sizeof(me.FfnReduceJob),
+           ctypes.sizeof(me.FfnPackJob), me.FfnPackJob.kind.offset, me.FfnPackJob.dst_cs.offset]
     assert [int(v) for v in out] == got, (out, got)
 
 
