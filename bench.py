@@ -229,10 +229,19 @@ class KernelTimer:
 
 
 def git_head():
+    """Short commit id of this tree: from git, or -- on a GPU box, where .git does not travel --
+    from the `.git_head` file scripts/gpu/stamp.sh writes before a gpurun call."""
     try:
-        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True,
-                              text=True, timeout=10).stdout.strip() or None
+        head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True,
+                              text=True, timeout=10).stdout.strip()
+        if head:
+            return head
     except Exception:
+        pass
+    try:
+        with open(os.path.join(ROOT, ".git_head")) as f:
+            return f.read().strip() or None
+    except OSError:
         return None
 
 

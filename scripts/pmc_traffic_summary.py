@@ -30,7 +30,7 @@ def per_kernel(path, counter):
     return acc
 
 
-def main(src, out, commit=None, rays=65536, samples=64):
+def main(src, out, commit=None, rays=65536, samples=64, command=None):
     fetch = per_kernel(src + "/fetch_counter_collection.csv", "FETCH_SIZE")
     write = per_kernel(src + "/write_counter_collection.csv", "WRITE_SIZE")
     kernels = collections.OrderedDict()
@@ -41,16 +41,21 @@ def main(src, out, commit=None, rays=65536, samples=64):
         kernels[name] = {"launches": n, "FETCH_SIZE_KB": round(f_kb, 1),
                          "WRITE_SIZE_KB": round(w_kb, 1),
                          "hbm_bytes": int((2 * f_kb + w_kb) * 1024)}
+    command = command or ("python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-target-shape "
+                          "--no-config3 --no-config5 --no-skip-leg --no-bf16-leg")
     doc = {"note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on "
-                   "`python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-target-shape --no-config3 --no-config5 --no-skip-leg --no-bf16-leg` (scripts/gpu/profile_round2.sh: train steps + the fused-render leg), MI355X; "
+                   "`" + command + "` (scripts/gpu/profile_round3.sh), MI355X; "
                    "KB per launch averaged over launches; hbm_bytes = (2*FETCH_SIZE + "
                    "WRITE_SIZE)*1024 (gfx950: FETCH_SIZE counts 128-B requests as 64 B for wide "
                    "streaming reads, MI355X_MICROARCH.md section HBM)",
            "commit": commit, "config": {"rays": rays, "samples": samples}, "kernels": kernels}
+    step = [k for k in kernels if "mlp_forward" in k or "mlp_backward" in k or "wgrad_unit" in k]
+    doc["training_step_mlp_kernels_hbm_bytes"] = sum(kernels[k]["hbm_bytes"] for k in step)
     with open(out, "w") as f:
         json.dump(doc, f, indent=1)
     print("wrote", out, len(kernels), "kernels")
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else None)
+    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else None,
+         command=sys.argv[4] if len(sys.argv) > 4 else None)
