@@ -35,7 +35,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-TRAFFIC_PROFILE = "profiles/r02_hbm_traffic.json"
+TRAFFIC_PROFILE = "profiles/r03_hbm_traffic.json"
 
 KERNEL_OF = {"ffn_mlp_forward": "mlp_forward_kernel<train>",
              "ffn_mlp_backward_data": "mlp_backward_data_kernel",
@@ -359,13 +359,16 @@ def config3_leg(device, cams, images, bounds, rays_per_step=65536, steps=3):
         elapsed = time.perf_counter() - t0
         timer.on = False
         engine.check_finite()
-        fine_kernels = timer.summary(prog, rays_per_step * 128)
+        # TrainEngine bounds its activation workspace: a 65 536 x 128 batch runs as
+        # `launches_per_step` forward / backward launches (2 at the default of 2^22 samples)
+        launches_per_step = max(1, len(next(iter(timer.spans.values()))) // steps)
+        fine_kernels = timer.summary(prog, rays_per_step * 128 // launches_per_step)
     finally:
         timer.close()
         del sampler.sample_t
-    coarse_ms = sum(a.elapsed_time(b) for a, b in coarse_events) / max(len(coarse_events), 1)
+    coarse_ms = sum(a.elapsed_time(b) for a, b in coarse_events) / steps
     step_ms = 1e3 * elapsed / steps
-    mlp_ms = sum(k["avg_ms"] for k in fine_kernels.values())
+    mlp_ms = sum(k["avg_ms"] for k in fine_kernels.values()) * launches_per_step
     flop = sum(k["flop_per_sample"] for k in fine_kernels.values()) * rays_per_step * 128
     side = cams[0].resolution.width
     out = {"workload": "lego_%d-shaped full NeRF train step: NeRF(8,256,9,10,3,4,[4],True), "
@@ -375,6 +378,9 @@ def config3_leg(device, cams, images, bounds, rays_per_step=65536, steps=3):
            "step_ms": round(step_ms, 2), "rays_per_s": round(rays_per_step / (step_ms * 1e-3), 1),
            "steps": steps, "final_loss": float(loss), "sampler_startup_s": round(startup_s, 3),
            "cdf_table_bytes": 0, "sampling_incl_coarse_pass_ms": round(coarse_ms, 3),
+           "launches_per_step": launches_per_step,
+           "activation_workspace_gb": round(4e-9 * (prog.saved_floats(rays_per_step * 128 // launches_per_step)
+                                                    + prog.dz_channels * rays_per_step * 128 // launches_per_step), 1),
            "fine_mlp_ms": round(mlp_ms, 3), "kernels": fine_kernels,
            "fine_mlp_frac_of_f32_mfma_peak": round(flop / (mlp_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
            "whole_step_frac_of_f32_mfma_peak": round(flop / (step_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)}
@@ -878,6 +884,9 @@ def main():
     timer.on = False
     timer.close()
     engine.check_finite()
+    # (a batch above TrainEngine's launch bound -- 2^22 samples -- runs as several launches)
+    launches_per_step = max(1, len(next(iter(timer.spans.values()))) // max(args.steps, 1)) if timer.spans else 1
+    n_samples //= launches_per_step
     kernels = timer.summary(prog, n_samples)
 
     # ---- render leg: 400x400 frames of the first cameras (replicas only: frame f -> rank f%world)
