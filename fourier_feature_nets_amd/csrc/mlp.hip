@@ -175,8 +175,10 @@ struct WaveCtx {
     const float* enc_table;  // LDS copies of the encoding tables
     const float* bias_lds;   // LDS copy of every step's (padded) bias
     uint4* masks;            // ReLU sign masks: [slot][block][half][lane] x 128 bit
-    int64_t block;           // global 32-sample block id
+    int64_t block;           // 32-sample block id inside this launch
     int64_t num_blocks;
+    int64_t slab_block0;     // slabs are indexed by block id of the WHOLE batch: this launch's first
+    int64_t slab_blocks;     // block and the batch's block count (a launch may cover a sub-range)
     float logit[4];
     int half;                // wide mode: which half of a step's output tiles this wave owns
     bool active;             // wide mode: false = lockstep dummy pass (block clamped, no stores)
@@ -187,8 +189,8 @@ __device__ __forceinline__ int saved_index(int cq, int s) { return cq * 32 + (s 
 
 __device__ __forceinline__ f32x4* slab_block(const ffn_mlp_chain& ch, float* base, int slot,
                                              const WaveCtx& w) {
-    return reinterpret_cast<f32x4*>(base + ch.slot_offset[slot] * w.num_blocks * 32) +
-           w.block * (int64_t)(ch.slot_channels[slot] * 8);
+    return reinterpret_cast<f32x4*>(base + ch.slot_offset[slot] * w.slab_blocks * 32) +
+           (w.slab_block0 + w.block) * (int64_t)(ch.slot_channels[slot] * 8);
 }
 
 // Wide mode (a layer wider than 256 channels): two waves share one 64 KiB slab and one block
@@ -520,6 +522,8 @@ __device__ __forceinline__ void wave_setup(WaveCtx& w, char* smem, int64_t n, in
     w.bias_lds = reinterpret_cast<const float*>(smem + kWavesPerBlock * kActBytesPerWave + kEncTableBytes);
     w.num_blocks = (n + kSamplesPerWave - 1) / kSamplesPerWave;
     w.block = (int64_t)blockIdx.x * teams + team;
+    w.slab_block0 = 0;
+    w.slab_blocks = w.num_blocks;
     w.active = true;
 }
 
@@ -528,7 +532,8 @@ __global__ void __launch_bounds__(256, 1)
 mlp_forward_kernel(const ffn_mlp_chain ch, const float* __restrict__ packed_w,
                    const float* __restrict__ bias, const float* __restrict__ positions,
                    const float* __restrict__ views, int64_t n, float* __restrict__ logits,
-                   float* __restrict__ saved, uint32_t* __restrict__ masks) {
+                   float* __restrict__ saved, uint32_t* __restrict__ masks, int64_t slab_block0,
+                   int64_t slab_blocks) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     stage_encoding_tables(ch.enc, reinterpret_cast<float*>(smem + kWavesPerBlock * kActBytesPerWave),
                           threadIdx.x, 256);
@@ -540,6 +545,7 @@ mlp_forward_kernel(const ffn_mlp_chain ch, const float* __restrict__ packed_w,
     WaveCtx w;
     int64_t stride;
     wave_setup<WIDE>(w, smem, n, stride);
+    if (slab_blocks > 0) { w.slab_block0 = slab_block0; w.slab_blocks = slab_blocks; }
     w.masks = reinterpret_cast<uint4*>(masks);
     f32x4* scratch = reinterpret_cast<f32x4*>(smem + kWavesPerBlock * kActBytesPerWave + kEncTableBytes +
                                               kBiasLdsFloats * 4) + (threadIdx.x >> 7) * 64;
@@ -804,11 +810,13 @@ template <bool WIDE>
 __global__ void __launch_bounds__(256, 1)
 mlp_backward_data_kernel(const ffn_mlp_chain ch, const float* __restrict__ packed_wt,
                          const float* __restrict__ d_logits, int64_t n,
-                         uint32_t* __restrict__ masks, float* __restrict__ dz) {
+                         uint32_t* __restrict__ masks, float* __restrict__ dz, int64_t slab_block0,
+                         int64_t slab_blocks) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     WaveCtx w;
     int64_t stride;
     wave_setup<WIDE>(w, smem, n, stride);
+    if (slab_blocks > 0) { w.slab_block0 = slab_block0; w.slab_blocks = slab_blocks; }
     w.masks = reinterpret_cast<uint4*>(masks);
     w.x0 = w.x1 = w.x2 = w.v0 = w.v1 = w.v2 = 0.0f;
     const int64_t passes = WIDE ? (w.num_blocks + stride - 1) / stride : 0;
@@ -907,29 +915,32 @@ static void allow_big_lds(K kernel) {
 template <int MODE, bool WIDE>
 static void launch_forward(const ffn_mlp_chain* chain, const float* packed_w, const float* bias,
                            const float* positions, const float* views, int64_t n, float* logits,
-                           float* saved, uint32_t* masks, void* stream) {
+                           float* saved, uint32_t* masks, int64_t slab_block0, int64_t slab_blocks,
+                           void* stream) {
     const int64_t blocks32 = (n + kSamplesPerWave - 1) / kSamplesPerWave;
     const int64_t grid = persistent_grid(blocks32, WIDE ? 2 : kWavesPerBlock);
     allow_big_lds(&mlp_forward_kernel<MODE, WIDE>);
     hipLaunchKernelGGL((mlp_forward_kernel<MODE, WIDE>), dim3((unsigned)grid), dim3(256), kLdsBytes,
                        (hipStream_t)stream, *chain, packed_w, bias, positions, views, n, logits, saved,
-                       masks);
+                       masks, slab_block0, slab_blocks);
 }
 
 extern "C" int ffn_mlp_forward(const ffn_mlp_chain* chain, const float* packed_w,
                                const float* bias, const float* positions, const float* views,
                                int64_t n, float* logits, float* saved, uint32_t* masks,
-                               void* stream) {
+                               int64_t slab_block0, int64_t slab_blocks, void* stream) {
     if (n == 0) return 0;
     if (n < 0 || validate_chain(chain, false)) return fail_arg("ffn_mlp_forward: bad chain or size");
     if ((saved == nullptr) != (masks == nullptr)) return fail_arg("ffn_mlp_forward: saved and masks go together");
+    if (slab_blocks != 0 && (slab_block0 < 0 || slab_block0 + (n + 31) / 32 > slab_blocks))
+        return fail_arg("ffn_mlp_forward: the launch's blocks must lie inside [0, slab_blocks)");
     const bool train = saved != nullptr;
     if (chain->wide) {
-        if (train) launch_forward<kTrainFwd, true>(chain, packed_w, bias, positions, views, n, logits, saved, masks, stream);
-        else launch_forward<kInfer, true>(chain, packed_w, bias, positions, views, n, logits, saved, masks, stream);
+        if (train) launch_forward<kTrainFwd, true>(chain, packed_w, bias, positions, views, n, logits, saved, masks, slab_block0, slab_blocks, stream);
+        else launch_forward<kInfer, true>(chain, packed_w, bias, positions, views, n, logits, saved, masks, slab_block0, slab_blocks, stream);
     } else {
-        if (train) launch_forward<kTrainFwd, false>(chain, packed_w, bias, positions, views, n, logits, saved, masks, stream);
-        else launch_forward<kInfer, false>(chain, packed_w, bias, positions, views, n, logits, saved, masks, stream);
+        if (train) launch_forward<kTrainFwd, false>(chain, packed_w, bias, positions, views, n, logits, saved, masks, slab_block0, slab_blocks, stream);
+        else launch_forward<kInfer, false>(chain, packed_w, bias, positions, views, n, logits, saved, masks, slab_block0, slab_blocks, stream);
     }
     return check_launch("ffn_mlp_forward");
 }
@@ -995,20 +1006,24 @@ extern "C" int ffn_focus_fused(const ffn_mlp_chain* chain, const float* packed_w
 
 template <bool WIDE>
 static void launch_backward(const ffn_mlp_chain* chain, const float* packed_wt, const float* d_logits,
-                            int64_t n, uint32_t* masks, float* dz, void* stream) {
+                            int64_t n, uint32_t* masks, float* dz, int64_t slab_block0,
+                            int64_t slab_blocks, void* stream) {
     const int64_t blocks32 = (n + kSamplesPerWave - 1) / kSamplesPerWave;
     const int64_t grid = persistent_grid(blocks32, WIDE ? 2 : kWavesPerBlock);
     allow_big_lds(&mlp_backward_data_kernel<WIDE>);
     hipLaunchKernelGGL((mlp_backward_data_kernel<WIDE>), dim3((unsigned)grid), dim3(256), kLdsBytes,
-                       (hipStream_t)stream, *chain, packed_wt, d_logits, n, masks, dz);
+                       (hipStream_t)stream, *chain, packed_wt, d_logits, n, masks, dz, slab_block0, slab_blocks);
 }
 
 extern "C" int ffn_mlp_backward_data(const ffn_mlp_chain* chain, const float* packed_wt,
                                      const float* d_logits, int64_t n, uint32_t* masks,
-                                     float* dz, void* stream) {
+                                     float* dz, int64_t slab_block0, int64_t slab_blocks,
+                                     void* stream) {
     if (n == 0) return 0;
     if (n < 0 || validate_chain(chain, true)) return fail_arg("ffn_mlp_backward_data: bad chain or size");
-    if (chain->wide) launch_backward<true>(chain, packed_wt, d_logits, n, masks, dz, stream);
-    else launch_backward<false>(chain, packed_wt, d_logits, n, masks, dz, stream);
+    if (slab_blocks != 0 && (slab_block0 < 0 || slab_block0 + (n + 31) / 32 > slab_blocks))
+        return fail_arg("ffn_mlp_backward_data: the launch's blocks must lie inside [0, slab_blocks)");
+    if (chain->wide) launch_backward<true>(chain, packed_wt, d_logits, n, masks, dz, slab_block0, slab_blocks, stream);
+    else launch_backward<false>(chain, packed_wt, d_logits, n, masks, dz, slab_block0, slab_blocks, stream);
     return check_launch("ffn_mlp_backward_data");
 }

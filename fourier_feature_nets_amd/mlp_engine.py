@@ -42,6 +42,17 @@ if os.environ.get("FFN_UNIT_COST"):       # "full,half,quarter,head" -- calibrat
     UNIT_COST, HEAD_COST = {4: _c[0], 2: _c[1], 1: _c[2]}, _c[3]
 
 
+# A training launch whose block count leaves the persistent grid a short last round (every one of
+# the 4 x CUs resident wavefronts owns whole 32-sample blocks, so 3.1 blocks per wavefront cost 4
+# rounds) is split: the full rounds on the one-wave-per-block kernels, the remainder on the
+# two-waves-per-block ("wide") kernels, whose round takes ~0.57 of the time.  At the reference's
+# default batch (1024 rays x 128 samples, ~3170 blocks) that is 3.57 instead of 4 rounds for the
+# forward and backward-data kernels.  Training launches only (inference keeps its bit-exact
+# batch independence: the two kernels sum a fused head's partial products in different orders).
+TAIL_PAIRS = os.environ.get("FFN_TAIL_PAIRS", "1") == "1"
+TAIL_MAX_FULL_ROUNDS = 16       # beyond that the tail is < 3 % of the launch
+
+
 class FfnEncoding(ctypes.Structure):
     _fields_ = [("b", ctypes.c_void_p), ("a", ctypes.c_void_p), ("num_freq", ctypes.c_int32),
                 ("include_input", ctypes.c_int32), ("scale", ctypes.c_float),
@@ -246,6 +257,7 @@ class MlpProgram:
         self._build_wgrad_jobs()
         self._build_forward16()
         self._build_backward16()
+        self._build_pair_chains()
 
     def _dz_buffer(self, floats: int) -> torch.Tensor:
         """The shared dZ workspace, grown (old buffer released first) when a larger batch shows up."""
@@ -399,6 +411,22 @@ class MlpProgram:
         self.num_grad_floats = g_off
         self.packed_fwd = torch.zeros((max(w_off, 1),), dtype=torch.float32, device=self.device)
         self.bias_buf = torch.zeros((b_off,), dtype=torch.float32, device=self.device)
+
+    def _build_pair_chains(self):
+        """Copies of the forward / backward-data chains flagged for the two-waves-per-block
+        kernels (same operand packs, same slabs), for chains those kernels accept: every logits
+        head fused, every step 64..256 channels wide."""
+        ok = not self.wide
+        for chain in (self.fwd, self.bwd):
+            for k in range(chain.num_steps):
+                st = chain.step[k]
+                ok = ok and st.out_tiles in (2, 4, 8) and st.dst == 0
+        self.pair_chain_ok = bool(ok and self.bwd.num_steps > 0)
+        self.fwd_pair = self.bwd_pair = None
+        if self.pair_chain_ok:
+            self.fwd_pair = FfnMlpChain.from_buffer_copy(bytes(self.fwd))
+            self.bwd_pair = FfnMlpChain.from_buffer_copy(bytes(self.bwd))
+            self.fwd_pair.wide = self.bwd_pair.wide = 1
 
     def _build_forward16(self):
         """Chain + operand buffer of the OPT-IN split-bf16 inference kernel (mlp_bf16.hip): the
@@ -763,14 +791,44 @@ class MlpProgram:
 
     def saved_floats(self, n: int) -> int:
         """Size (in floats) of the per-call training buffer: activation slabs followed by
-        the ReLU sign masks (256 words per 32-sample block and slab)."""
+        the ReLU sign masks (256 words per 32-sample block and slab) and, for chains that can
+        run a launch's tail on the two-waves-per-block kernels, that tail's masks (512 words per
+        block and slab, at most half a round of blocks)."""
         blocks = (n + 31) // 32
-        return self.saved_channels * 32 * blocks + self.fwd.num_slots * self.mask_words * blocks
+        return (self.saved_channels * 32 * blocks + self.fwd.num_slots * self.mask_words * blocks
+                + self._tail_mask_floats())
 
     def _split_saved(self, saved: torch.Tensor, n: int):
         blocks = (n + 31) // 32
         acts = self.saved_channels * 32 * blocks
         return saved[:acts], saved[acts:acts + self.fwd.num_slots * self.mask_words * blocks]
+
+    # ------------------------------------------------------------------ tail on wave pairs
+    def _resident_waves(self) -> int:
+        if getattr(self, "_waves", None) is None:
+            self._waves = 4 * torch.cuda.get_device_properties(self.device).multi_processor_count
+        return self._waves
+
+    def _tail_mask_floats(self) -> int:
+        if not (TAIL_PAIRS and self.pair_chain_ok) or self.device.type != "cuda":
+            return 0
+        return self.fwd.num_slots * 512 * (self._resident_waves() // 2)
+
+    def _tail_split(self, n: int) -> Optional[int]:
+        """Blocks the one-wave-per-block launch keeps when the rest goes to the wave-pair
+        kernels, or None: at least one full round, a remainder of at most half a round."""
+        if not (TAIL_PAIRS and self.pair_chain_ok):
+            return None
+        blocks = (n + 31) // 32
+        full, rest = divmod(blocks, self._resident_waves())
+        if full < 1 or full > TAIL_MAX_FULL_ROUNDS or rest == 0 or 2 * rest > self._resident_waves():
+            return None
+        return full * self._resident_waves()
+
+    def _tail_masks(self, saved: torch.Tensor, n: int) -> torch.Tensor:
+        blocks = (n + 31) // 32
+        start = self.saved_channels * 32 * blocks + self.fwd.num_slots * self.mask_words * blocks
+        return saved[start:start + self._tail_mask_floats()]
 
     def forward(self, positions: torch.Tensor, views: Optional[torch.Tensor],
                 saved: Optional[torch.Tensor] = None, precision: str = "f32") -> torch.Tensor:
@@ -795,9 +853,25 @@ class MlpProgram:
             return logits
         if precision != "f32":
             raise ValueError("precision is 'f32' or 'bf16x3'")
-        _call("ffn_mlp_forward", ctypes.byref(self.fwd), _dev(self.packed_fwd),
+        head = None if saved is None else self._tail_split(n)
+        if head is None:
+            _call("ffn_mlp_forward", ctypes.byref(self.fwd), _dev(self.packed_fwd),
                   _dev(self.bias_buf), _dev(positions, name="positions"),
-                  _dev(views, name="views"), c_i64(n), _dev(logits), _dev(acts), _dev(masks))
+                  _dev(views, name="views"), c_i64(n), _dev(logits), _dev(acts), _dev(masks),
+                  c_i64(0), c_i64(0))
+            return logits
+        # full rounds on the one-wave-per-block kernel, the short last round on wave pairs; both
+        # write the batch's slabs (block ids of the whole batch), each its own mask region
+        blocks, cut = (n + 31) // 32, head * 32
+        v_head = None if views is None else views[:cut]
+        v_tail = None if views is None else views[cut:]
+        _call("ffn_mlp_forward", ctypes.byref(self.fwd), _dev(self.packed_fwd), _dev(self.bias_buf),
+              _dev(positions[:cut], name="positions"), _dev(v_head, name="views"), c_i64(cut),
+              _dev(logits[:cut]), _dev(acts), _dev(masks), c_i64(0), c_i64(blocks))
+        _call("ffn_mlp_forward", ctypes.byref(self.fwd_pair), _dev(self.packed_fwd), _dev(self.bias_buf),
+              _dev(positions[cut:], name="positions"), _dev(v_tail, name="views"), c_i64(n - cut),
+              _dev(logits[cut:]), _dev(acts), _dev(self._tail_masks(saved, n)), c_i64(head),
+              c_i64(blocks))
         return logits
 
     def render(self, starts: torch.Tensor, directions: torch.Tensor, near_far: torch.Tensor,
@@ -884,6 +958,7 @@ class MlpProgram:
         if regenerate is None:
             regenerate = REGENERATE_FEATURES
         ws.use_plan("bf16x3" if wgrad16 else "f32")
+        whole = saved
         saved, masks = self._split_saved(saved, n)
         if precision == "bf16x3" and self.bwd16 is not None:
             if self._packed16_dirty:
@@ -892,8 +967,18 @@ class MlpProgram:
                   _dev(self.packed16_bwd, torch.int16), _dev(d_logits), c_i64(n), _dev(masks),
                   _dev(ws.dz))
         elif self.bwd.num_steps > 0:
-            _call("ffn_mlp_backward_data", ctypes.byref(self.bwd), _dev(self.packed_bwd),
-                      _dev(d_logits), c_i64(n), _dev(masks), _dev(ws.dz))
+            head = self._tail_split(n) if precision == "f32" else None
+            if head is None:
+                _call("ffn_mlp_backward_data", ctypes.byref(self.bwd), _dev(self.packed_bwd),
+                      _dev(d_logits), c_i64(n), _dev(masks), _dev(ws.dz), c_i64(0), c_i64(0))
+            else:           # the split of the matching forward call
+                blocks, cut = (n + 31) // 32, head * 32
+                _call("ffn_mlp_backward_data", ctypes.byref(self.bwd), _dev(self.packed_bwd),
+                      _dev(d_logits[:cut]), c_i64(cut), _dev(masks), _dev(ws.dz), c_i64(0),
+                      c_i64(blocks))
+                _call("ffn_mlp_backward_data", ctypes.byref(self.bwd_pair), _dev(self.packed_bwd),
+                      _dev(d_logits[cut:]), c_i64(n - cut), _dev(self._tail_masks(whole, n)),
+                      _dev(ws.dz), c_i64(head), c_i64(blocks))
         _call("ffn_mlp_wgrad_units_bf16x3" if wgrad16 else "ffn_mlp_wgrad_units",
               ctypes.byref(self.fwd),
                   _dev(self.wgrad_units_dev, torch.uint8), _dev(ws.unit_segments, torch.uint8),

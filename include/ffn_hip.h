@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define FFN_ABI_VERSION 1
+#define FFN_ABI_VERSION 2
 
 int ffn_abi_version(void);
 const char* ffn_last_error_string(void);
@@ -312,10 +312,18 @@ int ffn_mlp_pack_jobs(const ffn_pack_job* jobs, int num_jobs, void* stream);
  * of word tile/2 = accumulator register r of that lane, tiles counted inside the wave's half;
  * an odd tile count leaves the last word's bits shifted down by 16)
  * for the backward-data chain.  `bias` = bias_floats floats: per step its padded bias, plus
- * the fused heads' blocks (head_off). */
+ * the fused heads' blocks (head_off).
+ *
+ * A launch may cover a SUB-RANGE of a batch's 32-sample blocks (the host splits a batch whose
+ * block count leaves a short last round for the persistent grid, and runs that tail on the
+ * two-waves-per-block kernels): positions / views / logits / masks are then the sub-range's own
+ * arrays (n samples), while the slabs in `saved` are addressed by the batch's block ids --
+ * slab_block0 = the launch's first block, slab_blocks = the batch's block count (the slot stride).
+ * slab_blocks == 0: the launch is the whole batch. */
 int ffn_mlp_forward(const ffn_mlp_chain* chain, const float* packed_w, const float* bias,
                     const float* positions, const float* views, int64_t n, float* logits,
-                    float* saved, uint32_t* masks, void* stream);
+                    float* saved, uint32_t* masks, int64_t slab_block0, int64_t slab_blocks,
+                    void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Fused inference render: K2 + K3 + K4 + K5 in one launch.
@@ -430,7 +438,7 @@ int ffn_mlp_backward_data_bf16x3(const ffn_mlp_chain* chain, const uint16_t* pac
  * `saved`).  packed_wt holds the transposed operand packs. */
 int ffn_mlp_backward_data(const ffn_mlp_chain* chain, const float* packed_wt,
                           const float* d_logits, int64_t n, uint32_t* masks, float* dz,
-                          void* stream);
+                          int64_t slab_block0, int64_t slab_blocks, void* stream);
 
 /* Weight gradients  dW_l = sum over samples of dZ_l (x) X_l  (autograd of the nn.Linear
  * layers, fourier_feature_models.py:70-78 / nerf_model.py:103-124).  Every operand is a

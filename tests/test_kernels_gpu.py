@@ -502,12 +502,13 @@ def test_abi_rejects_bad_arguments_with_a_message():
     chain = FfnMlpChain()                 # num_steps == 0: not a chain
     with pytest.raises(FfnError, match="bad chain"):
         _lib.call("ffn_mlp_forward", ctypes.byref(chain), ptr, ptr, ptr, c_p(0), c_i64(8), ptr,
-                  c_p(0), c_p(0), stream)
+                  c_p(0), c_p(0), c_i64(0), c_i64(0), stream)
     chain.num_steps = 1
     chain.step[0].out_tiles = 3           # not a supported tile count
     chain.step[0].act_groups = 4
     with pytest.raises(FfnError, match="bad chain"):
-        _lib.call("ffn_mlp_backward_data", ctypes.byref(chain), ptr, ptr, c_i64(8), ptr, ptr, stream)
+        _lib.call("ffn_mlp_backward_data", ctypes.byref(chain), ptr, ptr, c_i64(8), ptr, ptr,
+                  c_i64(0), c_i64(0), stream)
     with pytest.raises(FfnError, match="ffn_occupancy_build"):
         _lib.call("ffn_occupancy_build", ptr, c_i(0), ctypes.c_float(0.1), c_i(0), c_p(0), ptr, stream)
     torch.cuda.synchronize()              # nothing was launched, nothing is poisoned

