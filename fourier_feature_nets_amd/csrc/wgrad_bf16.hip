@@ -2,88 +2,112 @@
 // stays the parity mode):  dW[j][k] = sum_s dZ[j][s] X[k][s]  with every f32 product as three
 // v_mfma_f32_32x32x16_bf16 products (hi*lo + lo*hi + hi*hi, f32 accumulation).
 //
-// Same units, segments, LDS images, staging and partial format as the f32 kernel -- the f32
-// slabs are copied into LDS exactly as they sit in HBM, a wave owns a 128x128 quadrant of dW in
-// 256 accumulator registers, and the reduce kernel is shared.  What changes is the contraction
-// step: the bf16 instruction contracts SIXTEEN samples, eight consecutive ones per lane, so lane
-// (g, i) reads the float4 of channel quad i at samples 16*ks + 8*g + 0..7 (eight conflict-free
-// ds_read_b128, the same LDS traffic per sample as the f32 kernel), splits its 32 values into
-// (hi, lo) bf16 -- component p of the eight float4 is the operand of output tile row-set p --
-// and issues 48 matrix instructions per sixteen samples where the f32 kernel issues 128 at
-// four times the cost each.  At that rate the kernel is bound by the slab traffic (2 x 32 KiB per
-// block and unit), not by the matrix pipe.
+// Same units, segments and partial format as the f32 kernel (the reduce kernel is shared); a wave
+// owns a 128x128 quadrant of dW in 256 accumulator registers.  The bf16 instruction contracts
+// SIXTEEN samples, eight consecutive ones per lane: lane (g, i) reads the float4 of channel quad i
+// at samples 16 ks + 8 g + 0..7, splits its 32 values into (hi, lo) bf16 -- component p of the
+// eight float4 is the operand of output tile row-set p -- and issues 48 matrix instructions per
+// sixteen samples (3.1k matrix cycles per 32-sample block).
 //
-// FEAT (regenerate_features, OFF by default): units whose input window is a slab of encoding
-// features do not read that slab -- each wave regenerates its share of the window (the feature
-// code of the forward kernels, fourier_features.h: same instructions, same bits) from the block's
-// 32 sample positions straight into the LDS image, and the forward pass need not save features
-// (2 of the 5 KiB per sample it writes, 2 of the 9 KiB this kernel reads, tiny model).  Built,
-// bit-identical, and measured SLOWER: the block's vector work (450 conversion + 280 feature
-// instructions, which this in-order wave does not overlap with its 96 matrix instructions)
-// then exceeds the 9.4k cycles the 64 KiB of slab traffic cost -- weight gradients 8.9 -> 11.9 ms
-// for 0.7 ms saved in the forward pass (knock-outs: no matrix instructions -3.2 ms, no feature
-// generation -2.6, no conversions -1.2, no contraction at all -3.1).
+// Round 3: the kernel used to be bound by instruction issue, not by HBM (its staging
+// pattern alone streams at 7.2 TB/s; one in-order wave per SIMD issued ~450 conversion
+// instructions, 96 matrix instructions, 32 operand reads, 16 staging loads and 16 deposits per
+// block one after the other).  Now
+//   * slabs go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, non-temporal): no staging
+//     registers, no ds_write pass.  A stage is HALF a block (the sixteen samples of one
+//     contraction step: 16 KiB of the dZ window + 16 KiB of the input window, rows of 256 B
+//     gathered from the slab's 512-B rows); four stages ring through LDS, three in flight
+//     (96 KiB per CU) while one is consumed; one workgroup barrier per stage;
+//   * the 64 registers that staged the slabs hold a SECOND operand set: while the matrix
+//     instructions of step i run on one set, the operands of step i+1 are read from LDS and
+//     converted into the other.
 #include <type_traits>
 
-#include "fourier_features.h"
 #include "wgrad_common.h"
 
 namespace ffn {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// component P of eight float4 -> (hi, lo) bf16 operand
+// component P of eight float4 -> (hi, lo) bf16 operand, three vector instructions per value: per
+// pair one v_cvt_pk_bf16_f32 (both hi parts, round to nearest), a shift / a mask back to f32, two
+// subtractions, one v_cvt_pk_bf16_f32 (both lo parts) -- written on the packed words so that
+// hipcc does not assemble the eight-wide operands element by element (73 moves per two steps).
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
 template <int P>
 __device__ __forceinline__ void split_component(const f32x4 (&v)[8], bf16x8& hi, bf16x8& lo) {
+    u32x4 hw, lw;
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        const float x = v[t][P];
-        const __bf16 h = (__bf16)x;
-        hi[t] = h;
-        lo[t] = (__bf16)(x - (float)h);
+    for (int t = 0; t < 4; ++t) {
+        f32x2v x;
+        x[0] = v[2 * t][P];
+        x[1] = v[2 * t + 1][P];
+        const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2));
+        f32x2v r;
+        r[0] = x[0] - __builtin_bit_cast(float, h << 16);
+        r[1] = x[1] - __builtin_bit_cast(float, h & 0xffff0000u);
+        hw[t] = h;
+        lw[t] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+    }
+    hi = __builtin_bit_cast(bf16x8, hw);
+    lo = __builtin_bit_cast(bf16x8, lw);
+}
+
+// LDS map: four stages [A half | B half] of 16 KiB each, then a 256-B row of zeros that idle lanes
+// of a narrow window read instead of branching.
+constexpr int kHalfBytes = 16 * 1024;
+constexpr int kStageBytes = 2 * kHalfBytes;
+constexpr int kStages = 4;
+constexpr int kZeroRowAt = kStages * kStageBytes;
+constexpr int kDmaLdsBytes = kZeroRowAt + 256;
+static_assert(kDmaLdsBytes <= kUnitLdsBytes, "the head unit's images and the DMA ring share one allocation");
+
+struct Operands {
+    bf16x8 ah[4], al[4], bh[4], bl[4];
+};
+
+// s_waitcnt vmcnt(n) for a wave-uniform n in 0..16 (the count is an immediate)
+__device__ __forceinline__ void wait_vmcnt(int n) {
+    switch (n) {
+#define FFN_CASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+        FFN_CASE(1) FFN_CASE(2) FFN_CASE(3) FFN_CASE(4) FFN_CASE(5) FFN_CASE(6) FFN_CASE(7) FFN_CASE(8)
+        FFN_CASE(9) FFN_CASE(10) FFN_CASE(11) FFN_CASE(12) FFN_CASE(13) FFN_CASE(14) FFN_CASE(15)
+        FFN_CASE(16)
+#undef FFN_CASE
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
 }
 
-// the encoding whose features fill a slab slot, -1 if the slot holds activations
-__device__ __forceinline__ int encoding_of_slot(const ffn_mlp_chain& ch, int slot) {
-    for (int i = 0; i < ch.num_steps; ++i)
-        if (ch.step[i].save_enc_slot == slot) return ch.step[i].enc_id;
-    return -1;
-}
-
-template <int CA, int CB, bool BIAS, bool FEAT>
+// CA / CB: 4-KiB chunks of the full-block image (8 = a window wider than 128 channels)
+template <int CA, int CB, bool BIAS>
 __device__ __forceinline__ void unit_segment16(const ffn_mlp_chain& ch, const ffn_wgrad_unit& unit,
                                                const ffn_wgrad_segment& seg, char* smem,
                                                const float* __restrict__ saved,
                                                const float* __restrict__ dz, int64_t num_blocks,
-                                               float* __restrict__ partials,
-                                               const float* __restrict__ points, int64_t n,
-                                               int enc_id) {
+                                               float* __restrict__ partials) {
     constexpr int NQ = (CA / 4) * (CB / 4);   // quadrants that exist: 4, 2 or 1
-    constexpr int NCH = CA + CB;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int hh = lane >> 5;
     const int li = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qd = wave & (NQ - 1);
-    // waves that share a quadrant split the block's two 16-sample steps (a 128x128 unit keeps
-    // two of its four waves idle: they contribute zero partials)
+    // waves that share a quadrant split the contraction steps (a 128x128 unit keeps two of its
+    // four waves idle: they contribute zero partials)
     const int part = NQ == 4 ? 0 : (NQ == 2 ? wave >> 1 : wave);
-    const int ks_begin = NQ == 4 ? 0 : part, ks_end = NQ == 4 ? 2 : (part < 2 ? part + 1 : part);
     const int mp = CB == 8 ? qd >> 1 : qd, np = CB == 8 ? (qd & 1) : 0;
     const bool a_ok = li < unit.m_quads - 32 * mp;   // this lane's quad exists in the M window
     const bool b_ok = li < unit.n_quads - 32 * np;
     const int64_t a_stride = (int64_t)ch.slot_channels[unit.m_slot] * 128;   // bytes per block
     const int64_t b_stride = (int64_t)ch.slot_channels[unit.n_slot] * 128;
-    const char* a_s = reinterpret_cast<const char*>(dz + ch.slot_offset[unit.m_slot] * num_blocks * 32) +
-                      unit.m_cq0 * 512 + seg.blk_begin * a_stride;
-    const char* b_s = reinterpret_cast<const char*>(saved + ch.slot_offset[unit.n_slot] * num_blocks * 32) +
-                      unit.n_cq0 * 512 + seg.blk_begin * b_stride;
-    a_s = uniform_ptr(a_s);
-    b_s = uniform_ptr(b_s);
-    const int ca_last = (unit.m_quads >> 3) - 1, cb_last = (unit.n_quads >> 3) - 1;
-    const int t16 = tid * 16;
+    const char* a_base = reinterpret_cast<const char*>(dz + ch.slot_offset[unit.m_slot] * num_blocks * 32) +
+                         unit.m_cq0 * 512;
+    const char* b_base = reinterpret_cast<const char*>(saved + ch.slot_offset[unit.n_slot] * num_blocks * 32) +
+                         unit.n_cq0 * 512;
+    const int64_t steps = 2 * (seg.blk_end - seg.blk_begin);      // contraction steps = stages
 
     f32x16 acc[4][4];
 #pragma unroll
@@ -94,156 +118,193 @@ __device__ __forceinline__ void unit_segment16(const ffn_mlp_chain& ch, const ff
             for (int r = 0; r < 16; ++r) acc[p][q][r] = 0.0f;
     f32x4 bsum = zero4();
 
-    // staging registers: R[j] = chunk j of the A image (j < CA) / chunk j-CA of the B image
-    // (wgrad.hip: chunks past the end of a window re-read its last chunk)
-    f32x4 R[NCH];
-    typedef const f32x4 __attribute__((address_space(1)))* gptr;
-    constexpr int NST = FEAT ? CA : NCH;      // chunks that are staged (FEAT: the A image only)
-
-    // FEAT: this lane's sample of a block, and the window's K groups generated into LDS image
-    // `buf`: wave w takes groups w, w+4, ... (group g = channel quads 2g and 2g+1 = lane halves)
-    const EncRegs enc = load_enc(ch.enc[FEAT ? enc_id : 0],
-                                 reinterpret_cast<const float*>(smem + kUnitLdsBytes) + (FEAT ? enc_id : 0) * kEncTablePitch);
-    const int groups = unit.n_quads >> 1, g_first = unit.n_cq0 >> 1;
-    float px = 0.0f, py = 0.0f, pz = 0.0f;
-    auto load_point = [&](int64_t blk) {
-        if (!FEAT) return;
-        blk = blk < num_blocks ? blk : num_blocks - 1;
-        int64_t sample = blk * 32 + li;
-        sample = sample < n ? sample : n - 1;             // the forward pass clamps the same way
-        px = points[sample * 3 + 0]; py = points[sample * 3 + 1]; pz = points[sample * 3 + 2];
-    };
-    // Trips of four K groups (two feature_oct calls = four independent packed sincos chains).
-    // Wave w owns the contiguous groups [w*per, (w+1)*per).
-    auto generate = [&](int buf) {
-        if (!FEAT) return;
-        const f32x2 s0 = (f32x2)(enc.scale * px), s1 = (f32x2)(enc.scale * py), s2 = (f32x2)(enc.scale * pz);
-        const f32x4 q0 = (f32x4)(enc.scale * px), q1 = (f32x4)(enc.scale * py), q2 = (f32x4)(enc.scale * pz);
-        const int per = ((groups + 15) >> 4) << 2;          // groups per wave, a multiple of 4
-        const int gl_end = (wave + 1) * per < groups ? (wave + 1) * per : groups;
-        for (int gl = wave * per; gl < gl_end; gl += 4) {
-            const int g = g_first + gl;
-            f32x4 v[4];
-            if (gl + 3 < gl_end && 4 * (g + 3) + 3 < enc.F) {
-                feature_oct(enc, g, hh, q0, q1, q2, v[0], v[1]);
-                feature_oct(enc, g + 2, hh, q0, q1, q2, v[2], v[3]);
-            } else {
+    // ---- LDS-DMA: a stage = up to 32 pieces of 1 KiB (16 for the A half, 16 for the B half),
+    // piece p of a half = rows 4p..4p+3 (quads) x 256 B; lane l of the issuing wave fetches the
+    // 16 B at row 4p + (l >> 4), column l & 15.  Wave w issues pieces w, w + 4, ... of both halves;
+    // pieces past the end of a window are not issued (`per_stage` = what this wave issues).
+    const int a_pieces = unit.m_quads >> 2, b_pieces = unit.n_quads >> 2;    // <= 16 each
+    const int per_stage = (a_pieces > wave ? (a_pieces - wave + 3) >> 2 : 0) +
+                          (b_pieces > wave ? (b_pieces - wave + 3) >> 2 : 0);
+    const int dma_lane = ((lane >> 4) * 512) + ((lane & 15) * 16);
+    auto issue_stage = [&](int64_t st, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;        // both windows 256 channels: no tests
+        const int64_t blk = seg.blk_begin + (st >> 1);
+        const int half = (int)(st & 1) * 256;
+        const char* ga = a_base + blk * a_stride + half + dma_lane;
+        const char* gb = b_base + blk * b_stride + half + dma_lane;
+        char* l = smem + (int)(st & (kStages - 1)) * kStageBytes;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) v[u] = feature_quad<false>(enc, g + u, hh, px, py, pz, s0, s1, s2);
-            }
+        for (int k = 0; k < 4; ++k) {
+            const int p = wave + 4 * k;
+            if (FULL || p < a_pieces)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga + p * 2048),
+                                                 (__attribute__((address_space(3))) void*)(l + p * 1024), 16, 0, 2);
+        }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int cq = 2 * (gl + u) + hh;
-                if (gl + u < gl_end)
-                    *reinterpret_cast<f32x4*>(smem + image_b(buf) + (cq * 32 + (li ^ (cq & 15))) * 16) = v[u];
-            }
+        for (int k = 0; k < 4; ++k) {
+            const int p = wave + 4 * k;
+            if (FULL || p < b_pieces)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + p * 2048),
+                                                 (__attribute__((address_space(3))) void*)(l + kHalfBytes + p * 1024), 16, 0, 2);
         }
     };
-#define FFN_REQUEST(j)                                                                         \
-    do {                                                                                       \
-        gptr chunk = (j) < CA ? (gptr)(a_s + ((j) < ca_last ? (j) : ca_last) * 4096)           \
-                              : (gptr)(b_s + ((j) - CA < cb_last ? (j) - CA : cb_last) * 4096);  \
-        asm volatile("" : "+s"(chunk));                                                        \
-        R[j] = __builtin_nontemporal_load(&chunk[tid]);                                                                     \
-    } while (0)
-#define FFN_DEPOSIT(cur, j)                                                                    \
-    *reinterpret_cast<f32x4*>(smem + ((j) < CA ? image_a(cur) + (j) * 4096                     \
-                                               : image_b(cur) + ((j) - CA) * 4096) + t16) = R[j]
 
-    // ---- prologue: first block -> LDS buffer 0, second block -> registers
-    load_point(seg.blk_begin);
-#pragma unroll
-    for (int j = 0; j < NST; ++j) FFN_REQUEST(j);
-#pragma unroll
-    for (int j = 0; j < NST; ++j) FFN_DEPOSIT(0, j);
-    generate(0);
-    load_point(seg.blk_begin + 1);
-    a_s += a_stride;
-    b_s += b_stride;
-    if (seg.blk_begin + 1 < seg.blk_end) {
-#pragma unroll
-        for (int j = 0; j < NST; ++j) FFN_REQUEST(j);
-    }
-    a_s += a_stride;       // from here on: the block after next
-    b_s += b_stride;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-
-    // This lane's float4 of sample u = 16 ks + 8 hh + t sits at byte (u ^ (li & 15)) * 16 of its
-    // quad row = lane_x ^ ((16 ks + t) << 4) with lane_x = ((8 hh) ^ (li & 15)) << 4 (disjoint
-    // bits).  Idle lanes of a narrow window point into the image's zero row.
+    // This lane's float4 of sample 8 hh + t of a stage sits at byte ((8 hh + t) ^ (li & 15)) * 16 of
+    // its quad's 256-B row.  Idle lanes of a narrow window point into the zero row.
     const unsigned lane_x = (unsigned)(((8 * hh) ^ (li & 15)) << 4);
-    const char* a_row = smem + image_a(0) + (a_ok ? (32 * mp + li) * 512 : kImageBytes);
-    const char* b_row = smem + image_b(0) + (b_ok ? (32 * np + li) * 512 : kImageBytes);
-
-    auto block_body = [&](auto cur_tag, int64_t blk_of_body, bool has1, bool has2) {
-        constexpr int CUR = decltype(cur_tag)::value;
-        constexpr int kToggle = CUR * kImageStride;
-        // The copy of the next block (registers -> free LDS buffer) comes first and the requests
-        // for the block after it follow at once: a block is only ~6k cycles of work here, and the
-        // requests must be in flight for all of it to cover the HBM round trip (the f32 kernel,
-        // 16k cycles per block, requests in the middle of the block).
-        if (has1) {
+    const int a_row = a_ok ? (32 * mp + li) * 256 : -1;
+    const int b_row = b_ok ? (32 * np + li) * 256 : -1;
+    auto read_half = [&](int64_t st, int row, int half_off, f32x4 (&v)[8]) {
+        const char* base = row >= 0 ? smem + (int)(st & (kStages - 1)) * kStageBytes + half_off + row
+                                    : smem + kZeroRowAt;
 #pragma unroll
-            for (int j = 0; j < NST; ++j) FFN_DEPOSIT(1 - CUR, j);
-            generate(1 - CUR);               // (the point of block b+1 was requested a block ago)
+        for (int t = 0; t < 8; ++t)
+            v[t] = *reinterpret_cast<const f32x4*>(base + (lane_x ^ (unsigned)(t << 4)));
+    };
+    auto mine = [&](int64_t st) -> bool {       // (wave-uniform) does this wave contract step st?
+        return NQ == 4 || (NQ == 2 ? (int)(st & 1) == part : (part < 2 && (int)(st & 1) == part));
+    };
+    auto load_operands = [&](int64_t st, Operands& o) {
+        f32x4 v[8];
+        read_half(st, a_row, 0, v);
+        if (BIAS) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) bsum += v[t];
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (has2) {
+        split_component<0>(v, o.ah[0], o.al[0]); split_component<1>(v, o.ah[1], o.al[1]);
+        split_component<2>(v, o.ah[2], o.al[2]); split_component<3>(v, o.ah[3], o.al[3]);
+        read_half(st, b_row, kHalfBytes, v);
+        split_component<0>(v, o.bh[0], o.bl[0]); split_component<1>(v, o.bh[1], o.bl[1]);
+        split_component<2>(v, o.bh[2], o.bl[2]); split_component<3>(v, o.bh[3], o.bl[3]);
+    };
+    auto contract = [&](const Operands& o) {
 #pragma unroll
-            for (int j = 0; j < NST; ++j) FFN_REQUEST(j);
-            load_point(blk_of_body + 2);
-        }
+        for (int p = 0; p < 4; ++p)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const bool mine = ks >= ks_begin && ks < ks_end;        // (wave-uniform)
-            if (mine) {
-                f32x4 av[8], bv[8];
+            for (int q = 0; q < 4; ++q)
+                acc[p][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.ah[p], o.bl[q], acc[p][q], 0, 0, 0);
 #pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    const unsigned off = lane_x ^ (unsigned)((16 * ks + t) << 4);
-                    av[t] = *reinterpret_cast<const f32x4*>(a_row + kToggle + off);
-                    bv[t] = *reinterpret_cast<const f32x4*>(b_row + kToggle + off);
-                }
-                if (BIAS) {
+        for (int p = 0; p < 4; ++p)
 #pragma unroll
-                    for (int t = 0; t < 8; ++t) bsum += av[t];
-                }
-                bf16x8 ah[4], al[4], bh[4], bl[4];
-                split_component<0>(av, ah[0], al[0]); split_component<1>(av, ah[1], al[1]);
-                split_component<2>(av, ah[2], al[2]); split_component<3>(av, ah[3], al[3]);
-                split_component<0>(bv, bh[0], bl[0]); split_component<1>(bv, bh[1], bl[1]);
-                split_component<2>(bv, bh[2], bl[2]); split_component<3>(bv, bh[3], bl[3]);
+            for (int q = 0; q < 4; ++q)
+                acc[p][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.al[p], o.bh[q], acc[p][q], 0, 0, 0);
 #pragma unroll
-                for (int p = 0; p < 4; ++p)
+        for (int p = 0; p < 4; ++p)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        acc[p][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[p], bl[q], acc[p][q], 0, 0, 0);
-#pragma unroll
-                for (int p = 0; p < 4; ++p)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        acc[p][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[p], bh[q], acc[p][q], 0, 0, 0);
-#pragma unroll
-                for (int p = 0; p < 4; ++p)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        acc[p][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[p], bh[q], acc[p][q], 0, 0, 0);
-            }
-        }
-        a_s += a_stride;
-        b_s += b_stride;
+            for (int q = 0; q < 4; ++q)
+                acc[p][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.ah[p], o.bh[q], acc[p][q], 0, 0, 0);
+    };
+    // every wave waits for ITS pieces of stage st (the stages issued after it stay in flight),
+    // then the workgroup meets: stage st is complete in LDS and stage st - 1 has been read by all
+    auto stage_ready = [&](int64_t st) {
+        const int64_t younger = steps - 1 - st < kStages - 2 ? steps - 1 - st : kStages - 2;
+        wait_vmcnt((int)younger * per_stage);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     };
 
-    for (int64_t blk = seg.blk_begin; blk < seg.blk_end; blk += 2) {
-        block_body(std::integral_constant<int, 0>{}, blk, blk + 1 < seg.blk_end, blk + 2 < seg.blk_end);
-        if (blk + 1 < seg.blk_end)
-            block_body(std::integral_constant<int, 1>{}, blk + 1, blk + 2 < seg.blk_end, blk + 3 < seg.blk_end);
+    // ---- prologue: stages 0..2 in flight, operands of step 0 in set 0
+    for (int s = 0; s < kStages - 1 && s < steps; ++s) issue_stage(s, std::false_type{});
+    Operands set0, set1;
+    stage_ready(0);
+    if (kStages - 1 < steps) issue_stage(kStages - 1, std::false_type{});
+    if (mine(0)) load_operands(0, set0);
+
+    // ---- steady state, two steps per trip (the operand sets alternate statically).  Step i:
+    // stage i+1 becomes ready (wait + barrier: every wave has also finished READING stage i, whose
+    // slot the next DMA may overwrite), stage i+4 is requested, then the matrix instructions of
+    // step i run while the operands of step i+1 are read and converted.
+    //
+    // Full units (all four quadrants exist: every wave contracts every step) get the interleaving
+    // spelled out and pinned: an in-order wave overlaps nothing by itself, and left to hipcc the
+    // conversions sit in front of the matrix instructions.  Per pass of 16 matrix instructions
+    // (4 per output row-set p), the ~30 conversion instructions of component p of the next
+    // step's operand follow the 4 instructions of row-set p: one matrix instruction, then seven
+    // vector instructions, sixteen times (sched_group_barrier masks: 0x008 MFMA, 0x002 VALU,
+    // 0x100 DS read).
+    auto step_pipelined = [&](auto bulk_tag, int64_t i, Operands& cur, Operands& nxt) {
+        // BULK: both windows are 256 channels wide (8 pieces per wave and stage) and stage i+4
+        // exists -- no branch, no jump table in the steady state
+        constexpr bool BULK = decltype(bulk_tag)::value;
+        if (BULK) {
+            asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            issue_stage(i + kStages, std::true_type{});
+        } else {
+            stage_ready(i + 1);
+            if (i + kStages < steps) issue_stage(i + kStages, std::false_type{});
+        }
+        f32x4 v[8];
+        read_half(i + 1, a_row, 0, v);
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#define FFN_PASS(X, Y, TAIL)                                                                   \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q)                                              \
+        acc[0][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.X[0], cur.Y[q], acc[0][q], 0, 0, 0);  \
+    TAIL(0);                                                                                   \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q)                                              \
+        acc[1][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.X[1], cur.Y[q], acc[1][q], 0, 0, 0);  \
+    TAIL(1);                                                                                   \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q)                                              \
+        acc[2][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.X[2], cur.Y[q], acc[2][q], 0, 0, 0);  \
+    TAIL(2);                                                                                   \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q)                                              \
+        acc[3][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.X[3], cur.Y[q], acc[3][q], 0, 0, 0);  \
+    TAIL(3);
+#define FFN_SPLIT_A(P) split_component<P>(v, nxt.ah[P], nxt.al[P])
+#define FFN_SPLIT_B(P) split_component<P>(v, nxt.bh[P], nxt.bl[P])
+#define FFN_NOTHING(P)
+#define FFN_PIN()                                                                              \
+    _Pragma("unroll") for (int k = 0; k < 16; ++k) {                                           \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                     \
+        __builtin_amdgcn_sched_group_barrier(0x002, BIAS ? 7 : 6, 0);                          \
     }
-#undef FFN_REQUEST
-#undef FFN_DEPOSIT
+        if (BIAS) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) bsum += v[t];
+        }
+        FFN_PASS(ah, bl, FFN_SPLIT_A)
+        FFN_PIN()
+        read_half(i + 1, b_row, kHalfBytes, v);
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+        FFN_PASS(al, bh, FFN_SPLIT_B)
+        FFN_PIN()
+        FFN_PASS(ah, bh, FFN_NOTHING)
+#undef FFN_PASS
+#undef FFN_SPLIT_A
+#undef FFN_SPLIT_B
+#undef FFN_NOTHING
+#undef FFN_PIN
+    };
+    auto step = [&](int64_t i, Operands& cur, Operands& nxt) {
+        if (i + 1 < steps) {
+            stage_ready(i + 1);
+            if (i + kStages < steps) issue_stage(i + kStages, std::false_type{});
+            if (mine(i + 1)) load_operands(i + 1, nxt);
+        }
+        if (mine(i)) contract(cur);
+    };
+    if (NQ == 4) {
+        int64_t i = 0;
+        if (a_pieces == 16 && b_pieces == 16) {
+            for (; i + kStages + 1 < steps; i += 2) {    // stages i+4 and i+5 exist
+                step_pipelined(std::true_type{}, i, set0, set1);
+                step_pipelined(std::true_type{}, i + 1, set1, set0);
+            }
+        }
+        for (; i + 2 < steps; i += 2) {
+            step_pipelined(std::false_type{}, i, set0, set1);
+            step_pipelined(std::false_type{}, i + 1, set1, set0);
+        }
+        step_pipelined(std::false_type{}, steps - 2, set0, set1);
+        contract(set1);                                  // the last step has nothing to prefetch
+    } else {
+        for (int64_t i = 0; i < steps; i += 2) {
+            step(i, set0, set1);
+            if (i + 1 < steps) step(i + 1, set1, set0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();          // the ring is idle: the next segment may reuse it
 
     {
         float* out = partials + (int64_t)(seg.slot + wave) * kPartialFloats;
@@ -263,13 +324,8 @@ wgrad_unit_bf16_kernel(const ffn_mlp_chain ch, const ffn_wgrad_unit* __restrict_
                        const ffn_wgrad_segment* __restrict__ segments,
                        const int32_t* __restrict__ seg_start, const float* __restrict__ saved,
                        const float* __restrict__ dz, const float* __restrict__ d_logits, int64_t n,
-                       float* __restrict__ partials, const float* __restrict__ positions,
-                       const float* __restrict__ views, int regenerate) {
+                       float* __restrict__ partials) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    for (int k = threadIdx.x; k < 4 * 128; k += 256)      // the zero row behind each image
-        reinterpret_cast<float*>(smem + (k >> 7) * kImageStride + kImageBytes)[k & 127] = 0.0f;
-    if (regenerate) stage_encoding_tables(ch.enc, reinterpret_cast<float*>(smem + kUnitLdsBytes), threadIdx.x, 256);
-    __syncthreads();
     const int64_t num_blocks = (n + 31) / 32;
     const int seg_lo = seg_start[blockIdx.x], seg_hi = seg_start[blockIdx.x + 1];
     for (int si = seg_lo; si < seg_hi; ++si) {
@@ -281,24 +337,25 @@ wgrad_unit_bf16_kernel(const ffn_mlp_chain ch, const ffn_wgrad_unit* __restrict_
             continue;
         }
         const ffn_wgrad_unit unit = units[seg.job];
+        // the zero rows: the one behind each image (head unit) / the DMA ring's (units)
         if (unit.kind == 1) {
-            // (the logits-head unit streams X at the HBM rate in f32 already)
+            for (int k = threadIdx.x; k < 4 * 128; k += 256)
+                reinterpret_cast<float*>(smem + (k >> 7) * kImageStride + kImageBytes)[k & 127] = 0.0f;
+        } else if (threadIdx.x < 64) {
+            reinterpret_cast<float*>(smem + kZeroRowAt)[threadIdx.x] = 0.0f;
+        }
+        __syncthreads();
+        if (unit.kind == 1) {
+            // (the logits-head unit: f32, register-staged, wgrad_common.h)
             head_segment(ch, unit, seg, smem, saved, d_logits, n, num_blocks, partials);
         } else {
             const bool m_wide = unit.m_quads > 32, n_wide = unit.n_quads > 32;
             const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
             const bool bias = unit.want_bias != 0 && (!n_wide || (wave & 1) == 0);
-            const int enc_id = regenerate ? encoding_of_slot(ch, unit.n_slot) : -1;
-            const float* points = enc_id == 1 ? views : positions;
 #define FFN_UNIT(CA, CB)                                                                         \
     do {                                                                                         \
-        if (enc_id >= 0) {                                                                       \
-            if (bias) unit_segment16<CA, CB, true, true>(ch, unit, seg, smem, saved, dz, num_blocks, partials, points, n, enc_id);   \
-            else unit_segment16<CA, CB, false, true>(ch, unit, seg, smem, saved, dz, num_blocks, partials, points, n, enc_id);      \
-        } else {                                                                                 \
-            if (bias) unit_segment16<CA, CB, true, false>(ch, unit, seg, smem, saved, dz, num_blocks, partials, points, n, 0);     \
-            else unit_segment16<CA, CB, false, false>(ch, unit, seg, smem, saved, dz, num_blocks, partials, points, n, 0);        \
-        }                                                                                        \
+        if (bias) unit_segment16<CA, CB, true>(ch, unit, seg, smem, saved, dz, num_blocks, partials);   \
+        else unit_segment16<CA, CB, false>(ch, unit, seg, smem, saved, dz, num_blocks, partials);       \
     } while (0)
             if (m_wide && n_wide) FFN_UNIT(8, 8);
             else if (m_wide) FFN_UNIT(8, 4);
@@ -318,16 +375,12 @@ extern "C" int ffn_mlp_wgrad_units_bf16x3(const ffn_mlp_chain* chain, const ffn_
                                           const ffn_wgrad_segment* segments, const int32_t* seg_start,
                                           int num_groups, const float* saved, const float* dz,
                                           const float* d_logits, int64_t n, float* partials,
-                                          const float* positions, const float* views,
-                                          int regenerate_features, void* stream) {
+                                          void* stream) {
     if (n <= 0 || num_groups <= 0) return fail_arg("ffn_mlp_wgrad_units_bf16x3: shape");
-    if (regenerate_features && positions == nullptr)
-        return fail_arg("ffn_mlp_wgrad_units_bf16x3: regenerating features needs the sample positions");
-    const size_t lds = kUnitLdsBytes + kEncTableBytes;
+    const size_t lds = kUnitLdsBytes;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_unit_bf16_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(wgrad_unit_bf16_kernel, dim3(num_groups), dim3(256), lds, (hipStream_t)stream,
-                       *chain, units, segments, seg_start, saved, dz, d_logits, n, partials, positions, views,
-                       regenerate_features);
+                       *chain, units, segments, seg_start, saved, dz, d_logits, n, partials);
     return check_launch("ffn_mlp_wgrad_units_bf16x3");
 }

@@ -26,14 +26,12 @@ WGRAD_GROUPS = 256          # one persistent workgroup per CU for the LDS-staged
 # 16.4k are MFMA issue), and of a head unit (32 MFMAs per wave, bound by its memory instructions)
 UNIT_COST = {4: 24, 2: 13, 1: 8}
 HEAD_COST = 6
-# the split-bf16 kernel (wgrad_bf16.hip) is bound by the slab traffic: a full unit streams 64 KiB
-# per block (~9.4k cycles measured), the f32 head unit 32 KiB (~4.5k)
-# FFN_BF16_REGENERATE_FEATURES=1: the split-bf16 forward does not save the encoding features and
-# the weight-gradient kernel regenerates them from the sample positions (bit-identical; measured
-# slower -- see wgrad_bf16.hip -- so the default is the f32 kernels' scheme)
-REGENERATE_FEATURES = os.environ.get("FFN_BF16_REGENERATE_FEATURES", "0") == "1"
-UNIT_COST16 = {4: 24, 2: 15, 1: 12}
-HEAD_COST16 = 12
+# the split-bf16 kernel (wgrad_bf16.hip): a full unit's block costs ~2.8 us (LDS-DMA staging,
+# conversions one step ahead of the matrix instructions); units with fewer quadrants run the
+# unpipelined path and cost about as much; the f32 logits-head unit (register-staged, one block
+# ahead: latency-bound) ~2 us per block (FFN_UNIT_COST16 sweeps on MI355X, tiny and full NeRF)
+UNIT_COST16 = {4: 24, 2: 24, 1: 20}
+HEAD_COST16 = 18
 if os.environ.get("FFN_UNIT_COST16"):
     _c = [int(v) for v in os.environ["FFN_UNIT_COST16"].split(",")]
     UNIT_COST16, HEAD_COST16 = {4: _c[0], 2: _c[1], 1: _c[2]}, _c[3]
@@ -465,9 +463,6 @@ class MlpProgram:
             # training mode of the kernel: every step saves its own output (the f32 chain saves
             # some of them on consumption by the next step)
             chain.step[self.step_of[i]].out_slot = self.slot_of.get(i, -1)
-            # ... and, with REGENERATE_FEATURES, none saves encoding features
-            if REGENERATE_FEATURES:
-                chain.step[self.step_of[i]].save_enc_slot = -1
             self.pack16_jobs.append((i, kblocks, torch.tensor(cmap, dtype=torch.int32, device=self.device), off))
             off += kblocks * 8 * 1024            # 8 tiles x (hi, lo) x 64 lanes x 8 bf16
         self.fwd16 = chain
@@ -944,19 +939,17 @@ class MlpProgram:
 
     def backward(self, d_logits: torch.Tensor, positions: torch.Tensor,
                  views: Optional[torch.Tensor], saved: torch.Tensor, grads: torch.Tensor,
-                 precision: str = "f32", regenerate: Optional[bool] = None):
+                 precision: str = "f32"):
         """Fills ``grads`` (flat, num_grad_floats) from d(loss)/d(logits) (N,4) and the
-        activations ``saved`` by the matching forward call.  ``precision="bf16x3"`` (opt-in)
-        runs the split-bf16 backward-data and weight-gradient kernels; the latter regenerates
-        the encoding features from ``positions`` / ``views`` (``regenerate=False``: reads the
-        feature slabs of ``saved``, which only an f32 forward call fills)."""
+        activations ``saved`` by the matching forward call (same ``precision``; the slab formats
+        are shared, so a buffer filled by the f32 forward also serves the split-bf16 backward).
+        ``precision="bf16x3"`` (opt-in) runs the split-bf16 backward-data and weight-gradient
+        kernels."""
         n = positions.shape[0]
         if n == 0:                      # an empty batch contributes no gradient
             return grads.zero_()
         ws = self.workspace(n)
         wgrad16 = precision == "bf16x3" and not self.wide
-        if regenerate is None:
-            regenerate = REGENERATE_FEATURES
         ws.use_plan("bf16x3" if wgrad16 else "f32")
         whole = saved
         saved, masks = self._split_saved(saved, n)
@@ -983,9 +976,7 @@ class MlpProgram:
               ctypes.byref(self.fwd),
                   _dev(self.wgrad_units_dev, torch.uint8), _dev(ws.unit_segments, torch.uint8),
                   _dev(ws.unit_seg_start, torch.int32), c_i(WGRAD_GROUPS), _dev(saved),
-                  _dev(ws.dz), _dev(d_logits), c_i64(n), _dev(ws.partials),
-                  *((_dev(positions, name="positions"), _dev(views, name="views"),
-                     c_i(int(bool(regenerate)))) if wgrad16 else ()))
+                  _dev(ws.dz), _dev(d_logits), c_i64(n), _dev(ws.partials))
         _call("ffn_mlp_wgrad_reduce", _dev(ws.reduce_jobs, torch.uint8),
                   c_i(ws.num_reduce_jobs), _dev(ws.partials), _dev(grads))
         return grads

@@ -479,16 +479,12 @@ int ffn_mlp_wgrad_units(const ffn_mlp_chain* chain, const ffn_wgrad_unit* units,
                         const float* d_logits, int64_t n, float* partials, void* stream);
 /* The same launch with every f32 product as three bf16 matrix products (OPT-IN "bf16x3" training
  * precision): same units, segments, slabs and partial format; ffn_mlp_wgrad_reduce is shared.
- * regenerate_features != 0: units whose input window is an encoding's feature slab do not read
- * it -- they recompute the features (the forward kernels' code: same bits) from `positions` /
- * `views` (N,3), so the forward pass need not have saved them (a step with save_enc_slot = -1 in
- * the chain given to ffn_mlp_forward_bf16x3_train). */
+ * (Slabs are staged by LDS-DMA in half-block stages, operands converted one contraction step
+ * ahead of the matrix instructions: csrc/wgrad_bf16.hip.) */
 int ffn_mlp_wgrad_units_bf16x3(const ffn_mlp_chain* chain, const ffn_wgrad_unit* units,
                                const ffn_wgrad_segment* segments, const int32_t* seg_start,
                                int num_groups, const float* saved, const float* dz,
-                               const float* d_logits, int64_t n, float* partials,
-                               const float* positions, const float* views,
-                               int regenerate_features, void* stream);
+                               const float* d_logits, int64_t n, float* partials, void* stream);
 
 /* Fixed-order reduction of the partials of each job into the flat natural-layout
  * gradient buffer (nn.Linear weight (out,in) row-major, then bias). */

@@ -1,14 +1,14 @@
-# knock-outs of the split-bf16 weight-gradient kernel: what bounds it?  (timing only)
-NOCONTRACT = ("            const bool mine = ks >= ks_begin && ks < ks_end;        // (wave-uniform)",
-              "            const bool mine = false && ks >= ks_begin && ks < ks_end;")
-NODEPOSIT = ("            for (int j = 0; j < NST; ++j) FFN_DEPOSIT(1 - CUR, j);\n            generate(1 - CUR);",
-             "            for (int j = 0; j < NST; ++j) asm volatile(\"\" :: \"v\"(R[j]));\n            generate(1 - CUR);")
-NOREQUEST = ("            for (int j = 0; j < NST; ++j) FFN_REQUEST(j);\n            load_point(blk_of_body + 2);",
-             "            for (int j = 0; j < NST; ++j) asm volatile(\"\" : \"+v\"(R[j]));\n            load_point(blk_of_body + 2);")
-NOBARRIER = ("        a_s += a_stride;\n        b_s += b_stride;\n        asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");\n        __builtin_amdgcn_s_barrier();\n    };",
-             "        a_s += a_stride;\n        b_s += b_stride;\n        asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");\n    };")
+# knock-outs of the LDS-DMA / pipelined split-bf16 weight-gradient kernel (timing only)
+NOSPLIT = [("#define FFN_SPLIT_A(P) split_component<P>(v, nxt.ah[P], nxt.al[P])", "#define FFN_SPLIT_A(P) nxt.ah[P][0] = (__bf16)v[P][0]"),
+           ("#define FFN_SPLIT_B(P) split_component<P>(v, nxt.bh[P], nxt.bl[P])", "#define FFN_SPLIT_B(P) nxt.bh[P][0] = (__bf16)v[P][0]")]
+NODMA = [("            issue_stage(i + kStages, std::true_type{});\n", "")]
+NOMFMA = [("        acc[0][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.X[0], cur.Y[q], acc[0][q], 0, 0, 0);  \\", "        acc[0][q][0] += (float)cur.X[0][0] * (float)cur.Y[q][0];  \\"),
+          ("        acc[1][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.X[1], cur.Y[q], acc[1][q], 0, 0, 0);  \\", "        acc[1][q][0] += (float)cur.X[1][0] * (float)cur.Y[q][0];  \\"),
+          ("        acc[2][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.X[2], cur.Y[q], acc[2][q], 0, 0, 0);  \\", "        acc[2][q][0] += (float)cur.X[2][0] * (float)cur.Y[q][0];  \\"),
+          ("        acc[3][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.X[3], cur.Y[q], acc[3][q], 0, 0, 0);  \\", "        acc[3][q][0] += (float)cur.X[3][0] * (float)cur.Y[q][0];  \\")]
 VARIANTS = {
-    "wg16_nc_nodep": {"wgrad_bf16.hip": [NOCONTRACT, NODEPOSIT]},
-    "wg16_nc_noreq": {"wgrad_bf16.hip": [NOCONTRACT, NOREQUEST]},
-    "wg16_nc_nodep_noreq": {"wgrad_bf16.hip": [NOCONTRACT, NODEPOSIT, NOREQUEST]},
+    "wg16_nosplit": {"wgrad_bf16.hip": NOSPLIT},
+    "wg16_nodma": {"wgrad_bf16.hip": NODMA},
+    "wg16_nosplit_nodma": {"wgrad_bf16.hip": NOSPLIT + NODMA},
+    "wg16_nomfma": {"wgrad_bf16.hip": NOMFMA},
 }
