@@ -452,3 +452,57 @@ def test_tail_of_a_training_launch_on_the_wave_pair_kernels(golden, name):
     # launches that do not qualify: exact rounds, a long remainder, too many rounds, tiny batches
     assert prog._tail_split(32 * waves) is None and prog._tail_split(32 * (waves + waves // 2 + 1)) is None
     assert prog._tail_split(32 * 100) is None and prog._tail_split(32 * (17 * waves + 5)) is None
+
+
+# ----------------------------------------------------------------------------------- one-launch packing, loss scalar
+@pytest.mark.parametrize("name", ["positional", "nerf", "gaussian512"])
+def test_pack_jobs_launch_equals_the_per_layer_packs(golden, name):
+    """`ffn_mlp_pack_jobs` (every operand pack, bias block and fused-head block of a model in one
+    launch over a device job table) writes exactly what the per-layer `ffn_mlp_pack` launches and
+    device copies of round 2 wrote -- forward packs, transposed backward-data packs, biases, head
+    rows -- and follows the weights when they change in place."""
+    import ctypes
+    from fourier_feature_nets_amd import ops
+    from fourier_feature_nets_amd._lib import c_i, c_p
+    from tests.test_kernels_gpu import _load_fourier, _load_nerf
+    g = golden("models")
+    model = _load_nerf(g, name, [4], True)[0] if name == "nerf" else _load_fourier(g, name)[0]
+    prog = model.program()                     # packed through the job table
+    with torch.no_grad():
+        for p in model._dense_params():
+            p.mul_(1.25)
+    model.invalidate_packed()
+    prog = model.program()
+    got_fwd, got_bwd, got_bias = prog.packed_fwd.clone(), prog.packed_bwd.clone(), prog.bias_buf.clone()
+    exp_fwd, exp_bwd, exp_bias = torch.zeros_like(got_fwd), torch.zeros_like(got_bwd), torch.zeros_like(got_bias)
+    for i, spec in enumerate(prog.layers):
+        if prog.step_of[i] is None:
+            continue
+        L = prog.fwd.step[prog.step_of[i]]
+        groups, tiles = prog.fwd_shapes[i]
+        w = spec.weight.detach()
+        ops._call("ffn_mlp_pack", ops._dev(w), c_i(w.shape[0]), c_i(w.shape[1]), c_i(w.stride(0)), c_i(0), c_p(0),
+                  ops._dev(prog.col_maps[i], torch.int32), c_i(groups), c_i(tiles),
+                  ops._dev(exp_fwd[L.w_off:L.w_off + groups * tiles * 256]))
+        exp_bias[L.b_off:L.b_off + spec.out] = spec.bias.detach()
+    for (i, off, channels) in prog.fused_heads:
+        spec = prog.layers[i]
+        col, cnt = spec.to_logits
+        exp_bias[off + col:off + col + cnt] = spec.bias.detach()
+        exp_bias[off + 4:off + 4 + 4 * channels].view(channels, 4)[:, col:col + cnt] = spec.weight.detach().t()
+    for (c, groups, tiles, off) in prog.bwd_packs:
+        w = prog.layers[c].weight.detach()
+        ops._call("ffn_mlp_pack", ops._dev(w), c_i(w.shape[0]), c_i(prog.layers[c].act_in), c_i(w.stride(0)), c_i(1),
+                  c_p(0), c_p(0), c_i(groups), c_i(tiles), ops._dev(exp_bwd[off:off + groups * tiles * 256]))
+    assert torch.equal(got_fwd, exp_fwd) and torch.equal(got_bwd, exp_bwd) and torch.equal(got_bias, exp_bias)
+    assert float(got_fwd.abs().max()) > 0
+
+
+def test_loss_value_kernel():
+    """ffn_loss_value: sums[0] / (3 n) + w * sums[1] / n in one launch (image_dataset.py:237-242);
+    NaN for an empty batch like the mean over nothing."""
+    from fourier_feature_nets_amd import ops
+    sums = torch.tensor([7.25, 0.625], device=dev())
+    assert abs(float(ops.loss_value(sums, 29, 0.1)) - (7.25 / 87 + 0.1 * 0.625 / 29)) < 1e-7
+    assert abs(float(ops.loss_value(sums, 29, 0.0)) - 7.25 / 87) < 1e-7
+    assert np.isnan(float(ops.loss_value(torch.zeros(2, device=dev()), 0, 0.1)))
