@@ -569,6 +569,34 @@ def config5_leg(device, bounds, rays_per_step=32768, samples=128, cameras=25, si
         del engine
         prog.release_workspaces()
         torch.cuda.empty_cache()
+    # one 800x800 frame of the same model: the fused kernel's pair-of-waves variant against the
+    # three-pass path (sample / model / composite over HBM), without and with the grid
+    caster = ffn.Raycaster(model)
+    with contextlib.redirect_stdout(io.StringIO()):
+        orbit = ffn.RaySampler(bounds, cams[:2], samples, device=device)
+    fwd_flop = 2 * sum(sp.out * sp.ld for sp in prog.layers)
+    frame_rays = float(orbit.valid.view(2, -1).sum(1, dtype=torch.int64).double().mean().item())
+    render = {"rays_per_frame": frame_rays}
+    for label, fused, occ in (("fused", "always", None), ("three_pass", False, None),
+                              ("fused_with_occupancy_grid", "always", grid),
+                              ("three_pass_with_occupancy_grid", False, grid)):
+        caster.fused_render, caster.occupancy = fused, occ
+        caster.render_image_device(orbit, 0, 32768)
+        torch.cuda.synchronize()
+        r0 = time.perf_counter()
+        for f in range(2):
+            caster.render_image_device(orbit, f, 32768)
+        torch.cuda.synchronize()
+        fps = 2 / (time.perf_counter() - r0)
+        render[label + "_fps"] = round(fps, 3)
+        if occ is None:
+            render[label + "_f32_mfma_frac"] = round(frame_rays * samples * fwd_flop * fps / 1e12
+                                                     / F32_MFMA_PEAK_TFLOPS, 4)
+    caster.check_finite()
+    out["render_%dx%d_%d_samples" % (size, size, samples)] = render
+    del caster, orbit
+    prog.release_workspaces()
+    torch.cuda.empty_cache()
     return out
 
 

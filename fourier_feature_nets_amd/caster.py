@@ -283,7 +283,7 @@ class Raycaster(nn.Module):
         self.shuffle_source = "numpy"
         self.process_group = None         # set to a torch.distributed group for data parallel
         self.occupancy = None             # an OccupancyGrid switches on empty-space skipping (no_grad renders)
-        self.fused_render = True          # render_image / render_rays through the one-launch kernel
+        self.fused_render = True          # render_image through the one-launch kernel (False: never; "always": see _can_fuse)
         # OPT-IN empty-space skipping DURING `fit` (new semantics, DESIGN K9; BASELINE config 5):
         # (warm-up steps, refresh interval) -- after the warm-up of exact steps the training
         # engine gets an occupancy grid derived from the model itself, rebuilt every interval
@@ -354,8 +354,15 @@ class Raycaster(nn.Module):
 
     def _can_fuse(self, sampler: RaySampler) -> bool:
         model = self.model
-        return (self.fused_render and hasattr(model, "program") and sampler.num_samples <= 256
-                and getattr(model, "precision", "f32") == "f32" and not model.program().wide)
+        if not (self.fused_render and hasattr(model, "program") and sampler.num_samples <= 256
+                and getattr(model, "precision", "f32") == "f32"):
+            return False
+        # 512-wide chains: the pair-of-waves variant equals the three-pass rate without a grid
+        # (1.27 vs 1.29 frames/s at 800x800x128) but loses to the globally compacted K9 path
+        # with one (13.7 vs 17.8: per-ray blocks of 32 and two pairs in step), so that case
+        # keeps the three passes
+        # (``fused_render = "always"`` overrides, for measurements)
+        return self.fused_render == "always" or not (model.program().wide and self.occupancy is not None)
 
     def render_rays(self, sampler: RaySampler, rays, include_depth=False,
                     image: Optional[torch.Tensor] = None, pixel_offset: int = 0,

@@ -616,6 +616,15 @@ struct RenderParams {
     uint8_t* image; int64_t pixel_offset;
 };
 
+// 512-wide chains (WIDE): a PAIR of waves owns a ray (each computes half of every step's output
+// channels, like the wide forward kernel).  The chain's barriers are workgroup-wide, so the two
+// pairs of a workgroup run in step: they take NEIGHBOURING rays (validity and occupancy of
+// adjacent pixels nearly always agree, so little is wasted), agree on max(blocks) per round and a
+// pair with fewer blocks -- or no ray -- runs the remaining passes on a dummy sample with its
+// results ignored.  The even wave of a pair adds the odd wave's partial logits and composites.
+constexpr int kRenderScratchBytes = 4096;   // [0,2K) partial logits (wide) | slot lists; [2K,3K) wide slot lists; [3K,..) block counts
+
+template <bool WIDE>
 __global__ void __launch_bounds__(256, 1)
 render_fused_kernel(const ffn_mlp_chain ch, const float* __restrict__ packed_w,
                     const float* __restrict__ bias, const RenderParams p) {
@@ -629,18 +638,27 @@ render_fused_kernel(const ffn_mlp_chain ch, const float* __restrict__ packed_w,
     __syncthreads();
     WaveCtx w;
     int64_t stride;
-    wave_setup<false>(w, smem, kSamplesPerWave, stride);
+    wave_setup<WIDE>(w, smem, kSamplesPerWave, stride);
     w.block = 0;                       // nothing is saved in inference: slab addressing is unused
     w.masks = nullptr;
     const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    uint16_t* slots = reinterpret_cast<uint16_t*>(smem + kWavesPerBlock * kActBytesPerWave + kEncTableBytes +
-                                                  kBiasLdsFloats * 4) + wave_in_block * 256;
+    constexpr int kTeams = WIDE ? 2 : kWavesPerBlock;
+    const int team = WIDE ? wave_in_block >> 1 : wave_in_block;
+    char* scratch = smem + kWavesPerBlock * kActBytesPerWave + kEncTableBytes + kBiasLdsFloats * 4;
+    f32x4* partial = reinterpret_cast<f32x4*>(scratch) + team * 64;
+    uint16_t* slots = reinterpret_cast<uint16_t*>(scratch + (WIDE ? 2048 : 0)) + team * 256;
+    volatile int* team_blocks = reinterpret_cast<volatile int*>(scratch + 3072);
     const int S = p.S;
-    const int waves = gridDim.x * kWavesPerBlock;
-    for (int r = blockIdx.x * kWavesPerBlock + wave_in_block; r < p.num_rays; r += waves) {
-        const int64_t ray = p.ray_index != nullptr ? p.ray_index[r] : p.ray_base + r;
-        if (p.valid != nullptr && p.valid[ray] == 0) {      // misses the volume: black, no pixel
-            if (w.lane == 0) {
+    const int rays_per_round = gridDim.x * kTeams;
+    const int rounds = (p.num_rays + rays_per_round - 1) / rays_per_round;
+    for (int round = 0; round < rounds; ++round) {
+        const int r = WIDE ? (round * (int)gridDim.x + (int)blockIdx.x) * 2 + team
+                           : (int)blockIdx.x * kWavesPerBlock + team + round * rays_per_round;
+        bool have = r < p.num_rays;
+        const int rr = have ? r : 0;       // a pair without a ray walks ray 0's addresses
+        const int64_t ray = p.ray_index != nullptr ? p.ray_index[rr] : p.ray_base + rr;
+        if (have && p.valid != nullptr && p.valid[ray] == 0) {      // misses the volume: black, no pixel
+            if (w.lane == 0 && w.half == 0) {
                 if (p.color != nullptr) {
                     p.color[(int64_t)r * 3 + 0] = 0.f; p.color[(int64_t)r * 3 + 1] = 0.f;
                     p.color[(int64_t)r * 3 + 2] = 0.f;
@@ -648,20 +666,21 @@ render_fused_kernel(const ffn_mlp_chain ch, const float* __restrict__ packed_w,
                 if (p.alpha != nullptr) p.alpha[r] = 0.f;
                 if (p.depth != nullptr) p.depth[r] = 0.f;
             }
-            continue;
+            have = false;
         }
+        if (!WIDE && !have) continue;
         const float sx = p.starts[ray * 3 + 0], sy = p.starts[ray * 3 + 1], sz = p.starts[ray * 3 + 2];
         const float dx = p.dirs[ray * 3 + 0], dy = p.dirs[ray * 3 + 1], dz = p.dirs[ray * 3 + 2];
         const float near = p.near_far[ray], far = p.near_far[p.total_rays + ray];
         const float span = sub_rn(far, near);
         // t of sample j: given, or near + linspace(0,1,S)[j] * (far - near) with separately
         // rounded multiply and add like the sampling kernel (bit-identical t and positions)
-        const float* trow = p.t_values != nullptr ? p.t_values + (int64_t)r * S : nullptr;
+        const float* trow = p.t_values != nullptr ? p.t_values + (int64_t)rr * S : nullptr;
         auto t_of = [&](int j) -> float {
             return trow != nullptr ? trow[j] : mul_add_rn(p.unit[j], span, near);
         };
-        int m = S;
-        if (p.occ_bits != nullptr) {
+        int m = have ? S : 0;
+        if (have && p.occ_bits != nullptr) {
             m = 0;
             for (int base = 0; base < S; base += 64) {
                 const int j = base + w.lane;
@@ -672,7 +691,7 @@ render_fused_kernel(const ffn_mlp_chain ch, const float* __restrict__ packed_w,
                 const uint64_t mask = __ballot(keep);
                 const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
                                                            __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                if (keep) slots[m + rank] = (uint16_t)j;
+                if (keep) slots[m + rank] = (uint16_t)j;   // wide: both waves of the pair write the same list
                 m += __popcll(mask);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -681,38 +700,54 @@ render_fused_kernel(const ffn_mlp_chain ch, const float* __restrict__ packed_w,
         RayAccum acc;
         acc.reset();
         const int nblk = (m + 31) >> 5;
-        for (int row = 0; 2 * row < nblk; ++row) {
+        int passes = nblk;
+        if (WIDE) {                        // both pairs run max(blocks) passes
+            if (w.lane == 0 && w.half == 0) team_blocks[team] = nblk;
+            team_barrier();
+            const int other = team_blocks[team ^ 1];
+            team_barrier();                // the next round's count may not overtake this read
+            passes = __builtin_amdgcn_readfirstlane(other > nblk ? other : nblk);
+        }
+        for (int row = 0; 2 * row < passes; ++row) {
             float4 lg = make_float4(0.f, 0.f, 0.f, 0.f);
             float tj = 0.0f;
             int jj = 0;
             bool act = false;
             for (int hb = 0; hb < 2; ++hb) {
                 const int k = 2 * row + hb;
-                if (k >= nblk) break;
+                if (k >= passes) break;
+                const bool mine = k < nblk;                   // else: a pass for the neighbour's sake
                 const int slot = 32 * k + w.s;
-                const bool valid = slot < m;
-                const int sl = valid ? slot : m - 1;          // tail lanes recompute the last sample
-                const int j = p.occ_bits != nullptr ? (int)slots[sl] : sl;
+                const bool valid = mine && slot < m;
+                const int sl = valid ? slot : (m > 0 ? m - 1 : 0);   // tail lanes recompute the last sample
+                const int j = !mine ? 0 : (p.occ_bits != nullptr ? (int)slots[sl] : sl);
                 const float t = t_of(j);
                 w.x0 = mul_add_rn(t, dx, sx);
                 w.x1 = mul_add_rn(t, dy, sy);
                 w.x2 = mul_add_rn(t, dz, sz);
                 w.v0 = dx; w.v1 = dy; w.v2 = dz;
                 w.logit[0] = w.logit[1] = w.logit[2] = w.logit[3] = 0.0f;
-                run_chain<kInfer, false>(ch, w, packed_w, nullptr);
-                float out[4];
+                run_chain<kInfer, WIDE>(ch, w, packed_w, nullptr);
+                f32x4 out;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) out[c] = w.logit[c] + __shfl_xor(w.logit[c], 32);
-                if (w.h == hb) {
+                if (WIDE) {               // the two waves of a pair hold partial sums
+                    if (w.half == 1) partial[w.lane] = out;
+                    team_barrier();
+                    if (w.half == 0) out += partial[w.lane];
+                }
+                if (w.h == hb && mine) {
                     lg = make_float4(out[0], out[1], out[2], out[3]);
                     tj = t; jj = j; act = valid;
                 }
             }
+            if (2 * row >= nblk || w.half != 0) continue;
             const bool last = jj == S - 1;
             const float tnext = (act && !last) ? t_of(jj + 1) : 0.0f;
             const SampleTerms q = make_terms(lg, tj, tnext, last, act, p.nan_flag);
             acc.row(q, w.lane, jj, act && !last);
         }
+        if (!have || w.half != 0) continue;
         acc.finish();
         if (w.lane == 0) {
             if (p.color != nullptr) {
@@ -906,10 +941,12 @@ static int64_t persistent_grid(int64_t blocks32, int teams) {
     return wgs < cus ? wgs : cus;
 }
 
+static const size_t kRenderLdsBytes = kLdsBytes - kTeamScratchBytes + kRenderScratchBytes;
+
 template <typename K>
-static void allow_big_lds(K kernel) {
+static void allow_big_lds(K kernel, size_t bytes = kLdsBytes) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
 template <int MODE, bool WIDE>
@@ -953,8 +990,7 @@ extern "C" int ffn_render_fused_fwd(const ffn_mlp_chain* chain, const float* pac
     if (rays->num_rays == 0) return 0;
     if (rays->num_rays < 0 || rays->num_samples < 1 || rays->num_samples > 256)
         return fail_arg("ffn_render_fused_fwd: need 1 <= num_samples <= 256");
-    if (validate_chain(chain, false) || chain->wide)
-        return fail_arg("ffn_render_fused_fwd: bad chain (512-wide chains render through ffn_mlp_forward)");
+    if (validate_chain(chain, false)) return fail_arg("ffn_render_fused_fwd: bad chain");
     if (rays->t_values == nullptr && rays->unit == nullptr)
         return fail_arg("ffn_render_fused_fwd: unit or t_values is required");
     RenderParams p;
@@ -974,11 +1010,17 @@ extern "C" int ffn_render_fused_fwd(const ffn_mlp_chain* chain, const float* pac
     }
     p.color = out->color; p.alpha = out->alpha; p.depth = out->depth; p.nan_flag = out->nan_flag;
     p.image = out->image; p.pixel_offset = out->pixel_offset;
-    const int64_t wgs = ((int64_t)rays->num_rays + kWavesPerBlock - 1) / kWavesPerBlock;
-    const int64_t grid = persistent_grid(wgs * kWavesPerBlock, kWavesPerBlock);
-    allow_big_lds(&render_fused_kernel);
-    hipLaunchKernelGGL(render_fused_kernel, dim3((unsigned)grid), dim3(256), kLdsBytes,
-                       (hipStream_t)stream, *chain, packed_w, bias, p);
+    if (chain->wide) {                 // a pair of waves per ray, two pairs per workgroup
+        const int64_t grid = persistent_grid(rays->num_rays, 2);
+        allow_big_lds(&render_fused_kernel<true>, kRenderLdsBytes);
+        hipLaunchKernelGGL(render_fused_kernel<true>, dim3((unsigned)grid), dim3(256), kRenderLdsBytes,
+                           (hipStream_t)stream, *chain, packed_w, bias, p);
+    } else {
+        const int64_t grid = persistent_grid(rays->num_rays, kWavesPerBlock);
+        allow_big_lds(&render_fused_kernel<false>, kRenderLdsBytes);
+        hipLaunchKernelGGL(render_fused_kernel<false>, dim3((unsigned)grid), dim3(256), kRenderLdsBytes,
+                           (hipStream_t)stream, *chain, packed_w, bias, p);
+    }
     return check_launch("ffn_render_fused_fwd");
 }
 

@@ -881,9 +881,7 @@ class MlpProgram:
         (color (R,3) | None, alpha (R) | None, depth (R) | None); ``image`` (H,W,3) uint8,
         zeroed by the caller, additionally receives the truncated u8 pixels at
         ``ray id - pixel_offset``.  ``occupancy`` = an OccupancyGrid switches on empty-space
-        skipping."""
-        if self.wide:
-            raise NotImplementedError("the fused render kernel covers chains of <= 256 channels")
+        skipping.  512-wide chains run the kernel's pair-of-waves-per-ray variant."""
         base, valid = 0, None
         if isinstance(ray_index, tuple):
             base, rays, valid = int(ray_index[0]), int(ray_index[1]), ray_index[2]

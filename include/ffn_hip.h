@@ -342,7 +342,7 @@ int ffn_mlp_forward(const ffn_mlp_chain* chain, const float* packed_w, const flo
  *   out:       any of color (R,3), alpha (R), depth (R) may be NULL; image != NULL also
  *              writes the u8 pixel (x*255 truncated, ray_sampler.py:193-196) at pixel
  *              ray_id - pixel_offset of an (H*W,3) frame the caller has zeroed.
- * The chain must be a narrow (<= 256-channel) forward chain; num_samples <= 256.
+ * Any forward chain (a wide one runs a pair of wavefronts per ray); num_samples <= 256.
  */
 typedef struct ffn_render_rays {
     const float* starts;       /* (num_rays_total,3)                                   */

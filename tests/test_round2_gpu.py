@@ -458,8 +458,8 @@ def test_fused_render_full_nerf_and_samplers(golden):
 
 def test_fused_render_image_and_fallbacks(golden):
     """render_image through the fused kernel (u8 pixels written by the kernel) vs the unfused
-    path: at most one u8 level apart, almost everywhere identical; a 512-wide model silently
-    takes the unfused path."""
+    path: at most one u8 level apart, almost everywhere identical; a 512-wide model fuses too
+    (the pair-of-waves variant, tests/test_round3_gpu.py)."""
     import fourier_feature_nets_amd as ffn
     from tests.test_kernels_gpu import _load_fourier
     from tests.test_pipeline_gpu import _small_model
@@ -475,8 +475,11 @@ def test_fused_render_image_and_fallbacks(golden):
     assert a.max() > 0
     wide, _ = _load_fourier(golden("models"), "gaussian512")
     wcaster = ffn.Raycaster(wide)
-    assert not wcaster._can_fuse(sampler)
-    assert wcaster.render_image(sampler, 0, 100).shape == (16, 16, 3)
+    assert wcaster._can_fuse(sampler)
+    wa = wcaster.render_image(sampler, 0, 100)
+    wcaster.fused_render = False
+    wb = wcaster.render_image(sampler, 0, 100)
+    assert wa.shape == (16, 16, 3) and np.abs(wa.astype(np.int32) - wb.astype(np.int32)).max() <= 1
 
 
 def test_fused_render_with_empty_space_skipping():

@@ -506,3 +506,69 @@ def test_loss_value_kernel():
     assert abs(float(ops.loss_value(sums, 29, 0.1)) - (7.25 / 87 + 0.1 * 0.625 / 29)) < 1e-7
     assert abs(float(ops.loss_value(sums, 29, 0.0)) - 7.25 / 87) < 1e-7
     assert np.isnan(float(ops.loss_value(torch.zeros(2, device=dev()), 0, 0.1)))
+
+
+# ----------------------------------------------------------------------------------- 512-wide fused render
+@pytest.mark.parametrize("S", [16, 37, 64, 200])
+def test_wide_fused_render_equals_the_three_pass_render(golden, S):
+    """The pair-of-waves variant of ffn_render_fused_fwd (512-wide chains): same chain interpreter
+    and composite terms as the three-pass path, so BIT FOR BIT the same colours / alphas / depths --
+    for an index list of odd length (one pair of the last workgroup has no ray), for a single ray,
+    and for a whole-camera range filtered in the kernel (pairs whose ray misses the volume keep in
+    step with their neighbour)."""
+    import fourier_feature_nets_amd as ffn
+    from tests.test_kernels_gpu import _load_fourier
+    from tests.test_round2_gpu import _scene_sampler, _render_both_ways
+    model, _ = _load_fourier(golden("models"), "gaussian512")
+    assert model.program().wide
+    caster = ffn.Raycaster(model)
+    sampler = _scene_sampler(S)
+    rays = sampler.valid_index(torch.arange(0, sampler.num_rays, 3, device=dev()))
+    rays = rays[:rays.numel() - (1 - rays.numel() % 2)]          # odd count
+    assert rays.numel() % 2 == 1 and rays.numel() > 100
+    for subset in (rays, rays[:1]):
+        fused, plain = _render_both_ways(caster, sampler, subset)
+        assert torch.equal(fused.color, plain.color) and torch.equal(fused.alpha, plain.alpha)
+        assert torch.equal(fused.depth, plain.depth)
+    assert float(fused.alpha.max()) >= 0.0
+    caster.check_finite()
+    with torch.no_grad():
+        per = sampler.rays_per_camera
+        ranged = caster.render_rays(sampler, (per, per), include_depth=True)
+        ids = torch.arange(per, 2 * per, device=dev())
+        listed = caster.render_rays(sampler, sampler.valid_index(ids), include_depth=True)
+    keep = sampler.valid[ids] != 0
+    assert bool(keep.any()) and bool((~keep).any())
+    assert torch.equal(ranged.color[keep], listed.color) and torch.equal(ranged.alpha[keep], listed.alpha)
+    assert torch.equal(ranged.depth[keep], listed.depth)
+    assert float(ranged.color[~keep].abs().max()) == 0.0
+
+
+def test_wide_fused_render_with_empty_space_skipping(golden):
+    """In-kernel per-ray compaction in the pair-of-waves variant: neighbouring rays keep different
+    numbers of samples (a random grid), so the pairs of a workgroup run unequal block counts and
+    pad with ignored passes.  == the K9 compaction path (same samples evaluated, the others
+    contribute exactly 0)."""
+    import fourier_feature_nets_amd as ffn
+    from tests.test_kernels_gpu import _load_fourier
+    from tests.test_round2_gpu import _scene_sampler
+    model, _ = _load_fourier(golden("models"), "gaussian512")
+    caster = ffn.Raycaster(model)
+    sampler = _scene_sampler(128)
+    data = np.load(SCENE)
+    g = 8
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    logits = torch.zeros((g ** 3, 4))
+    logits[:, 3] = torch.where(torch.rand(g ** 3, generator=gen) < 0.3, 5.0, -20.0)
+    grid = ffn.OccupancyGrid.from_logits(logits.to(dev()), data["bounds"], g, 0.01, False)
+    assert 0.15 < grid.fraction_occupied() < 0.45
+    rays = sampler.valid_index(torch.arange(0, sampler.num_rays, 2, device=dev()))
+    with torch.no_grad():
+        full = caster.render_rays(sampler, rays, include_depth=True)
+        caster.occupancy = grid
+        skip_fused = caster.render_rays(sampler, rays, include_depth=True)
+        skip_k9 = caster.render(sampler.sample(rays, None), True)
+    np.testing.assert_allclose(skip_fused.color.cpu().numpy(), skip_k9.color.cpu().numpy(), rtol=2e-6, atol=1e-6)
+    np.testing.assert_allclose(skip_fused.alpha.cpu().numpy(), skip_k9.alpha.cpu().numpy(), rtol=2e-6, atol=1e-6)
+    assert not torch.equal(skip_fused.color, full.color)        # the grid did remove samples
+    caster.check_finite()
