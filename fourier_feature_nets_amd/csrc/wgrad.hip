@@ -18,19 +18,40 @@
 
 namespace ffn {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float comp_of(const f32x4& v, int q) { return v[q]; }
+__device__ __forceinline__ float comp_of(const f32x2& v, int q) { return v[q]; }
+__device__ __forceinline__ float comp_of(float v, int) { return v; }
+template <int NF> struct BOperand { typedef f32x4 type; };
+template <> struct BOperand<2> { typedef f32x2 type; };
+template <> struct BOperand<4> { typedef float type; };
+
 // CA / CB = 4 KiB chunks staged per block for the A / B image: 8 for a window wider than 128
 // channels (two quadrants along that side), 4 otherwise; BIAS = this wave also sums dZ.
-template <int CA, int CB, bool BIAS>
+//
+// NF = fold of a NARROW input window (the encoding features: 63 or 27 channels).  A lane's
+// float4 is a channel quad and its four components feed four different column tiles, so a window
+// of <= 16 quads would leave half of every tile's 32 columns on the zero row.  Folded, lane group
+// g = li / (32 / NF) reads quad li % (32 / NF) and takes components g * (4 / NF) ... of it (an
+// 8- or 4-byte LDS read at +g * 16 / NF): 4 / NF full column tiles per step instead of four
+// half-empty ones -- half / a quarter of the matrix instructions, and only the window's 2 / 1
+// chunks staged.  Column j of tile q' is then channel 4 * (j % (32/NF)) + (j / (32/NF)) * (4/NF)
+// + q' (ffn_reduce_job.n_fold tells the reducer).
+template <int CA, int CB, bool BIAS, int NF = 1>
 __device__ __forceinline__ void unit_segment(const ffn_mlp_chain& ch, const ffn_wgrad_unit& unit,
                                              const ffn_wgrad_segment& seg, char* smem,
                                              const float* __restrict__ saved,
                                              const float* __restrict__ dz, int64_t num_blocks,
                                              float* __restrict__ partials) {
+    static_assert(NF == 1 || CB == 4, "only a window of one quadrant folds");
     constexpr int NQ = (CA / 4) * (CB / 4);   // quadrants that exist: 4, 2 or 1
-    constexpr int NCH = CA + CB;
+    constexpr int CBS = CB / NF;              // chunks of the B image that are staged
+    constexpr int NCH = CA + CBS;
     constexpr int S = 4 * NQ;                 // sample pairs of a block this wave multiplies
-    constexpr int WPS = NCH / (S / 4);        // chunks deposited per step, steps [0, S/4)
-    constexpr int LPS = NCH / (S / 2);        // chunks requested per step, steps [S/4, 3S/4)
+    constexpr int NQM = 4 / NF;               // column tiles per step
+    constexpr int kGroupLanes = 32 / NF;
+    // chunks [k * NCH / (S/4), (k+1) * NCH / (S/4)) are deposited in step k of [0, S/4);
+    // chunks [k * NCH / (S/2), ...) requested in step S/4 + k of [S/4, 3S/4)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int hh = lane >> 5;
@@ -39,8 +60,10 @@ __device__ __forceinline__ void unit_segment(const ffn_mlp_chain& ch, const ffn_
     const int qd = wave & (NQ - 1);
     const int part = NQ == 4 ? 0 : (NQ == 2 ? wave >> 1 : wave);
     const int mp = CB == 8 ? qd >> 1 : qd, np = CB == 8 ? (qd & 1) : 0;
+    const int qi = li & (kGroupLanes - 1);           // B: this lane's quad ...
+    const int fg = li / kGroupLanes;                 // ... and which of its components (folded windows)
     const bool a_ok = li < unit.m_quads - 32 * mp;   // this lane's quad exists in the M window
-    const bool b_ok = li < unit.n_quads - 32 * np;
+    const bool b_ok = qi < unit.n_quads - 32 * np;
     const int64_t a_stride = (int64_t)ch.slot_channels[unit.m_slot] * 128;   // bytes per block
     const int64_t b_stride = (int64_t)ch.slot_channels[unit.n_slot] * 128;
     // wave-uniform base of the block being requested; lanes add tid*16
@@ -101,15 +124,30 @@ __device__ __forceinline__ void unit_segment(const ffn_mlp_chain& ch, const ffn_
     // sits at byte ((2u + hh) ^ (li & 15)) * 16 = x0 ^ (i << 5) for u = part*S + i.
     // Idle lanes of a narrow window point into the image's zero row.
     const unsigned x0 = (unsigned)(((hh ^ (li & 15)) << 4) ^ ((part * S) << 5));
+    const unsigned x0b = (unsigned)(((hh ^ (qi & 15)) << 4) ^ ((part * S) << 5));
     const unsigned lds0 = (unsigned)(size_t)smem;
     const unsigned a_row = lds0 + image_a(0) + (a_ok ? (32 * mp + li) * 512 : kImageBytes);
-    const unsigned b_row = lds0 + image_b(0) + (b_ok ? (32 * np + li) * 512 : kImageBytes);
+    const unsigned b_row = lds0 + image_b(0) + (b_ok ? (32 * np + qi) * 512 : kImageBytes) +
+                           (NF > 1 ? fg * (16 / NF) : 0);
     unsigned a_at[S], b_at[S];
 #pragma unroll
     for (int i = 0; i < S; ++i) {
         a_at[i] = a_row + (x0 ^ (unsigned)(i << 5));
-        b_at[i] = b_row + (x0 ^ (unsigned)(i << 5));
+        b_at[i] = b_row + (x0b ^ (unsigned)(i << 5));
     }
+    typedef typename BOperand<NF>::type bvec;
+#define FFN_READ_OPERANDS(dst_a, dst_b, idx, tail)                                             \
+    do {                                                                                       \
+        if constexpr (NF == 1)                                                                 \
+            asm volatile("ds_read_b128 %0, %2 offset:%4\n\tds_read_b128 %1, %3 offset:%4" tail \
+                         : "=&v"(dst_a), "=&v"(dst_b) : "v"(a_at[idx]), "v"(b_at[idx]), "i"(kToggle) : "memory"); \
+        else if constexpr (NF == 2)                                                            \
+            asm volatile("ds_read_b128 %0, %2 offset:%4\n\tds_read_b64 %1, %3 offset:%4" tail  \
+                         : "=&v"(dst_a), "=&v"(dst_b) : "v"(a_at[idx]), "v"(b_at[idx]), "i"(kToggle) : "memory"); \
+        else                                                                                   \
+            asm volatile("ds_read_b128 %0, %2 offset:%4\n\tds_read_b32 %1, %3 offset:%4" tail  \
+                         : "=&v"(dst_a), "=&v"(dst_b) : "v"(a_at[idx]), "v"(b_at[idx]), "i"(kToggle) : "memory"); \
+    } while (0)
 
     // one block out of the buffers of parity CUR (compile-time: the toggle is an immediate).
     // Operand reads are hand-issued (inline asm, so hipcc's waitcnt pass does not see them)
@@ -118,32 +156,33 @@ __device__ __forceinline__ void unit_segment(const ffn_mlp_chain& ch, const ffn_
     auto block_body = [&](auto cur_tag, bool has1, bool has2) {
         constexpr int CUR = decltype(cur_tag)::value;
         constexpr int kToggle = CUR * kImageStride;
-        f32x4 a, b, a_n, b_n;
-        asm volatile("ds_read_b128 %0, %2 offset:%4\n\tds_read_b128 %1, %3 offset:%4\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(a), "=&v"(b) : "v"(a_at[0]), "v"(b_at[0]), "i"(kToggle) : "memory");
+        f32x4 a, a_n;
+        bvec b, b_n;
+        FFN_READ_OPERANDS(a, b, 0, "\n\ts_waitcnt lgkmcnt(0)");
 #pragma unroll
         for (int i = 0; i < S; ++i) {
             constexpr int kLast = S - 1;
             const int in = i + 1 < S ? i + 1 : kLast;
-            asm volatile("ds_read_b128 %0, %2 offset:%4\n\tds_read_b128 %1, %3 offset:%4"
-                         : "=&v"(a_n), "=&v"(b_n) : "v"(a_at[in]), "v"(b_at[in]), "i"(kToggle) : "memory");
+            FFN_READ_OPERANDS(a_n, b_n, in, "");
             __builtin_amdgcn_sched_barrier(0);
             if (BIAS) bsum += a;
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    acc[p][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[p], b[q], acc[p][q], 0, 0, 0);
+                for (int q = 0; q < NQM; ++q)
+                    acc[p][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[p], comp_of(b, q), acc[p][q], 0, 0, 0);
                 if (p == 0) {
                     if (i < S / 4) {
                         if (has1) {
 #pragma unroll
-                            for (int jj = 0; jj < WPS; ++jj) FFN_DEPOSIT(1 - CUR, i * WPS + jj);
+                            for (int j = (i * NCH) / (S / 4); j < ((i + 1) * NCH) / (S / 4); ++j)
+                                FFN_DEPOSIT(1 - CUR, j);
                         }
                     } else if (i < 3 * S / 4) {
                         if (has2) {
 #pragma unroll
-                            for (int jj = 0; jj < LPS; ++jj) FFN_REQUEST((i - S / 4) * LPS + jj);
+                            for (int j = ((i - S / 4) * NCH) / (S / 2); j < ((i - S / 4 + 1) * NCH) / (S / 2); ++j)
+                                FFN_REQUEST(j);
                         }
                     }
                 }
@@ -166,13 +205,14 @@ __device__ __forceinline__ void unit_segment(const ffn_mlp_chain& ch, const ffn_
     }
 #undef FFN_REQUEST
 #undef FFN_DEPOSIT
+#undef FFN_READ_OPERANDS
 
     {
         float* out = partials + (int64_t)(seg.slot + wave) * kPartialFloats;
 #pragma unroll
         for (int p = 0; p < 4; ++p)
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int q = 0; q < NQM; ++q)      // (the reducer does not read the tiles a fold leaves out)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     out[((p * 4 + q) * 16 + r) * 64 + lane] = acc[p][q][r];
@@ -211,15 +251,23 @@ wgrad_unit_kernel(const ffn_mlp_chain ch, const ffn_wgrad_unit* __restrict__ uni
             // the bias gradient rides on the waves of the layer's first window that own
             // an n-half 0 quadrant (all variants execute the same barriers)
             const bool bias = unit.want_bias != 0 && (!n_wide || (wave & 1) == 0);
-#define FFN_UNIT(CA, CB)                                                                       \
+#define FFN_UNIT(CA, CB, NF)                                                                   \
     do {                                                                                       \
-        if (bias) unit_segment<CA, CB, true>(ch, unit, seg, smem, saved, dz, num_blocks, partials);  \
-        else unit_segment<CA, CB, false>(ch, unit, seg, smem, saved, dz, num_blocks, partials);      \
+        if (bias) unit_segment<CA, CB, true, NF>(ch, unit, seg, smem, saved, dz, num_blocks, partials);  \
+        else unit_segment<CA, CB, false, NF>(ch, unit, seg, smem, saved, dz, num_blocks, partials);      \
     } while (0)
-            if (m_wide && n_wide) FFN_UNIT(8, 8);
-            else if (m_wide) FFN_UNIT(8, 4);
-            else if (n_wide) FFN_UNIT(4, 8);
-            else FFN_UNIT(4, 4);
+            const int fold = ffn_wgrad_fold(unit.n_quads);
+            if (m_wide && n_wide) FFN_UNIT(8, 8, 1);
+            else if (n_wide) FFN_UNIT(4, 8, 1);
+            else if (m_wide) {
+                if (fold == 4) FFN_UNIT(8, 4, 4);
+                else if (fold == 2) FFN_UNIT(8, 4, 2);
+                else FFN_UNIT(8, 4, 1);
+            } else {
+                if (fold == 4) FFN_UNIT(4, 4, 4);
+                else if (fold == 2) FFN_UNIT(4, 4, 2);
+                else FFN_UNIT(4, 4, 1);
+            }
 #undef FFN_UNIT
         }
         __syncthreads();
@@ -235,8 +283,6 @@ wgrad_reduce_kernel(const ffn_reduce_job* __restrict__ rjobs, const float* __res
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < elems + 256; e += gridDim.x * blockDim.x) {
         float sum = 0.0f;
         if (e < elems) {
-            for (int s = job.slot_begin; s < job.slot_end; s += job.slot_stride)
-                sum += partials[(int64_t)s * kPartialFloats + e];
             const int lane = e & 63;
             const int r = (e >> 6) & 15;
             const int tile = e >> 10;
@@ -244,10 +290,16 @@ wgrad_reduce_kernel(const ffn_reduce_job* __restrict__ rjobs, const float* __res
             const int i = (r & 3) + 8 * (r >> 2) + 4 * hh;
             int row, kint;
             if (job.kind == 0) {
+                // folded window (n_fold 2 / 4): 4 / n_fold column tiles exist, column jj is quad
+                // jj % (32 / n_fold), component (jj / (32 / n_fold)) * (4 / n_fold) + q
+                const int fold = job.n_fold > 1 ? job.n_fold : 1;
+                const int group_lanes = 32 / fold, tiles = 4 / fold;
                 const int p = tile >> 2, q = tile & 3;
+                if (q >= tiles) continue;
+                const int quad = jj % group_lanes;
                 row = job.m_ch0 + 4 * i + p;
-                kint = job.k_base + 4 * (job.n_quad0 + jj) + q;
-                if (jj >= job.n_quads) continue;
+                kint = job.k_base + 4 * (job.n_quad0 + quad) + (jj / group_lanes) * tiles + q;
+                if (quad >= job.n_quads) continue;
             } else {
                 row = jj;
                 kint = job.k_base + 4 * (job.n_quad0 + i) + tile;
@@ -256,6 +308,8 @@ wgrad_reduce_kernel(const ffn_reduce_job* __restrict__ rjobs, const float* __res
             if (row >= job.rows) continue;
             const int col = job.col_map[kint];
             if (col < 0) continue;
+            for (int s = job.slot_begin; s < job.slot_end; s += job.slot_stride)
+                sum += partials[(int64_t)s * kPartialFloats + e];
             grads[job.w_grad_off + (int64_t)row * job.ld + col] = sum;
         } else if (job.has_bias) {
             // bias strip: full job -> float4 per lane (channels 4i+p); head -> one float per lane

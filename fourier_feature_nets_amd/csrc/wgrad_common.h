@@ -10,6 +10,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kPartialFloats = 16 * 16 * 64 + 256;  // 16 tiles + bias strip
 
+// fold of a narrow input window in the exact-f32 unit kernel (see wgrad.hip); the host passes the
+// same value to the reducer in ffn_reduce_job.n_fold
+__host__ __device__ __forceinline__ constexpr int ffn_wgrad_fold(int n_quads) {
+    return n_quads <= 8 ? 4 : (n_quads <= 16 ? 2 : 1);
+}
+
 __device__ __forceinline__ f32x4 zero4() { f32x4 z; z[0] = z[1] = z[2] = z[3] = 0.0f; return z; }
 
 // tells the compiler a pointer is wave-uniform (so that it lives in SGPRs and loads through it

@@ -26,6 +26,12 @@ WGRAD_GROUPS = 256          # one persistent workgroup per CU for the LDS-staged
 # 16.4k are MFMA issue), and of a head unit (32 MFMAs per wave, bound by its memory instructions)
 UNIT_COST = {4: 24, 2: 13, 1: 8}
 HEAD_COST = 6
+# folded narrow input windows (quadrants, fold): half / a quarter of the matrix instructions of the
+# unfolded unit, and by then as much operand streaming as matrix work
+FOLD_COST = {(2, 2): 7, (2, 4): 5, (1, 2): 4, (1, 4): 3}
+if os.environ.get("FFN_FOLD_COST"):       # "h2,h4,q2,q4" -- calibration experiments
+    _c = [int(v) for v in os.environ["FFN_FOLD_COST"].split(",")]
+    FOLD_COST = {(2, 2): _c[0], (2, 4): _c[1], (1, 2): _c[2], (1, 4): _c[3]}
 # the split-bf16 kernel (wgrad_bf16.hip): a full unit's block costs ~2.8 us (LDS-DMA staging,
 # conversions one step ahead of the matrix instructions); units with fewer quadrants run the
 # unpipelined path and cost about as much; the f32 logits-head unit (register-staged, one block
@@ -93,6 +99,7 @@ class FfnReduceJob(ctypes.Structure):
                 ("n_quad0", ctypes.c_int32), ("n_quads", ctypes.c_int32),
                 ("k_base", ctypes.c_int32), ("ld", ctypes.c_int32), ("has_bias", ctypes.c_int32),
                 ("lg_n", ctypes.c_int32), ("slot_stride", ctypes.c_int32),
+                ("n_fold", ctypes.c_int32), ("reserved", ctypes.c_int32),
                 ("w_grad_off", ctypes.c_int64), ("b_grad_off", ctypes.c_int64),
                 ("col_map", ctypes.c_void_p)]
 
@@ -629,6 +636,15 @@ class MlpProgram:
         return segs, starts
 
     @staticmethod
+    def _fold(n_quads: int, precision: str) -> int:
+        """Fold of a narrow input window (csrc/wgrad_common.h ``ffn_wgrad_fold``: the exact-f32
+        unit kernel packs <= 16 / <= 8 quads into 2 / 1 column tiles; the split-bf16 kernel
+        does not fold)."""
+        if precision != "f32":
+            return 1
+        return 4 if n_quads <= 8 else (2 if n_quads <= 16 else 1)
+
+    @staticmethod
     def _quadrants(m_quads: int, n_quads: int):
         """(m halves, n halves) of a unit: the 128x128 quadrants that exist."""
         return (2 if m_quads > 32 else 1), (2 if n_quads > 32 else 1)
@@ -645,7 +661,8 @@ class MlpProgram:
                 unit_costs.append(head_cost)
             else:
                 mh, nh = self._quadrants(meta["m_quads"], meta["n_quads"])
-                unit_costs.append(unit_cost[mh * nh])
+                fold = self._fold(meta["n_quads"], precision)
+                unit_costs.append(unit_cost[mh * nh] if fold == 1 else FOLD_COST[(mh * nh, fold)])
         raw, unit_starts = self._split(unit_costs, blocks, WGRAD_GROUPS)
         unit_segments = []
         unit_slots = [[] for _ in self.wgrad_units]
@@ -664,7 +681,7 @@ class MlpProgram:
                     reduce_jobs.append(FfnReduceJob(
                         1, sl[0] + half, sl[-1] + 4, 0, spec.out, meta["n_quad0"] + 32 * half,
                         min(32, meta["n_quads"] - 32 * half), meta["k_base"], spec.ld,
-                        int(meta["first"] and half == 0), meta["lg_n"], 2,
+                        int(meta["first"] and half == 0), meta["lg_n"], 2, 1, 0,
                         self.grad_w_off[meta["layer"]], self.grad_b_off[meta["layer"]],
                         self.col_maps[meta["layer"]].data_ptr()))
                 continue
@@ -677,6 +694,7 @@ class MlpProgram:
                         0, sl[0] + qd, sl[-1] + 4, 4 * (meta["m0"] + 32 * mp), spec.out,
                         meta["n_quad0"] + 32 * np_, min(32, meta["n_quads"] - 32 * np_),
                         meta["k_base"], spec.ld, int(meta["first"] and np_ == 0), 0, mh * nh,
+                        self._fold(meta["n_quads"], precision), 0,
                         self.grad_w_off[meta["layer"]], self.grad_b_off[meta["layer"]],
                         self.col_maps[meta["layer"]].data_ptr()))
         return dict(unit_segments=unit_segments, unit_starts=unit_starts,

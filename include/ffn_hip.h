@@ -500,6 +500,13 @@ typedef struct ffn_reduce_job {
     int32_t has_bias;              /* this job also carries the bias gradient          */
     int32_t lg_n;
     int32_t slot_stride;           /* distance between consecutive slots of this job   */
+    int32_t n_fold;                /* kind 0: 1, or the fold of a narrow input window: the
+                                      exact-f32 unit kernel packs a window of <= 16 / <= 8
+                                      quads into 2 / 1 column tiles (n_fold 2 / 4; column j of
+                                      tile q = quad j % (32/n_fold), component
+                                      (j / (32/n_fold)) * (4/n_fold) + q); the split-bf16 unit
+                                      kernel does not fold (n_fold 1)                       */
+    int32_t reserved;
     int64_t w_grad_off;            /* float offset of dW inside `grads`                */
     int64_t b_grad_off;            /* float offset of db inside `grads`                */
     const int32_t* col_map;        /* internal K index -> natural column, or -1        */

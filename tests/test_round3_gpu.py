@@ -6,6 +6,7 @@ optimiser step) against the masked oracle, micro-batched training steps, and dat
 
 import contextlib
 import io
+import math
 import os
 import socket
 import subprocess
@@ -572,3 +573,44 @@ def test_wide_fused_render_with_empty_space_skipping(golden):
     np.testing.assert_allclose(skip_fused.alpha.cpu().numpy(), skip_k9.alpha.cpu().numpy(), rtol=2e-6, atol=1e-6)
     assert not torch.equal(skip_fused.color, full.color)        # the grid did remove samples
     caster.check_finite()
+
+
+# ----------------------------------------------------------------------------------- folded narrow windows
+@pytest.mark.parametrize("channels,freqs", [(256, 10), (256, 4), (128, 10), (128, 4), (64, 2), (256, 1)])
+def test_weight_gradients_of_narrow_input_windows(channels, freqs):
+    """The exact-f32 unit kernel folds an input window of <= 16 / <= 8 channel quads into 2 / 1
+    column tiles (csrc/wgrad.hip, ffn_reduce_job.n_fold): every (quadrants, fold) variant --
+    (2,2) (2,4) (1,2) (1,4) -- against the oracle's autograd on the same weights, ragged sample
+    counts, several segments per unit.  (freqs f -> 6 f sin/cos features: 60, 24, 12, 6 channels.)"""
+    import fourier_feature_nets_amd as ffn
+    torch.manual_seed(channels + freqs)
+    b = (torch.randn(3, 3 * freqs) * 2.0)
+    a = torch.ones(3 * freqs)
+    model = ffn.FourierFeatureMLP(3, 4, a, b, [channels] * 3)
+    ws = [layer.weight.detach().clone() for layer in model.layers]
+    bs = [layer.bias.detach().clone() for layer in model.layers]
+    ref = orc.OracleFourierMLP(a, b, ws, bs)
+    model = model.to(dev())
+    prog = model.program()
+    folds = {prog._fold(m["n_quads"], "f32") for m in prog.unit_meta if not m.get("head")}
+    assert (2 if freqs == 10 else 4) in folds
+    for n in (70, 40000 + 13):
+        x = torch.rand(n, 3) * 2 - 1
+        probe = torch.randn(n, 4) / math.sqrt(n)
+        for par in list(ref.weights) + list(ref.biases):
+            par.grad = None
+        model.zero_grad()
+        exp = ref(x)
+        (exp * probe).sum().backward()
+        y = model(x.to(dev()))
+        np.testing.assert_allclose(y.detach().cpu().numpy(), exp.detach().numpy(), rtol=1e-4, atol=1e-4)
+        (y * probe.to(dev())).sum().backward()
+        # (a scrambled column mapping would give O(1) errors; what remains is f32 rounding of
+        # the features and an occasional ReLU sign flip)
+        for i, layer in enumerate(model.layers):
+            for got, want, what in ((layer.weight.grad, ref.weights[i].grad, "weight"),
+                                    (layer.bias.grad, ref.biases[i].grad, "bias")):
+                got, want = got.cpu().double(), want.double()
+                rel = float((got - want).norm() / want.norm())
+                assert rel < 2e-3, "layer %d %s: relative L2 error %.3g (n = %d)" % (i, what, rel, n)
+                assert float((got - want).abs().max()) < 2e-2 * float(want.abs().max())
