@@ -304,8 +304,6 @@ class MlpProgram:
         # a layer wider than 256 channels switches the whole chain to the two-waves-per-block
         # kernels (64 KiB slab per pair)
         self.wide = any(sp.to_logits is None and sp.out > 256 for sp in self.layers)
-        if os.environ.get("FFN_FORCE_WIDE") == "1":     # experiment: the two-waves-per-block kernels
-            self.wide = True
         fwd.wide = 1 if self.wide else 0
         w_off = b_off = 0
         self.col_maps: List[torch.Tensor] = []
