@@ -52,8 +52,7 @@ __device__ __forceinline__ void ring_kblock(Ring16& w, f32x16 (&acc)[OT16], cons
                                             const bf16x8& bl, f32x4 (&stage)[2][4],
                                             bf16x8 (&wh)[2][8], bf16x8 (&wl)[2][8]) {
     int ahead = w.flat + 6;
-    ahead = ahead < w.total_kb ? ahead : ahead - w.total_kb;
-    ahead = ahead < w.total_kb ? ahead : ahead - w.total_kb;
+    while (ahead >= w.total_kb) ahead -= w.total_kb;   // (uniform; one pass except in toy chains)
     const f32x4* src = w.gweights + (int64_t)ahead * kBlockVecs16 + w.tid;
 #pragma unroll
     for (int i = 0; i < 4; ++i) stage[PAR][i] = src[256 * i];

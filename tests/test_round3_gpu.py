@@ -614,3 +614,29 @@ def test_weight_gradients_of_narrow_input_windows(channels, freqs):
                 rel = float((got - want).norm() / want.norm())
                 assert rel < 2e-3, "layer %d %s: relative L2 error %.3g (n = %d)" % (i, what, rel, n)
                 assert float((got - want).abs().max()) < 2e-2 * float(want.abs().max())
+
+
+def test_split_bf16_toy_chains():
+    """Chains with fewer K blocks than the weight ring's look-ahead (one hidden layer: two to four
+    K blocks in all): the ring wraps around the chain several times per request."""
+    import fourier_feature_nets_amd as ffn
+    torch.manual_seed(3)
+    x = (torch.rand(3000, 3, device=dev()) * 2 - 1)
+    for channels, freqs in (([64], 2), ([32], 1), ([64, 64], 2), ([256], 10)):
+        b = torch.randn(3, 3 * freqs)
+        model = ffn.FourierFeatureMLP(3, 4, torch.ones(3 * freqs), b, channels).to(dev())
+        with torch.no_grad():
+            exact = model(x)
+            model.precision = "bf16x3"
+            split = model(x)
+        assert float((exact - split).abs().max()) < 2e-4 * max(1.0, float(exact.abs().max())), channels
+        # and the training kernels
+        model.precision = "f32"
+        grads = {}
+        for mode in ("f32", "bf16x3"):
+            model.train_precision = mode
+            model.zero_grad()
+            (model(x) * torch.linspace(-1, 1, 12000, device=dev()).view(3000, 4)).sum().backward()
+            grads[mode] = [p.grad.clone() for p in model.parameters() if p.grad is not None]
+        for g32, g16 in zip(grads["f32"], grads["bf16x3"]):
+            assert float((g32 - g16).norm()) <= 2e-3 * float(g32.norm()) + 1e-6, channels
