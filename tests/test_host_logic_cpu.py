@@ -116,6 +116,18 @@ def test_chain_and_wgrad_plans(make):
                         for row in rows:
                             hits[row, col] += 1
             assert hits.min() == 1 and hits.max() == 1, (li, hits.min(), hits.max())
+        # the reducer is told the fold the exact-f32 unit kernel applies to a narrow input window
+        # (csrc/wgrad_common.h ffn_wgrad_fold, decided on the UNIT's window); the split-bf16
+        # kernel never folds
+        expected = []
+        for meta in prog.unit_meta:
+            if meta.get("head"):
+                expected += [1] * sum(1 for half in range(2) if meta["n_quads"] - 32 * half > 0)
+            else:
+                mh, nh = prog._quadrants(meta["m_quads"], meta["n_quads"])
+                rule = 4 if meta["n_quads"] <= 8 else (2 if meta["n_quads"] <= 16 else 1)
+                expected += [rule if precision == "f32" else 1] * (mh * nh)
+        assert [rj.n_fold for rj in plan["reduce_jobs"]] == expected
         slots = set()
         for rj in plan["reduce_jobs"]:
             mine = set(range(rj.slot_begin, rj.slot_end, rj.slot_stride))
