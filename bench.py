@@ -702,7 +702,9 @@ def bf16_train_leg(device, dataset, rays_per_step, samples, steps=6):
             "first_step_gradient_max_abs_error": err, "first_step_gradient_max_abs": scale,
             "first_step_gradient_relative_l2_error": rel_l2,
             "loss_after_%d_steps" % (steps + 2): losses,
-            "bound": "HBM: the saved-activation slabs (75.8 GB per step) at ~3.3 TB/s average"}
+            "bound": "instruction issue of one in-order wave per SIMD (matrix + conversion + staging "
+                     "instructions in sequence), not HBM: 74 GB per step at ~3.6 TB/s average where the "
+                     "kernels' own staging pattern streams 7.2 TB/s (DESIGN: split-bf16 section)"}
 
 
 def render_leg(args, caster, sampler, world, rank, barrier):
