@@ -26,6 +26,12 @@
 namespace ffn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// the activation slabs live in LDS and are addressed through LDS-typed pointers (built from the
+// 32-bit LDS address): no generic-pointer aperture checks, ds_read / ds_write by construction
+typedef f32x4 __attribute__((address_space(3))) lds_f32x4;
+__device__ __forceinline__ lds_f32x4* lds_slab(const char* generic_lds_address) {
+    return (lds_f32x4*)(uint32_t)(uintptr_t)generic_lds_address;
+}
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kSamplesPerWave = 32;
@@ -105,7 +111,7 @@ pack_jobs_kernel(const ffn_pack_job* __restrict__ jobs) {
 template <bool SAVE>
 __device__ __forceinline__ void generate_features(const EncRegs& enc, int c0, int count, int h,
                                                   int s, int lane, float x0, float x1, float x2,
-                                                  f32x4* act, f32x4* fsave, int g_begin, int g_step) {
+                                                  lds_f32x4* act, f32x4* fsave, int g_begin, int g_step) {
     // trips of 4 K groups: g_begin, g_begin + g_step, ... (two waves sharing a slab split them)
     const f32x2 s0 = (f32x2)(enc.scale * x0), s1 = (f32x2)(enc.scale * x1), s2 = (f32x2)(enc.scale * x2);
     const f32x4 q0 = (f32x4)(enc.scale * x0), q1 = (f32x4)(enc.scale * x1), q2 = (f32x4)(enc.scale * x2);
@@ -150,6 +156,26 @@ __device__ __forceinline__ void pipeline_plain() {
     __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
     __builtin_amdgcn_sched_group_barrier(0x008, 8 * OT, 0);
 }
+// Inference: the weight loads of a half-trip (2 * OT global_load_dwordx4, consumed one half-trip
+// = 8 * OT MFMAs later) are spread ONE PER FOUR MFMAs.  A lone wave spends ~10 issue cycles per L2
+// load, and sixteen of them in a row in front of the MFMA block leave the matrix pipe idle for
+// ~150 cycles per half-trip once the previous block's last MFMA has drained (knock-out without
+// the loads: -3.3 % tiny, -4 % full NeRF; scripts/probes/variants_kloop.py); behind a running
+// MFMA their issue is free: -1.7 % on the inference forward, same box
+// (scripts/gpu/r3_ab_kloop.sh).  The pattern orders ONE basic block, and the training / backward
+// trips are several (their save stores are conditional).  Measured there and not adopted: the
+// condition hoisted into two copies of the loop (150-190 spilled registers, training forward
+// +14 %); the loads moved next to their half-trip's MFMAs (training forward +-0, full-NeRF
+// backward data +5 %) -- with stores in the trip the in-order vmcnt, not the issue slots, decides.
+template <int OT>
+__device__ __forceinline__ void pipeline_spread() {
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+    for (int i = 0; i < 2 * OT; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+}
 // `wg` is the WAVE-UNIFORM address of tile 0 of the wanted K group; tiles are 64 float4
 // apart, lanes 16 B.  Keeping the running pointer uniform lets the loads use the scalar-base
 // addressing mode: the group walk and its end-of-panel clamp are SALU work, not VALU work
@@ -171,7 +197,7 @@ struct WaveCtx {
     float x0, x1, x2;        // position of this lane's sample
     float v0, v1, v2;        // view direction of this lane's sample
     f32x4 dl;                // backward: d(loss)/d(logits) of this lane's sample
-    f32x4* act;              // this wave's LDS slab, indexed [group*64 + lane]
+    lds_f32x4* act;          // this wave's LDS slab, indexed [group*64 + lane]
     const float* enc_table;  // LDS copies of the encoding tables
     const float* bias_lds;   // LDS copy of every step's (padded) bias
     uint4* masks;            // ReLU sign masks: [slot][block][half][lane] x 128 bit
@@ -299,39 +325,65 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
 #define FFN_SAVE(g, value)                                                                     \
     __builtin_nontemporal_store((value), reinterpret_cast<f32x4*>(save_s + (int64_t)(g) * 1024 +   \
                               (save_lane ^ (unsigned)((((g) * 2) & 15) << 4))))
-        const f32x4* xa = w.act + w.lane;
+        const lds_f32x4* xa = w.act + w.lane;
         x0 = xa[0];
         x1 = xa[64];
-        for (int g = 0; g < count; g += 4) {
-            load_group<OT>(wb0, wnext, w.lane);
-            load_group<OT>(wb1, wnext + kGroupStride, w.lane);
-            x2 = xa[128];
-            x3 = xa[192];
-            if (save_lo) {
-                FFN_SAVE(g, x0);
-                FFN_SAVE(g + 1, x1);
-            }
-            mma_group<OT>(acc, wa0, x0);
-            mma_group<OT>(acc, wa1, x1);
-            gnext = gnext + 2 < glast ? gnext + 2 : glast;      // clamp at the end of the panel
-            wnext = wp + (int64_t)gnext * kGroupStride;
-            load_group<OT>(wa0, wnext, w.lane);
-            load_group<OT>(wa1, wnext + kGroupStride, w.lane);
-            xa += 256;
-            if (g + 4 < count) {
+        if (MODE == kInfer) {
+            // one basic block per trip (pipeline_spread): the next trip's first operands are read
+            // unconditionally -- the last trip re-reads its own groups, never consumed
+            for (int g = 0; g < count; g += 4) {
+                load_group<OT>(wb0, wnext, w.lane);
+                load_group<OT>(wb1, wnext + kGroupStride, w.lane);
+                x2 = xa[128];
+                x3 = xa[192];
+                mma_group<OT>(acc, wa0, x0);
+                mma_group<OT>(acc, wa1, x1);
+                gnext = gnext + 2 < glast ? gnext + 2 : glast;      // clamp at the end of the panel
+                wnext = wp + (int64_t)gnext * kGroupStride;
+                load_group<OT>(wa0, wnext, w.lane);
+                load_group<OT>(wa1, wnext + kGroupStride, w.lane);
+                xa += g + 4 < count ? 256 : 0;
                 x0 = xa[0];
                 x1 = xa[64];
+                mma_group<OT>(acc, wb0, x2);
+                mma_group<OT>(acc, wb1, x3);
+                gnext = gnext + 2 < glast ? gnext + 2 : glast;
+                wnext = wp + (int64_t)gnext * kGroupStride;
+                pipeline_spread<OT>();
+                pipeline_spread<OT>();
             }
-            if (save_hi) {
-                FFN_SAVE(g + 2, x2);
-                FFN_SAVE(g + 3, x3);
+        } else {
+            for (int g = 0; g < count; g += 4) {
+                load_group<OT>(wb0, wnext, w.lane);
+                load_group<OT>(wb1, wnext + kGroupStride, w.lane);
+                x2 = xa[128];
+                x3 = xa[192];
+                if (save_lo) {
+                    FFN_SAVE(g, x0);
+                    FFN_SAVE(g + 1, x1);
+                }
+                mma_group<OT>(acc, wa0, x0);
+                mma_group<OT>(acc, wa1, x1);
+                gnext = gnext + 2 < glast ? gnext + 2 : glast;      // clamp at the end of the panel
+                wnext = wp + (int64_t)gnext * kGroupStride;
+                load_group<OT>(wa0, wnext, w.lane);
+                load_group<OT>(wa1, wnext + kGroupStride, w.lane);
+                xa += 256;
+                if (g + 4 < count) {
+                    x0 = xa[0];
+                    x1 = xa[64];
+                }
+                if (save_hi) {
+                    FFN_SAVE(g + 2, x2);
+                    FFN_SAVE(g + 3, x3);
+                }
+                mma_group<OT>(acc, wb0, x2);
+                mma_group<OT>(acc, wb1, x3);
+                gnext = gnext + 2 < glast ? gnext + 2 : glast;
+                wnext = wp + (int64_t)gnext * kGroupStride;
+                pipeline_plain<OT>();
+                pipeline_plain<OT>();
             }
-            mma_group<OT>(acc, wb0, x2);
-            mma_group<OT>(acc, wb1, x3);
-            gnext = gnext + 2 < glast ? gnext + 2 : glast;
-            wnext = wp + (int64_t)gnext * kGroupStride;
-            pipeline_plain<OT>();
-            pipeline_plain<OT>();
         }
 #undef FFN_SAVE
     }
@@ -517,7 +569,7 @@ __device__ __forceinline__ void wave_setup(WaveCtx& w, char* smem, int64_t n, in
     const int team = WIDE ? wave_in_block >> 1 : wave_in_block;
     w.half = WIDE ? (wave_in_block & 1) : 0;
     stride = (int64_t)gridDim.x * teams;
-    w.act = reinterpret_cast<f32x4*>(smem + team * (kActBytesPerWave * kWavesPerBlock / teams));
+    w.act = lds_slab(smem + team * (kActBytesPerWave * kWavesPerBlock / teams));
     w.enc_table = reinterpret_cast<const float*>(smem + kWavesPerBlock * kActBytesPerWave);
     w.bias_lds = reinterpret_cast<const float*>(smem + kWavesPerBlock * kActBytesPerWave + kEncTableBytes);
     w.num_blocks = (n + kSamplesPerWave - 1) / kSamplesPerWave;
@@ -828,7 +880,7 @@ focus_fused_kernel(const ffn_mlp_chain ch, const float* __restrict__ packed_w,
         float sigma[1], delta[1];
         sigma[0] = w.lane < n ? softplus_probe(sigma_logit) : 0.0f;
         delta[0] = w.lane < n - 1 ? sub_rn(t_of(w.lane + 1), t_of(w.lane)) : 0.0f;
-        float* c = reinterpret_cast<float*>(w.act);       // the wave's slab is idle between rays
+        float* c = (float*)w.act;                         // the wave's slab is idle between rays
         float* tv = c + 256;
         cdf_of_probe<1>(sigma, delta, n, w.lane, c);
         float* row = p.t_io + (int64_t)r * p.S;
