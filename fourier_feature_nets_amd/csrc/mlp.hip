@@ -167,9 +167,12 @@ __device__ __forceinline__ void pipeline_plain() {
 // condition hoisted into two copies of the loop (150-190 spilled registers, training forward
 // +14 %); the loads moved next to their half-trip's MFMAs (training forward +-0, full-NeRF
 // backward data +5 %) -- with stores in the trip the in-order vmcnt, not the issue slots, decides.
-template <int OT>
+template <int OT, bool SAVES = false>
 __device__ __forceinline__ void pipeline_spread() {
     __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    // training: the half-trip's two save stores go FIRST -- vmcnt retires in order, so the loads
+    // behind them wait for their acknowledgement, but those loads are consumed a half-trip later
+    if (SAVES) __builtin_amdgcn_sched_group_barrier(0x040, 2, 0);
 #pragma unroll
     for (int i = 0; i < 2 * OT; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
@@ -289,6 +292,10 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
     // ---- K segments.  Every operand comes out of the slab: first the activations the
     // previous step left there (GA groups), then the encoding features, generated into the
     // slab in bursts of up to kChunk K groups between two K loops.
+    // Narrow training forward: EVERY K-loop trip saves the four operand groups it reads (hidden
+    // activations on consume, encoding features likewise) -- the host plans it so
+    // (validate_chain) -- which makes the trip one straight line whose issue order can be pinned.
+    constexpr bool kTripSaves = MODE == kTrainFwd && !WIDE;
     const int feat_chunks = MODE == kBackward ? 0 : (GX + kChunk - 1) / kChunk;
     const int segs = (GA > 0 ? 1 : 0) + feat_chunks;
     for (int sg = 0; sg < segs; ++sg) {
@@ -296,7 +303,8 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
         int count = GA;
         f32x4* save = nullptr;
         if (!feat) {
-            if (MODE != kInfer && L.save_in_slot >= 0 && w.active) save = slab_block(ch, slab_out, L.save_in_slot, w);
+            if (kTripSaves || (MODE != kInfer && L.save_in_slot >= 0 && w.active))
+                save = slab_block(ch, slab_out, L.save_in_slot, w);
         } else {
             const int c0 = (sg - (GA > 0 ? 1 : 0)) * kChunk;
             count = GX - c0 < kChunk ? GX - c0 : kChunk;
@@ -305,12 +313,18 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
             const float p1 = L.enc_id == 0 ? w.x1 : w.v1;
             const float p2 = L.enc_id == 0 ? w.x2 : w.v2;
             if (WIDE && sg > 0) team_barrier();   // the partner may still read what we overwrite
-            if (MODE == kTrainFwd && L.save_enc_slot >= 0 && w.active)
-                generate_features<true>(enc, c0, count, w.h, w.s, w.lane, p0, p1, p2, w.act,
-                                        slab_block(ch, slab_out, L.save_enc_slot, w), 4 * half, 4 * TW);
-            else
+            if (kTripSaves) {
+                // the features are saved like activations: "on consume", by the K-loop trips
                 generate_features<false>(enc, c0, count, w.h, w.s, w.lane, p0, p1, p2, w.act, nullptr,
                                          4 * half, 4 * TW);
+                save = slab_block(ch, slab_out, L.save_enc_slot, w) + c0 * 64;   // 1 KiB per K group
+            } else if (MODE == kTrainFwd && L.save_enc_slot >= 0 && w.active) {
+                generate_features<true>(enc, c0, count, w.h, w.s, w.lane, p0, p1, p2, w.act,
+                                        slab_block(ch, slab_out, L.save_enc_slot, w), 4 * half, 4 * TW);
+            } else {
+                generate_features<false>(enc, c0, count, w.h, w.s, w.lane, p0, p1, p2, w.act, nullptr,
+                                         4 * half, 4 * TW);
+            }
             if (WIDE) team_barrier();
         }
         // wide mode: each wave of the pair saves half of what both consume
@@ -328,7 +342,7 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
         const lds_f32x4* xa = w.act + w.lane;
         x0 = xa[0];
         x1 = xa[64];
-        if (MODE == kInfer) {
+        if (MODE == kInfer || kTripSaves) {
             // one basic block per trip (pipeline_spread): the next trip's first operands are read
             // unconditionally -- the last trip re-reads its own groups, never consumed
             for (int g = 0; g < count; g += 4) {
@@ -336,6 +350,10 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
                 load_group<OT>(wb1, wnext + kGroupStride, w.lane);
                 x2 = xa[128];
                 x3 = xa[192];
+                if (kTripSaves) {
+                    FFN_SAVE(g, x0);
+                    FFN_SAVE(g + 1, x1);
+                }
                 mma_group<OT>(acc, wa0, x0);
                 mma_group<OT>(acc, wa1, x1);
                 gnext = gnext + 2 < glast ? gnext + 2 : glast;      // clamp at the end of the panel
@@ -343,14 +361,18 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
                 load_group<OT>(wa0, wnext, w.lane);
                 load_group<OT>(wa1, wnext + kGroupStride, w.lane);
                 xa += g + 4 < count ? 256 : 0;
+                if (kTripSaves) {
+                    FFN_SAVE(g + 2, x2);
+                    FFN_SAVE(g + 3, x3);
+                }
                 x0 = xa[0];
                 x1 = xa[64];
                 mma_group<OT>(acc, wb0, x2);
                 mma_group<OT>(acc, wb1, x3);
                 gnext = gnext + 2 < glast ? gnext + 2 : glast;
                 wnext = wp + (int64_t)gnext * kGroupStride;
-                pipeline_spread<OT>();
-                pipeline_spread<OT>();
+                pipeline_spread<OT, kTripSaves>();
+                pipeline_spread<OT, kTripSaves>();
             }
         } else {
             for (int g = 0; g < count; g += 4) {
@@ -954,7 +976,7 @@ extern "C" int ffn_mlp_pack_jobs(const ffn_pack_job* jobs, int num_jobs, void* s
     return check_launch("ffn_mlp_pack_jobs");
 }
 
-static int validate_chain(const ffn_mlp_chain* ch, bool backward) {
+static int validate_chain(const ffn_mlp_chain* ch, bool backward, bool train = false) {
     if (ch == nullptr || ch->num_steps < 1 || ch->num_steps > FFN_MAX_STEPS) return 1;
     if (ch->bias_floats < 0 || ch->bias_floats > kBiasLdsFloats) return 1;
     const bool wide = ch->wide != 0;
@@ -970,6 +992,9 @@ static int validate_chain(const ffn_mlp_chain* ch, bool backward) {
         if (backward && L.aux_groups && (L.lg_n < 1 || L.lg_col < 0 || L.lg_col + L.lg_n > 4)) return 1;
         if (!backward && L.dst == 1 &&
             (wide || L.out_n < 1 || L.out_n > 4 || L.out_col < 0 || L.out_col + L.out_n > 4))
+            return 1;
+        // the narrow training forward saves from every K-loop trip
+        if (train && !wide && ((L.act_groups > 0 && L.save_in_slot < 0) || (L.aux_groups > 0 && L.save_enc_slot < 0)))
             return 1;
     }
     return 0;
@@ -1019,7 +1044,9 @@ extern "C" int ffn_mlp_forward(const ffn_mlp_chain* chain, const float* packed_w
                                int64_t n, float* logits, float* saved, uint32_t* masks,
                                int64_t slab_block0, int64_t slab_blocks, void* stream) {
     if (n == 0) return 0;
-    if (n < 0 || validate_chain(chain, false)) return fail_arg("ffn_mlp_forward: bad chain or size");
+    if (n < 0 || validate_chain(chain, false, saved != nullptr))
+        return fail_arg("ffn_mlp_forward: bad chain or size (training chains save every K segment: "
+                        "save_in_slot / save_enc_slot set wherever a step has activation / encoding inputs)");
     if ((saved == nullptr) != (masks == nullptr)) return fail_arg("ffn_mlp_forward: saved and masks go together");
     if (slab_blocks != 0 && (slab_block0 < 0 || slab_block0 + (n + 31) / 32 > slab_blocks))
         return fail_arg("ffn_mlp_forward: the launch's blocks must lie inside [0, slab_blocks)");

@@ -316,7 +316,20 @@ class MlpProgram:
         slot_off = 0
         g_off = 0
         last_producer = -1
-        saved_already = set()
+        # Who saves a hidden layer's output for the backward pass: EVERY step that consumes it
+        # saves it "on consume" from inside its K loop (the training forward's K-loop trips all
+        # save what they read: one straight-line trip); only an output that no step consumes
+        # (it feeds fused logits heads only) is saved by its producer's epilogue.  Supported
+        # models have at most one consuming step per output; a second one would store the same
+        # values to the same place again.
+        stepped_consumers = set()
+        prev = -1
+        for j, sp in enumerate(self.layers):
+            fusable = sp.to_logits is not None and sp.enc_id is None and sp.act_in > 0
+            if sp.act_in > 0 and not fusable:
+                stepped_consumers.add(prev)
+            if sp.to_logits is None:
+                prev = j
         num_steps = 0
         for i, spec in enumerate(self.layers):
             if spec.act_in % 32:
@@ -347,9 +360,8 @@ class MlpProgram:
                 P.head_off = b_off
                 self.fused_heads.append((i, b_off, spec.act_in))
                 b_off += 4 + 4 * spec.act_in
-                if last_producer not in saved_already:
+                if last_producer not in stepped_consumers:
                     P.save_out_slot = self.slot_of[last_producer]
-                    saved_already.add(last_producer)
                 self.step_of.append(None)
                 continue
             if num_steps >= MAX_STEPS:
@@ -363,9 +375,8 @@ class MlpProgram:
             L.out_tiles = _tiles(spec.out, self.wide and spec.to_logits is None)
             L.relu = 1 if spec.relu else 0
             L.save_in_slot = L.save_out_slot = L.mask_slot = L.save_enc_slot = L.head_off = -1
-            if spec.act_in > 0 and last_producer not in saved_already:
+            if spec.act_in > 0:
                 L.save_in_slot = self.slot_of[last_producer]
-                saved_already.add(last_producer)
             if spec.to_logits is None:
                 L.dst, L.out_col, L.out_n = 0, 0, 0
                 if spec.out % 32:
@@ -391,12 +402,16 @@ class MlpProgram:
         fwd.num_steps = num_steps
         fwd.num_slots = len(self.slot_of)
         fwd.bias_floats = b_off
-        # encoding features are saved by the first step that generates them (slabs after the
-        # hidden-layer ones), so that every weight-gradient window is an ordinary slab window
+        # encoding features are saved by every step that generates them (slabs after the
+        # hidden-layer ones; a second user -- NeRF's skip layer -- stores the same 8 KiB per block
+        # again), so that every weight-gradient window is an ordinary slab window
         self.dz_channels = slot_off
         self.enc_slot: Dict[int, int] = {}
         for i, spec in enumerate(self.layers):
-            if spec.enc_id is None or spec.enc_id in self.enc_slot:
+            if spec.enc_id is None:
+                continue
+            if spec.enc_id in self.enc_slot:
+                fwd.step[self.step_of[i]].save_enc_slot = self.enc_slot[spec.enc_id]
                 continue
             slot = fwd.num_slots + len(self.enc_slot)
             if slot >= MAX_STEPS:
@@ -446,6 +461,13 @@ class MlpProgram:
         if any(st.dst != 0 for _, st in steps):
             return
         chain = FfnMlpChain.from_buffer_copy(bytes(self.fwd))
+        seen_enc = set()               # this kernel saves an encoding's features once
+        for i, _ in steps:
+            st16 = chain.step[self.step_of[i]]
+            if st16.save_enc_slot >= 0:
+                if st16.save_enc_slot in seen_enc:
+                    st16.save_enc_slot = -1
+                seen_enc.add(st16.save_enc_slot)
         self.pack16_jobs = []          # (layer index, kblocks, col map tensor, element offset)
         off = 0
         for i, st in steps:
