@@ -236,7 +236,10 @@ typedef struct ffn_step {
     int32_t out_col;
     int32_t out_n;
     int32_t save_in_slot;  /* slab that receives the act-part INPUT while it is being
-                              consumed (forward: H for backward; backward: dZ), or -1  */
+                              consumed (forward: H for backward; backward: dZ), or -1.
+                              A TRAINING forward chain of <= 256 channels sets it on every
+                              step with act_groups > 0 (and save_enc_slot on every step
+                              with aux_groups > 0): its K-loop trips save unconditionally */
     int32_t save_out_slot; /* slab that receives the step's output (backward: dZ of the
                               last step; forward: input of a fused head), or -1        */
     int32_t mask_slot;     /* ReLU sign-mask slot: a forward step writes the sign bits of
