@@ -358,8 +358,8 @@ class Raycaster(nn.Module):
                 and getattr(model, "precision", "f32") == "f32"):
             return False
         # 512-wide chains: the pair-of-waves variant equals the three-pass rate without a grid
-        # (1.27 vs 1.29 frames/s at 800x800x128) but loses to the globally compacted K9 path
-        # with one (13.7 vs 17.8: per-ray blocks of 32 and two pairs in step), so that case
+        # (1.33 vs 1.35 frames/s at 800x800x128) but loses to the globally compacted K9 path
+        # with one (14.3 vs 18.6: per-ray blocks of 32 and two pairs in step), so that case
         # keeps the three passes
         # (``fused_render = "always"`` overrides, for measurements)
         return self.fused_render == "always" or not (model.program().wide and self.occupancy is not None)
