@@ -301,15 +301,25 @@ wgrad_reduce_kernel(const ffn_reduce_job* __restrict__ rjobs, const float* __res
                 kint = job.k_base + 4 * (job.n_quad0 + quad) + (jj / group_lanes) * tiles + q;
                 if (quad >= job.n_quads) continue;
             } else {
-                row = jj;
-                kint = job.k_base + 4 * (job.n_quad0 + i) + tile;
-                if (jj >= job.lg_n || i >= job.n_quads) continue;
+                // head unit (wgrad_common.h): float (q * 4 + ch) * 64 + lane, lane = (sample
+                // block, logits column); the thread of sample block 0 sums the sixteen
+                const int q = e >> 8, chn = (e >> 6) & 3, col_j = lane & 3;
+                row = col_j;
+                kint = job.k_base + 4 * (job.n_quad0 + q) + chn;
+                if ((lane >> 2) != 0 || col_j >= job.lg_n || q >= job.n_quads) continue;
             }
             if (row >= job.rows) continue;
             const int col = job.col_map[kint];
             if (col < 0) continue;
-            for (int s = job.slot_begin; s < job.slot_end; s += job.slot_stride)
-                sum += partials[(int64_t)s * kPartialFloats + e];
+            for (int s = job.slot_begin; s < job.slot_end; s += job.slot_stride) {
+                const float* part = partials + (int64_t)s * kPartialFloats + e;
+                if (job.kind == 0) {
+                    sum += part[0];
+                } else {
+#pragma unroll
+                    for (int b = 0; b < 16; ++b) sum += part[4 * b];
+                }
+            }
             grads[job.w_grad_off + (int64_t)row * job.ld + col] = sum;
         } else if (job.has_bias) {
             // bias strip: full job -> float4 per lane (channels 4i+p); head -> one float per lane
@@ -327,7 +337,8 @@ wgrad_reduce_kernel(const ffn_reduce_job* __restrict__ rjobs, const float* __res
                 if (b >= job.lg_n) continue;
                 for (int s = job.slot_begin; s < job.slot_end; s += job.slot_stride) {
                     const float* strip = partials + (int64_t)s * kPartialFloats + 16 * 16 * 64;
-                    sum += strip[b] + strip[32 + b];
+#pragma unroll
+                    for (int sbk = 0; sbk < 16; ++sbk) sum += strip[4 * sbk + b];
                 }
                 grads[job.b_grad_off + b] = sum;
             }

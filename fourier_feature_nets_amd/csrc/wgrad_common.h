@@ -61,10 +61,16 @@ __device__ __forceinline__ constexpr int image_a(int cur) { return cur * kImageS
 __device__ __forceinline__ constexpr int image_b(int cur) { return (2 + cur) * kImageStride; }
 
 // Logits-head rows inside the LDS-staged kernel: dW_head[j][k] = sum_s dl[s][j] * X[k][s] for
-// the <= 4 head outputs j.  X (<= 256 channels) is staged like any slab (through registers,
-// two blocks ahead); wave w owns channel half (w & 1) and sample half (w >> 1) of every
-// block: 8 steps x 4 MFMAs.  The unit is bound by the stream of X (32 KiB per ~2k cycles of
-// MFMA work), which is why the copy is kept two blocks deep.
+// the <= 4 head outputs j.  X (<= 256 channels) is staged like any slab (through registers, two
+// blocks ahead).  The products run on v_mfma_f32_4x4x1_16b_f32 -- sixteen independent 4x4 outer
+// products per instruction: block b = lane / 4 is a SAMPLE, A lane (b, i) = channel 4 quad + i of
+// that sample (one ds_read_b32), B lane (b, j) = d_logits column j of it (a coalesced dword load),
+// D[vgpr i][lane (b, j)] the partial dW[j][4 quad + i] of sample block b; the sixteen sample
+// blocks are summed by the reducer.  Wave w owns quads 16 w .. 16 w + 15 of the window, every
+// sample: 32 eight-cycle matrix instructions per 32-sample block where the 32x32x2 formulation
+// (4 of 32 columns used) spent 32 sixty-four-cycle ones.  The unit is bound by the stream of X
+// (32 KiB per block).  Partial of wave w (slot segment.slot + w): float (q * 4 + i) * 64 + lane
+// for its quad q, channel i; the bias strip holds dl summed per lane (b, j).
 __device__ __forceinline__ void head_segment(const ffn_mlp_chain& ch, const ffn_wgrad_unit& unit,
                                              const ffn_wgrad_segment& seg, char* smem,
                                              const float* __restrict__ saved,
@@ -72,47 +78,41 @@ __device__ __forceinline__ void head_segment(const ffn_mlp_chain& ch, const ffn_
                                              int64_t num_blocks, float* __restrict__ partials) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int hh = lane >> 5;
-    const int li = lane & 31;
+    const int sb = lane >> 2;                 // sample block of this lane: sample 16 hs + sb
+    const int li = lane & 3;                  // A: channel of the quad; B / D: logits column
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int half = wave & 1, sh = wave >> 1;
     const int lg_col = unit.m_slot, lg_n = unit.m_cq0;      // head units reuse the M fields
-    const bool x_ok = li < unit.n_quads - 32 * half;
     const bool col_ok = li < lg_n;
-    const int col = col_ok ? lg_col + li : 0;
     const int64_t x_stride = (int64_t)ch.slot_channels[unit.n_slot] * 128;    // bytes per block
     const char* x_s = reinterpret_cast<const char*>(saved + ch.slot_offset[unit.n_slot] * num_blocks * 32) +
                       unit.n_cq0 * 512 + seg.blk_begin * x_stride;
     x_s = uniform_ptr(x_s);
     const int c_last = (unit.n_quads >> 3) - 1;
     const int t16 = tid * 16;
-    f32x16 acc[4];
+    f32x4 acc[16];
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[p][r] = 0.0f;
+    for (int q = 0; q < 16; ++q) acc[q] = zero4();
     float bsum = 0.0f;
-    // this wave's 8 sample pairs of a block; d_logits straight from HBM (512 B / block),
-    // fetched one block ahead so that their latency hides behind the previous block
-    // a block's d_logits are 32 consecutive float4: uniform block base + a per-lane constant
-    // + 32 B per step (immediate); only a ragged last block needs per-sample clamping
-    const int dl_lane = (2 * (8 * sh) + hh) * 4 + col;
-    auto load_dl = [&](int64_t blk, float (&dst)[8]) {
+    // d_logits of a block: lane (sb, li) takes column lg_col + li of samples sb and 16 + sb --
+    // uniform block base + a per-lane constant; fetched one block ahead.  Only a ragged last
+    // block needs per-sample clamping.
+    const int dl_lane = 4 * sb + (col_ok ? lg_col + li : 0);
+    auto load_dl = [&](int64_t blk, float (&dst)[2]) {
         typedef const float __attribute__((address_space(1)))* gfloat;
         if ((blk + 1) * 32 <= n) {
             gfloat base = (gfloat)uniform_ptr(d_logits + blk * 128);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float v = base[dl_lane + 8 * k];
-                dst[k] = col_ok ? v : 0.0f;
+            for (int hs = 0; hs < 2; ++hs) {
+                const float v = base[dl_lane + 64 * hs];
+                dst[hs] = col_ok ? v : 0.0f;
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int64_t sample = blk * 32 + 2 * (8 * sh + k) + hh;
+            for (int hs = 0; hs < 2; ++hs) {
+                const int64_t sample = blk * 32 + 16 * hs + sb;
                 const int64_t sc = sample < n ? sample : n - 1;
-                const float v = d_logits[sc * 4 + col];
-                dst[k] = (col_ok && sample < n) ? v : 0.0f;
+                const float v = d_logits[sc * 4 + (col_ok ? lg_col + li : 0)];
+                dst[hs] = (col_ok && sample < n) ? v : 0.0f;
             }
         }
     };
@@ -125,7 +125,7 @@ __device__ __forceinline__ void head_segment(const ffn_mlp_chain& ch, const ffn_
         R[j] = __builtin_nontemporal_load(&chunk[tid]);                                                                     \
     } while (0)
 #define FFN_DEPOSIT(cur, j) *reinterpret_cast<f32x4*>(smem + image_a(cur) + (j) * 4096 + t16) = R[j]
-    float dl[8], dl_next[8];
+    float dl[2], dl_next[2];
     load_dl(seg.blk_begin, dl);
 #pragma unroll
     for (int j = 0; j < 8; ++j) FFN_REQUEST(j);
@@ -139,48 +139,55 @@ __device__ __forceinline__ void head_segment(const ffn_mlp_chain& ch, const ffn_
     x_s += x_stride;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    const int sw = li & 15;
+    // LDS byte address (inside an image) of this lane's float of quad q, sample half 0: quad row,
+    // float4 slot (sample ^ (quad & 15)), component li; the second half is +256 B.  Quads past the
+    // window read the zero row behind the image.
+    unsigned a_at[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int quad = 16 * wave + q;
+        a_at[q] = quad < unit.n_quads ? (unsigned)(quad * 512 + ((sb ^ q) << 4) + 4 * li)
+                                      : (unsigned)(kImageBytes + 4 * li);
+    }
     for (int64_t blk = seg.blk_begin; blk < seg.blk_end; ++blk) {
         const int cur = (int)((blk - seg.blk_begin) & 1);
         const bool has1 = blk + 1 < seg.blk_end, has2 = blk + 2 < seg.blk_end;
         load_dl(has1 ? blk + 1 : blk, dl_next);
-        const f32x4* lx = reinterpret_cast<const f32x4*>(smem + image_a(cur)) +
-                          (x_ok ? (32 * half + li) * 32 : kImageBytes / 16);
-        f32x4 a = lx[(2 * (8 * sh) + hh) ^ sw];
+        const char* img = smem + image_a(cur);
+        bsum += dl[0] + dl[1];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            // the next step's operand is read while this step's MFMAs run
-            const f32x4 a_next = lx[(2 * (8 * sh + (k < 7 ? k + 1 : k)) + hh) ^ sw];
-            bsum += dl[k];
+        for (int q = 0; q < 16; ++q) {
+            const float a0 = *reinterpret_cast<const float*>(img + a_at[q]);
+            const float a1 = *reinterpret_cast<const float*>(img + a_at[q] + 256);   // (zero row: 512 B)
+            acc[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0, dl[0], acc[q], 0, 0, 0);
+            acc[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1, dl[1], acc[q], 0, 0, 0);
+            if (q < 8) {
+                if (q < 2) {
+                    if (has1) {
 #pragma unroll
-            for (int p = 0; p < 4; ++p)
-                acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[p], dl[k], acc[p], 0, 0, 0);
-            if (k < 2) {
-                if (has1) {
+                        for (int jj = 0; jj < 4; ++jj) FFN_DEPOSIT(cur ^ 1, q * 4 + jj);
+                    }
+                } else if (q < 6) {
+                    if (has2) {
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) FFN_DEPOSIT(cur ^ 1, k * 4 + jj);
-                }
-            } else if (k < 6) {
-                if (has2) {
-#pragma unroll
-                    for (int jj = 0; jj < 2; ++jj) FFN_REQUEST((k - 2) * 2 + jj);
+                        for (int jj = 0; jj < 2; ++jj) FFN_REQUEST((q - 2) * 2 + jj);
+                    }
                 }
             }
-            a = a_next;
         }
         x_s += x_stride;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-#pragma unroll
-        for (int k = 0; k < 8; ++k) dl[k] = dl_next[k];
+        dl[0] = dl_next[0];
+        dl[1] = dl_next[1];
     }
 #undef FFN_REQUEST
 #undef FFN_DEPOSIT
     float* out = partials + (int64_t)(seg.slot + wave) * kPartialFloats;
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
+    for (int q = 0; q < 16; ++q)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) out[(p * 16 + r) * 64 + lane] = acc[p][r];
+        for (int i = 0; i < 4; ++i) out[(q * 4 + i) * 64 + lane] = acc[q][i];
     out[16 * 16 * 64 + lane] = bsum;
 }
 

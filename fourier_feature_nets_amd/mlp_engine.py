@@ -23,9 +23,10 @@ MAX_STEPS = 16
 WGRAD_GROUPS = 256          # one persistent workgroup per CU for the LDS-staged units
 # relative cost of one 32-sample block of a unit, by the number of 128x128 quadrants it has
 # (calibrated on MI355X with FFN_UNIT_COST sweeps: a full unit is ~18k cycles per block, of which
-# 16.4k are MFMA issue), and of a head unit (32 MFMAs per wave, bound by its memory instructions)
+# 16.4k are MFMA issue), and of a head unit (32 4x4x1 MFMAs per wave, bound by the stream of its
+# input slab: measured ~3.9; a cost of 3 puts too many of its blocks on one workgroup and costs 30 %)
 UNIT_COST = {4: 24, 2: 13, 1: 8}
-HEAD_COST = 6
+HEAD_COST = 5
 # folded narrow input windows (quadrants, fold): half / a quarter of the matrix instructions of the
 # unfolded unit, and by then as much operand streaming as matrix work
 FOLD_COST = {(2, 2): 7, (2, 4): 5, (1, 2): 4, (1, 4): 3}
@@ -34,10 +35,11 @@ if os.environ.get("FFN_FOLD_COST"):       # "h2,h4,q2,q4" -- calibration experim
     FOLD_COST = {(2, 2): _c[0], (2, 4): _c[1], (1, 2): _c[2], (1, 4): _c[3]}
 # the split-bf16 kernel (wgrad_bf16.hip): a full unit's block costs ~2.8 us (LDS-DMA staging,
 # conversions one step ahead of the matrix instructions); units with fewer quadrants run the
-# unpipelined path and cost about as much; the f32 logits-head unit (register-staged, one block
-# ahead: latency-bound) ~2 us per block (FFN_UNIT_COST16 sweeps on MI355X, tiny and full NeRF)
+# unpipelined path and cost about as much; the f32 logits-head unit (register-staged, 4x4x1
+# MFMAs) ~1.4 us per block (FFN_UNIT_COST16 sweeps on MI355X, tiny and full NeRF: best at 12,
+# a cliff at 10)
 UNIT_COST16 = {4: 24, 2: 24, 1: 20}
-HEAD_COST16 = 18
+HEAD_COST16 = 13
 if os.environ.get("FFN_UNIT_COST16"):
     _c = [int(v) for v in os.environ["FFN_UNIT_COST16"].split(",")]
     UNIT_COST16, HEAD_COST16 = {4: _c[0], 2: _c[1], 1: _c[2]}, _c[3]
@@ -695,13 +697,13 @@ class MlpProgram:
             sl = unit_slots[u]
             assert sl == list(range(sl[0], sl[-1] + 4, 4))
             if meta.get("head"):
-                for half in range(2):           # channel halves; both sample halves summed
-                    if meta["n_quads"] - 32 * half <= 0:
+                for wave in range(4):           # wave w owns quads 16 w .. 16 w + 15, every sample
+                    if meta["n_quads"] - 16 * wave <= 0:
                         continue
                     reduce_jobs.append(FfnReduceJob(
-                        1, sl[0] + half, sl[-1] + 4, 0, spec.out, meta["n_quad0"] + 32 * half,
-                        min(32, meta["n_quads"] - 32 * half), meta["k_base"], spec.ld,
-                        int(meta["first"] and half == 0), meta["lg_n"], 2, 1, 0,
+                        1, sl[0] + wave, sl[-1] + 4, 0, spec.out, meta["n_quad0"] + 16 * wave,
+                        min(16, meta["n_quads"] - 16 * wave), meta["k_base"], spec.ld,
+                        int(meta["first"] and wave == 0), meta["lg_n"], 4, 1, 0,
                         self.grad_w_off[meta["layer"]], self.grad_b_off[meta["layer"]],
                         self.col_maps[meta["layer"]].data_ptr()))
                 continue

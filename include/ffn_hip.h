@@ -472,8 +472,8 @@ typedef struct ffn_wgrad_unit {
     int32_t n_slot;    /* slab index of the input window                               */
     int32_t n_cq0;     /* first channel quad of the window                             */
     int32_t n_quads;   /* valid quads (<= 64, multiple of 8)                           */
-    int32_t kind;      /* 0 = dW block; 1 = logits-head rows: waves own (channel half,
-                          sample half), partial slots segment.slot + 2*sample_half + half */
+    int32_t kind;      /* 0 = dW block; 1 = logits-head rows: wave w owns channel quads
+                          16 w .. 16 w + 15 of the window, partial slot segment.slot + w     */
 } ffn_wgrad_unit;
 
 int ffn_mlp_wgrad_units(const ffn_mlp_chain* chain, const ffn_wgrad_unit* units,

@@ -122,7 +122,7 @@ def test_chain_and_wgrad_plans(make):
         expected = []
         for meta in prog.unit_meta:
             if meta.get("head"):
-                expected += [1] * sum(1 for half in range(2) if meta["n_quads"] - 32 * half > 0)
+                expected += [1] * sum(1 for wave in range(4) if meta["n_quads"] - 16 * wave > 0)
             else:
                 mh, nh = prog._quadrants(meta["m_quads"], meta["n_quads"])
                 rule = 4 if meta["n_quads"] <= 8 else (2 if meta["n_quads"] <= 16 else 1)
