@@ -190,13 +190,19 @@ class TrainEngine:
                 sums.add_(part)
         if self.group is not None:
             self._all_reduce()
+        if global_count == 0:
+            # no ray of the batch hits the volume (every rank sees the same global count).  The
+            # reference takes the mean of empty tensors here (ray_caster.py:321-326): a NaN loss
+            # whose backward poisons every weight.  The loss is reported the same way (0 / 0), but
+            # the optimiser step is skipped: no moment decay, no weight decay, weights intact.
+            return ops.loss_value(sums, 0, aw)
         self.count += 1
         ops.clip_adam(self.flat, self.grads, self.exp_avg, self.exp_avg_sq, self.count, lr,
                       weight_decay=self.weight_decay, scratch=self.scratch,
                       norm_out=self.grad_norm)
         self.model.invalidate_packed()
         # (a fresh tensor: the reduce buffer is overwritten by the next step)
-        loss = ops.loss_value(sums, max(global_count, 0), aw)
+        loss = ops.loss_value(sums, global_count, aw)
         if self.loss_history is not None:
             self.loss_history.append(loss)
         return loss

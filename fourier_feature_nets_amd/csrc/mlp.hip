@@ -37,7 +37,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kSamplesPerWave = 32;
 constexpr int kWavesPerBlock = 4;
 constexpr int kActBytesPerWave = 32 * 1024;  // 256 channels x 32 samples x 4 B
-constexpr int kBiasLdsFloats = 4096;         // LDS copy of all (padded) biases
+constexpr int kBiasLdsFloats = 4096;         // LDS copy of the bias buffer's first floats: every
+                                             // fused-head block, then as many step biases as fit
 
 enum Mode { kInfer = 0, kTrainFwd = 1, kBackward = 2 };
 
@@ -202,7 +203,8 @@ struct WaveCtx {
     f32x4 dl;                // backward: d(loss)/d(logits) of this lane's sample
     lds_f32x4* act;          // this wave's LDS slab, indexed [group*64 + lane]
     const float* enc_table;  // LDS copies of the encoding tables
-    const float* bias_lds;   // LDS copy of every step's (padded) bias
+    const float* bias_lds;   // LDS copy of the head of the bias buffer (kBiasLdsFloats floats)
+    const float* bias_glb;   // the whole bias buffer (steps whose bias lies past the LDS copy)
     uint4* masks;            // ReLU sign masks: [slot][block][half][lane] x 128 bit
     int64_t block;           // 32-sample block id inside this launch
     int64_t num_blocks;
@@ -255,8 +257,20 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
         for (int o = 0; o < OT; ++o)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[o][r] = 0.0f;
-    } else {
+    } else if (L.b_off + 32 * OT * TW <= kBiasLdsFloats) {
         const float* bv = w.bias_lds + L.b_off + 32 * OT * half + 4 * w.h;
+#pragma unroll
+        for (int o = 0; o < OT; ++o)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(bv + 32 * o + 8 * q);
+#pragma unroll
+                for (int p = 0; p < 4; ++p) acc[o][4 * q + p] = b4[p];
+            }
+    } else {
+        // a deep / 512-wide chain whose biases outgrow the LDS copy (a 512-wide full NeRF: 7.9k
+        // floats): this step's bias comes from L2 -- two distinct 16-byte addresses per load
+        const float* bv = w.bias_glb + L.b_off + 32 * OT * half + 4 * w.h;
 #pragma unroll
         for (int o = 0; o < OT; ++o)
 #pragma unroll
@@ -613,12 +627,14 @@ mlp_forward_kernel(const ffn_mlp_chain ch, const float* __restrict__ packed_w,
                           threadIdx.x, 256);
     {
         float* bl = reinterpret_cast<float*>(smem + kWavesPerBlock * kActBytesPerWave + kEncTableBytes);
-        for (int i = threadIdx.x; i < ch.bias_floats; i += 256) bl[i] = bias[i];
+        const int staged = ch.bias_floats < kBiasLdsFloats ? ch.bias_floats : kBiasLdsFloats;
+        for (int i = threadIdx.x; i < staged; i += 256) bl[i] = bias[i];
     }
     __syncthreads();                  // narrow mode: the only barrier of the kernel
     WaveCtx w;
     int64_t stride;
     wave_setup<WIDE>(w, smem, n, stride);
+    w.bias_glb = bias;
     if (slab_blocks > 0) { w.slab_block0 = slab_block0; w.slab_blocks = slab_blocks; }
     w.masks = reinterpret_cast<uint4*>(masks);
     f32x4* scratch = reinterpret_cast<f32x4*>(smem + kWavesPerBlock * kActBytesPerWave + kEncTableBytes +
@@ -707,12 +723,14 @@ render_fused_kernel(const ffn_mlp_chain ch, const float* __restrict__ packed_w,
                           threadIdx.x, 256);
     {
         float* bl = reinterpret_cast<float*>(smem + kWavesPerBlock * kActBytesPerWave + kEncTableBytes);
-        for (int i = threadIdx.x; i < ch.bias_floats; i += 256) bl[i] = bias[i];
+        const int staged = ch.bias_floats < kBiasLdsFloats ? ch.bias_floats : kBiasLdsFloats;
+        for (int i = threadIdx.x; i < staged; i += 256) bl[i] = bias[i];
     }
     __syncthreads();
     WaveCtx w;
     int64_t stride;
     wave_setup<WIDE>(w, smem, kSamplesPerWave, stride);
+    w.bias_glb = bias;
     w.block = 0;                       // nothing is saved in inference: slab addressing is unused
     w.masks = nullptr;
     const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -864,12 +882,14 @@ focus_fused_kernel(const ffn_mlp_chain ch, const float* __restrict__ packed_w,
                           threadIdx.x, 256);
     {
         float* bl = reinterpret_cast<float*>(smem + kWavesPerBlock * kActBytesPerWave + kEncTableBytes);
-        for (int i = threadIdx.x; i < ch.bias_floats; i += 256) bl[i] = bias[i];
+        const int staged = ch.bias_floats < kBiasLdsFloats ? ch.bias_floats : kBiasLdsFloats;
+        for (int i = threadIdx.x; i < staged; i += 256) bl[i] = bias[i];
     }
     __syncthreads();
     WaveCtx w;
     int64_t stride;
     wave_setup<false>(w, smem, kSamplesPerWave, stride);
+    w.bias_glb = bias;
     w.block = 0;
     w.masks = nullptr;
     const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -925,6 +945,7 @@ mlp_backward_data_kernel(const ffn_mlp_chain ch, const float* __restrict__ packe
     WaveCtx w;
     int64_t stride;
     wave_setup<WIDE>(w, smem, n, stride);
+    w.bias_glb = nullptr;              // (a backward chain has no biases)
     if (slab_blocks > 0) { w.slab_block0 = slab_block0; w.slab_blocks = slab_blocks; }
     w.masks = reinterpret_cast<uint4*>(masks);
     w.x0 = w.x1 = w.x2 = w.v0 = w.v1 = w.v2 = 0.0f;
@@ -978,7 +999,7 @@ extern "C" int ffn_mlp_pack_jobs(const ffn_pack_job* jobs, int num_jobs, void* s
 
 static int validate_chain(const ffn_mlp_chain* ch, bool backward, bool train = false) {
     if (ch == nullptr || ch->num_steps < 1 || ch->num_steps > FFN_MAX_STEPS) return 1;
-    if (ch->bias_floats < 0 || ch->bias_floats > kBiasLdsFloats) return 1;
+    if (ch->bias_floats < 0) return 1;
     const bool wide = ch->wide != 0;
     for (int i = 0; i < ch->num_steps; ++i) {
         const ffn_step& L = ch->step[i];
@@ -987,6 +1008,9 @@ static int validate_chain(const ffn_mlp_chain* ch, bool backward, bool train = f
         if (L.act_groups < 0 || L.aux_groups < 0 || L.act_groups > (wide ? 64 : 32)) return 1;
         if ((L.act_groups & 3) || (L.aux_groups & 3) || L.act_groups + L.aux_groups == 0) return 1;
         if (!backward && L.aux_groups > 0 && (L.enc_id < 0 || L.enc_id > 1)) return 1;
+        // fused-head blocks (4 bias floats + 4 per channel) are read from the LDS copy only
+        if (!backward && L.head_off >= 0 && L.head_off + 4 + 128 * ot > kBiasLdsFloats) return 1;
+        if (!backward && (L.b_off < 0 || L.b_off + 32 * ot > ch->bias_floats)) return 1;
         if (!backward && (ch->enc[0].num_freq > 256 || ch->enc[1].num_freq > 256)) return 1;
         if (backward && L.aux_groups != 0 && L.aux_groups != 4) return 1;
         if (backward && L.aux_groups && (L.lg_n < 1 || L.lg_col < 0 || L.lg_col + L.lg_n > 4)) return 1;

@@ -142,7 +142,10 @@ class ImageDataset(RayDataset):
         # ground truth (a GPU division by a constant may differ in the last ulp)
         rgb = images[..., :3]
         if color_space == "YCrCb":          # image_dataset.py:114-115, on the u8 image
-            rgb = rgb_to_ycrcb_u8(rgb)
+            # image by image like the reference: the fixed-point conversion works in int32 with
+            # several full-size temporaries (16-20x the u8 footprint)
+            rgb = np.stack([rgb_to_ycrcb_u8(frame) for frame in rgb]) if rgb.ndim == 4 \
+                else rgb_to_ycrcb_u8(rgb)
         self.colors = torch.from_numpy(
             (rgb.astype(np.float32) / 255).reshape(-1, 3)).to(dev).contiguous()
         has_alpha = images.shape[-1] == 4

@@ -20,6 +20,7 @@ from ._lib import c_i, c_i64, c_p
 from .ops import _call, _dev
 
 MAX_STEPS = 16
+BIAS_LDS_FLOATS = 4096      # csrc/mlp.hip kBiasLdsFloats: the LDS copy of the bias buffer's head
 WGRAD_GROUPS = 256          # one persistent workgroup per CU for the LDS-staged units
 # relative cost of one 32-sample block of a unit, by the number of 128x128 quadrants it has
 # (calibrated on MI355X with FFN_UNIT_COST sweeps: a full unit is ~18k cycles per block, of which
@@ -188,15 +189,26 @@ class DenseSpec:
         self.to_logits = to_logits     # (first column, count) or None
         self.out = int(weight.shape[0])
         self.ld = int(weight.shape[1])
+        # widths the kernels run at (zero-padded to a supported tile count; MlpProgram sets them)
+        self.out_p = self.out
+        self.act_in_p = self.act_in
+
+
+def _padded_width(channels: int, wide: bool = False) -> int:
+    """Width a hidden layer of ``channels`` outputs runs at: the kernels' tile counts are 1/2/4/8
+    tiles of 32 channels (2/4/8/16 in a chain with a layer wider than 256), so any other width is
+    zero-padded to the next one -- zero rows / columns in the operand packs, zero bias, zero
+    fused-head weights; the padding's activations, dZ and gradients are exactly 0 in f32 and the
+    reducer drops them (reference: nn.Linear accepts any width, ``train_nerf.py:28-31``)."""
+    for width in ((64, 128, 256, 512) if wide else (32, 64, 128, 256)):
+        if channels <= width:
+            return width
+    raise NotImplementedError("fused MLP kernels support hidden layers of up to 512 channels "
+                              "(got %d)" % channels)
 
 
 def _tiles(channels: int, wide: bool = False) -> int:
-    tiles = (channels + 31) // 32
-    if tiles not in ((2, 4, 8, 16) if wide else (1, 2, 4, 8)):
-        raise NotImplementedError(
-            "fused MLP kernels support layer widths of 32/64/128/256 channels, or "
-            "64/128/256/512 next to a 512-wide layer (got %d)" % channels)
-    return tiles
+    return _padded_width(channels, wide) // 32
 
 
 class Workspace:
@@ -307,7 +319,17 @@ class MlpProgram:
         # kernels (64 KiB slab per pair)
         self.wide = any(sp.to_logits is None and sp.out > 256 for sp in self.layers)
         fwd.wide = 1 if self.wide else 0
-        w_off = b_off = 0
+        # any nn.Linear width is accepted: hidden layers run zero-padded to a supported tile count
+        producer = -1
+        for i, sp in enumerate(self.layers):
+            sp.act_in_p = self.layers[producer].out_p if (sp.act_in > 0 and producer >= 0) else sp.act_in
+            if sp.to_logits is None:
+                sp.out_p = _padded_width(sp.out, self.wide)
+                producer = i
+        # bias buffer = [fused-head blocks | per-step padded biases]: the kernels keep its first
+        # BIAS_LDS_FLOATS floats in LDS (every head block must be there: the epilogues read them
+        # per channel quad); a step whose bias block lies beyond reads it from global memory / L2
+        w_off = b_off = h_off = 0
         self.col_maps: List[torch.Tensor] = []
         self.step_of: List[Optional[int]] = []   # layer index -> forward step (None = fused head)
         self.fwd_shapes: Dict[int, tuple] = {}
@@ -334,15 +356,13 @@ class MlpProgram:
                 prev = j
         num_steps = 0
         for i, spec in enumerate(self.layers):
-            if spec.act_in % 32:
-                raise NotImplementedError("activation widths must be multiples of 32")
             enc = None if spec.enc_id is None else self.encodings[spec.enc_id]
             self.producer_of.append(last_producer if spec.act_in > 0 else -1)
             if spec.act_in > 0 and (last_producer < 0 or
                                     self.layers[last_producer].out != spec.act_in):
                 raise ValueError("layer %d consumes %d channels but the previous producer "
                                  "wrote a different width" % (i, spec.act_in))
-            act_groups = spec.act_in // 8
+            act_groups = spec.act_in_p // 8
             cmap = [c if c < spec.act_in else -1 for c in range(8 * act_groups)]
             if enc is not None:
                 for c in range(enc.width):
@@ -359,9 +379,9 @@ class MlpProgram:
                 P = fwd.step[self.step_of[last_producer]]
                 if P.head_off >= 0:
                     raise NotImplementedError("a layer may feed at most one logits head")
-                P.head_off = b_off
-                self.fused_heads.append((i, b_off, spec.act_in))
-                b_off += 4 + 4 * spec.act_in
+                P.head_off = h_off
+                self.fused_heads.append((i, h_off, spec.act_in))
+                h_off += 4 + 4 * spec.act_in_p
                 if last_producer not in stepped_consumers:
                     P.save_out_slot = self.slot_of[last_producer]
                 self.step_of.append(None)
@@ -374,22 +394,20 @@ class MlpProgram:
             L.act_groups = act_groups
             L.aux_groups = 0 if enc is None else enc.width // 8
             L.enc_id = 0 if spec.enc_id is None else spec.enc_id
-            L.out_tiles = _tiles(spec.out, self.wide and spec.to_logits is None)
+            L.out_tiles = spec.out_p // 32 if spec.to_logits is None else 1
             L.relu = 1 if spec.relu else 0
             L.save_in_slot = L.save_out_slot = L.mask_slot = L.save_enc_slot = L.head_off = -1
             if spec.act_in > 0:
                 L.save_in_slot = self.slot_of[last_producer]
             if spec.to_logits is None:
                 L.dst, L.out_col, L.out_n = 0, 0, 0
-                if spec.out % 32:
-                    raise NotImplementedError("hidden widths must be multiples of 32")
                 slot = len(self.slot_of)
                 self.slot_of[i] = slot
                 if spec.relu:
                     L.mask_slot = slot           # sign bits of this layer's output
-                fwd.slot_channels[slot] = spec.out
+                fwd.slot_channels[slot] = spec.out_p
                 fwd.slot_offset[slot] = slot_off
-                slot_off += spec.out
+                slot_off += spec.out_p
                 last_producer = i
             else:
                 if self.wide:
@@ -401,6 +419,12 @@ class MlpProgram:
             self.fwd_shapes[i] = (groups, L.out_tiles)
             w_off += groups * L.out_tiles * 256
             b_off += 32 * L.out_tiles
+        if h_off > BIAS_LDS_FLOATS:
+            raise NotImplementedError("fused logits heads need %d floats of LDS (limit %d)"
+                                      % (h_off, BIAS_LDS_FLOATS))
+        for k in range(num_steps):
+            fwd.step[k].b_off += h_off
+        b_off += h_off
         fwd.num_steps = num_steps
         fwd.num_slots = len(self.slot_of)
         fwd.bias_floats = b_off
@@ -423,8 +447,6 @@ class MlpProgram:
             fwd.slot_channels[slot] = self.encodings[spec.enc_id].width
             fwd.slot_offset[slot] = slot_off
             slot_off += self.encodings[spec.enc_id].width
-        if b_off > 4096:
-            raise NotImplementedError("more than 4096 bias + fused-head floats")
         self.fwd = fwd
         self.saved_channels = slot_off
         self.mask_words = 512 if self.wide else 256     # uint32 of ReLU sign bits per slot and block
@@ -456,7 +478,7 @@ class MlpProgram:
         self.fwd16 = None
         self.packed16 = None
         self._packed16_dirty = True
-        if self.wide or self.device.type != "cuda":
+        if self.wide or self.device.type != "cuda" or self.fwd.bias_floats > BIAS_LDS_FLOATS:
             return
         steps = [(i, self.fwd.step[self.step_of[i]]) for i in range(len(self.layers))
                  if self.step_of[i] is not None]
@@ -475,13 +497,14 @@ class MlpProgram:
         for i, st in steps:
             spec = self.layers[i]
             enc = None if spec.enc_id is None else self.encodings[spec.enc_id]
-            kb_act = spec.act_in // 16
+            kb_act = spec.act_in_p // 16
             kb_feat = 0 if enc is None else enc.width // 16
             cmap = []
             for g in range(kb_act):
                 for h in range(2):
                     for j in range(8):
-                        cmap.append(16 * g + (4 * h + j if j < 4 else 8 + 4 * h + (j - 4)))
+                        c = 16 * g + (4 * h + j if j < 4 else 8 + 4 * h + (j - 4))
+                        cmap.append(c if c < spec.act_in else -1)
             for g in range(kb_feat):
                 for h in range(2):
                     for j in range(8):
@@ -521,8 +544,8 @@ class MlpProgram:
             if len(hidden) > 1 or len(heads) > 1:
                 raise NotImplementedError("a layer may feed at most one hidden layer and one head")
             st = FfnStep()
-            st.out_tiles = _tiles(self.layers[j].out, self.wide)
-            st.act_groups = 0 if not hidden else self.layers[hidden[0]].out // 8
+            st.out_tiles = self.layers[j].out_p // 32
+            st.act_groups = 0 if not hidden else self.layers[hidden[0]].out_p // 8
             st.aux_groups = 4 if heads else 0
             st.relu = 0
             st.mask_slot = self.slot_of[j] if self.layers[j].relu else -1
@@ -572,12 +595,11 @@ class MlpProgram:
             heads = [c for c in consumers[j] if self.layers[c].to_logits is not None]
             if hidden:
                 c = hidden[0]
-                kb = self.layers[c].out // 16
-                if self.layers[c].out % 32:
-                    return
+                kb = self.layers[c].out_p // 16
                 # K order = the register hand-off order of the consumer's dZ
                 cmap = [16 * g + (4 * h + jj if jj < 4 else 8 + 4 * h + (jj - 4))
                         for g in range(kb) for h in range(2) for jj in range(8)]
+                cmap = [k if k < self.layers[c].out else -1 for k in cmap]
                 self.pack16_bwd_jobs.append((c, kb, torch.tensor(cmap, dtype=torch.int32, device=self.device), off))
                 off += kb * 8 * 1024
             if heads:
@@ -601,17 +623,17 @@ class MlpProgram:
             windows = []        # (slot, first quad, quads, k_base)
             if spec.act_in > 0:
                 slot = self.slot_of[self.producer_of[i]]
-                quads = spec.act_in // 4
+                quads = spec.act_in_p // 4
                 for q0 in range(0, quads, 64):
                     windows.append((slot, q0, min(64, quads - q0), 0))
             if enc is not None:
                 quads = enc.width // 4
                 for q0 in range(0, quads, 64):
                     windows.append((self.enc_slot[spec.enc_id], q0, min(64, quads - q0),
-                                    spec.act_in))
+                                    spec.act_in_p))
             if spec.to_logits is None:
                 m_slot = self.slot_of[i]
-                out_quads = spec.out // 4
+                out_quads = spec.out_p // 4
                 for m0 in range(0, out_quads, 64):
                     for wi, (ns, q0, nq, kb) in enumerate(windows):
                         self.wgrad_units.append(FfnWgradUnit(m_slot, m0, min(64, out_quads - m0),
@@ -873,6 +895,12 @@ class MlpProgram:
         n = positions.shape[0]
         logits = torch.empty((n, 4), dtype=torch.float32, device=self.device)
         acts, masks = (None, None) if saved is None else self._split_saved(saved, n)
+        if saved is not None:
+            # what `backward` must match: the f32 forward writes the tail blocks' sign masks into
+            # their own region when the launch is split (`_tail_split`), the split-bf16 kernels
+            # know one mask region only
+            split = self._tail_split(n) if precision == "f32" else None
+            self._fwd_record = (saved.data_ptr(), n, precision, split)
         if precision == "bf16x3":
             if saved is None:
                 return self.forward16(positions, views)
@@ -979,13 +1007,22 @@ class MlpProgram:
                  views: Optional[torch.Tensor], saved: torch.Tensor, grads: torch.Tensor,
                  precision: str = "f32"):
         """Fills ``grads`` (flat, num_grad_floats) from d(loss)/d(logits) (N,4) and the
-        activations ``saved`` by the matching forward call (same ``precision``; the slab formats
-        are shared, so a buffer filled by the f32 forward also serves the split-bf16 backward).
+        activations ``saved`` by the matching forward call, in the SAME ``precision`` and with the
+        same tail split: the slab formats are shared by the two modes, but an f32 forward whose
+        launch was split (``_tail_split``) leaves the tail blocks' ReLU masks in a region only the
+        f32 backward reads -- a mismatch raises instead of differentiating with stale masks.
         ``precision="bf16x3"`` (opt-in) runs the split-bf16 backward-data and weight-gradient
         kernels."""
         n = positions.shape[0]
         if n == 0:                      # an empty batch contributes no gradient
             return grads.zero_()
+        record = getattr(self, "_fwd_record", None)
+        if record is not None and record[0] == saved.data_ptr() and record[1] == n:
+            split = self._tail_split(n) if precision == "f32" else None
+            if record[2] != precision or record[3] != split:
+                raise RuntimeError("MlpProgram.backward: `saved` was filled by a %s forward (tail "
+                                   "split %s) but the backward was asked for %s (tail split %s)"
+                                   % (record[2], record[3], precision, split))
         ws = self.workspace(n)
         wgrad16 = precision == "bf16x3" and not self.wide
         ws.use_plan("bf16x3" if wgrad16 else "f32")

@@ -268,7 +268,11 @@ typedef struct ffn_mlp_chain {
     int32_t num_slots;                     /* hidden-layer slabs (= sign-mask slots);
                                               entries num_slots.. of the two arrays below
                                               describe the encoding-feature slabs        */
-    int32_t bias_floats;                   /* total padded bias floats (<= 4096)      */
+    int32_t bias_floats;                   /* floats in the bias buffer: [fused-head blocks |
+                                              per-step padded biases].  The kernels stage its
+                                              first 4096 floats in LDS; every head block must lie
+                                              inside that copy, a step bias beyond it is read
+                                              from global memory                              */
     int32_t wide;                          /* != 0: some layer is wider than 256 channels:
                                               two waves share a 32-sample block and a 64 KiB
                                               slab, out_tiles may be 16 and must be even,

@@ -47,6 +47,12 @@ def main():
     if args.mode == "dilate":
         train.mode = ffn.RayDataset.Mode.Dilate
     os.makedirs(args.results_dir, exist_ok=True)
+    if args.make_activations and rank == 0:
+        # (train_tiny_nerf.py:137-146 of the reference adds an ActivationVisualizer: a lecture
+        # visualisation of per-layer activations, outside the HIP hot path -- SURVEY section 2)
+        print("warning: --make-activations is not supported on the HIP path (the fused kernels "
+              "keep hidden activations on the CU); training continues without the activation "
+              "video", file=sys.stderr)
     caster = _cli.apply_skipping(ffn.Raycaster(_cli.apply_precision(model.to(args.device), args.precision)), args)
     caster.process_group = group      # data parallel under torch.distributed.run
     if world > 1:                     # distinct jitter streams; weights are broadcast by fit

@@ -56,6 +56,13 @@ def test_encoding_internal_order_covers_every_natural_column_once():
     lambda: ffn.MLP(3, 4, num_channels=64),
     lambda: ffn.NeRF(4, 64, 5, 6, 2, 3, [2], False),
     lambda: ffn.GaussianFourierMLP(3, 4, 10.0, num_channels=512),
+    # widths the kernels have no tile count for run zero-padded (any nn.Linear width is accepted)
+    lambda: ffn.MLP(3, 4, num_channels=96),
+    lambda: ffn.NeRF(8, 192, 9, 10, 3, 4, [4], True),
+    lambda: ffn.NeRF(8, 32, 9, 10, 3, 4, [4], True),
+    lambda: ffn.NeRF(8, 512, 9, 10, 3, 4, [4], True),
+    lambda: ffn.PositionalFourierMLP(3, 4, 5.5, num_channels=384),
+    lambda: ffn.MLP(3, 4, num_layers=2, num_channels=7),
 ])
 def test_chain_and_wgrad_plans(make):
     model = make()
@@ -146,10 +153,14 @@ def test_chain_and_wgrad_plans(make):
 def test_unsupported_shapes_raise_not_fall_back():
     with pytest.raises(NotImplementedError):
         _plan(ffn.GaussianFourierMLP(3, 4, 10.0, num_channels=1024))
-    with pytest.raises(NotImplementedError):       # biases of a 512-wide NeRF exceed the LDS copy
-        _plan(ffn.NeRF(8, 512, 9, 10, 3, 4, [4], True))
     with pytest.raises(NotImplementedError):
-        _plan(ffn.MLP(3, 4, num_channels=96))
+        _plan(ffn.NeRF(8, 513, 9, 10, 3, 4, [4], True))
+    # everything up to 512 channels plans: padded widths, biases beyond the kernels' LDS copy
+    wide = _plan(ffn.NeRF(8, 512, 9, 10, 3, 4, [4], True))
+    assert wide.fwd.bias_floats > 4096 and all(off + 4 + 4 * ch <= 4096 for _, off, ch in wide.fused_heads)
+    padded = _plan(ffn.MLP(3, 4, num_channels=96))
+    assert [sp.out_p for sp in padded.layers] == [128, 128, 128, 4]
+    assert [sp.act_in_p for sp in padded.layers] == [0, 128, 128, 128]
     model = ffn.MLP(3, 4, num_channels=32)
     with pytest.raises(RuntimeError, match="GPU"):
         model(torch.zeros(2, 3))
