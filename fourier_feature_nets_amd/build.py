@@ -30,6 +30,9 @@ SOURCES = {
     "mlp.hip": [],
     "mlp_bf16.hip": [],
     "mlp_bf16_bwd.hip": [],
+    # (two waves per SIMD: packed-f32 VALU instructions collide with the other wave's matrix
+    # instructions -- keep the compiler from re-packing the unpacked feature / split arithmetic)
+    "mlp_bf16_ws.hip": ["-fno-slp-vectorize"],
     "wgrad.hip": [],
     "wgrad_bf16.hip": [],
     "occupancy.hip": [],

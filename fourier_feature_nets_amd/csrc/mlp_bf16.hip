@@ -58,49 +58,6 @@ pack_bf16_kernel(const float* __restrict__ src, int rows, int cols, int ld,
     }
 }
 
-// ---------------------------------------------------------------------------------- helpers
-struct Enc16 {
-    const float* tab;   // LDS: rows b0 | b1 | b2 | a, kEncRowPitch floats each
-    int F, raw;
-    float scale;
-};
-
-// The 8 internal feature channels 16*G + 8*h + j (j = 0..7) of this lane's sample: frequencies
-// 8G + 4h + {0,1,2,3}, (cos, sin) interleaved; channels 2F..2F+2 are the raw inputs.
-template <bool TRIG_ONLY>
-__device__ __forceinline__ void features16(const Enc16& enc, int G, int h, float x0, float x1,
-                                           float x2, float (&v)[8]) {
-    const int k0 = 8 * G + 4 * h;
-    const int kk = k0 < kEncRowPitch - 4 ? k0 : kEncRowPitch - 4;
-    const f32x4 b0 = *reinterpret_cast<const f32x4*>(enc.tab + kk);
-    const f32x4 b1 = *reinterpret_cast<const f32x4*>(enc.tab + kEncRowPitch + kk);
-    const f32x4 b2 = *reinterpret_cast<const f32x4*>(enc.tab + 2 * kEncRowPitch + kk);
-    const f32x4 amp = *reinterpret_cast<const f32x4*>(enc.tab + 3 * kEncRowPitch + kk);
-    const f32x4 s0 = (f32x4)(enc.scale * x0), s1 = (f32x4)(enc.scale * x1), s2 = (f32x4)(enc.scale * x2);
-    // same operation order as the f32 kernel: mul, fma, fma
-    f32x4 ang = b0 * s0;
-    ang = __builtin_elementwise_fma(s1, b1, ang);
-    ang = __builtin_elementwise_fma(s2, b2, ang);
-    f32x4 sn, cs;
-    fast_sincos_n<f32x4, 4>(ang, sn, cs);
-    const f32x4 c = amp * cs, s = amp * sn;
-    if (TRIG_ONLY) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { v[2 * i] = c[i]; v[2 * i + 1] = s[i]; }
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int k = k0 + i;
-        const int off = 2 * (k - enc.F);
-        const float raw_even = (enc.raw && off == 0) ? x0 : ((enc.raw && off == 2) ? x2 : 0.0f);
-        const float raw_odd = (enc.raw && off == 0) ? x1 : 0.0f;
-        const bool trig = k < enc.F;
-        v[2 * i] = trig ? c[i] : raw_even;
-        v[2 * i + 1] = trig ? s[i] : raw_odd;
-    }
-}
-
 struct Ctx16 : Ring16 {
     int h, s;
     float x0, x1, x2, v0, v1, v2;
@@ -346,15 +303,30 @@ static int launch_forward16(const char* what, const ffn_mlp_chain* chain, const 
     if (n == 0) return 0;
     if (n < 0 || chain == nullptr || chain->num_steps < 1 || chain->num_steps > FFN_MAX_STEPS)
         return fail_arg(what);
-    if (chain->wide || chain->bias_floats < 0 || chain->bias_floats > kBiasFloats16) return fail_arg(what);
+    const bool wide = chain->wide != 0;
+    if (chain->bias_floats < 0) return fail_arg(what);
+    int kb_feat = 0, kb_all = 0;
     for (int i = 0; i < chain->num_steps; ++i) {
         const ffn_step& L = chain->step[i];
         const int ot = L.out_tiles;
         // (slab-destination steps with fused heads only)
-        if (!(ot == 1 || ot == 2 || ot == 4 || ot == 8) || L.dst != 0 || (L.act_groups & 3) ||
-            (L.aux_groups & 3) || L.act_groups < 0 || L.act_groups > 32 || L.aux_groups < 0 ||
-            L.act_groups + L.aux_groups == 0 || (L.aux_groups > 0 && (L.enc_id < 0 || L.enc_id > 1)))
+        const bool tiles_ok = wide ? (ot == 2 || ot == 4 || ot == 8 || ot == 16) : (ot == 1 || ot == 2 || ot == 4 || ot == 8);
+        if (!tiles_ok || L.dst != 0 || (L.act_groups & 3) ||
+            (L.aux_groups & 3) || L.act_groups < 0 || L.act_groups > (wide ? 64 : 32) || L.aux_groups < 0 ||
+            L.act_groups + L.aux_groups == 0 || (L.aux_groups > 0 && (L.enc_id < 0 || L.enc_id > 1)) ||
+            (L.head_off >= 0 && L.head_off + 4 + 128 * ot > 4096))
             return fail_arg(what);
+        kb_feat += L.aux_groups >> 1;
+        kb_all += (L.act_groups + L.aux_groups) >> 1;
+    }
+    // Two organisations of the same arithmetic (bf16_ring.h): 512-wide chains exist only in the
+    // two-waves-per-SIMD one; of the narrow chains it is the faster one where the encoding is a
+    // large part of the work (tiny NeRF: -5 %), the ring kernels elsewhere (full NeRF: +6 %).
+    // FFN_BF16_KERNELS=ring|ws overrides (the ring kernels need all biases in their LDS copy).
+    const bool ring_ok = !wide && chain->bias_floats <= kBiasFloats16;
+    if (!ring_ok || prefer_ws_kernels(4 * kb_feat >= kb_all)) {
+        launch_forward16_ws(chain, packed_w, bias, positions, views, n, logits, saved, masks, stream);
+        return check_launch(what);
     }
     const int64_t groups = ((n + 31) / 32 + 3) / 4;
     int cus = 256;

@@ -153,15 +153,23 @@ extern "C" int ffn_mlp_backward_data_bf16x3(const ffn_mlp_chain* chain, const ui
                                             float* dz, void* stream) {
     if (n == 0) return 0;
     const char* what = "ffn_mlp_backward_data_bf16x3: unsupported chain or size";
-    if (n < 0 || chain == nullptr || chain->num_steps < 1 || chain->num_steps > FFN_MAX_STEPS || chain->wide)
+    if (n < 0 || chain == nullptr || chain->num_steps < 1 || chain->num_steps > FFN_MAX_STEPS)
         return fail_arg(what);
+    const bool wide = chain->wide != 0;
     for (int i = 0; i < chain->num_steps; ++i) {
         const ffn_step& L = chain->step[i];
         const int ot = L.out_tiles;
-        if (!(ot == 1 || ot == 2 || ot == 4 || ot == 8) || (L.act_groups & 3) || L.act_groups < 0 ||
-            L.act_groups > 32 || (L.act_groups == 0 && L.aux_groups == 0) ||
+        const bool tiles_ok = wide ? (ot == 2 || ot == 4 || ot == 8 || ot == 16) : (ot == 1 || ot == 2 || ot == 4 || ot == 8);
+        if (!tiles_ok || (L.act_groups & 3) || L.act_groups < 0 ||
+            L.act_groups > (wide ? 64 : 32) || (L.act_groups == 0 && L.aux_groups == 0) ||
             (L.aux_groups > 0 && (L.lg_col < 0 || L.lg_n < 1 || L.lg_col + L.lg_n > 4)))
             return fail_arg(what);
+    }
+    // (the backward chain has no encoding work: the ring kernels unless told otherwise; 512-wide
+    // chains exist only in the two-waves-per-SIMD organisation)
+    if (wide || prefer_ws_kernels(false)) {
+        launch_backward16_ws(chain, packed_wt, d_logits, n, masks, dz, stream);
+        return check_launch(what);
     }
     const int64_t groups = ((n + 31) / 32 + 3) / 4;
     int cus = 256;

@@ -471,14 +471,16 @@ class MlpProgram:
             self.fwd_pair.wide = self.bwd_pair.wide = 1
 
     def _build_forward16(self):
-        """Chain + operand buffer of the OPT-IN split-bf16 inference kernel (mlp_bf16.hip): the
-        forward chain with its weight offsets pointing into a bf16 (hi, lo) operand buffer whose
-        K order is the register hand-off order of that kernel.  ``self.fwd16`` stays None for
-        chains it does not cover (512-wide layers, MFMA logits steps)."""
+        """Chain + operand buffer of the OPT-IN split-bf16 kernels (mlp_bf16.hip, mlp_bf16_ws.hip):
+        the forward chain with its weight offsets pointing into a bf16 (hi, lo) operand buffer
+        whose K order is the register hand-off order of those kernels.  512-wide chains pack 16
+        output tiles per K block (two-waves-per-SIMD kernels only).  ``self.fwd16`` stays None for
+        chains with MFMA logits steps."""
         self.fwd16 = None
         self.packed16 = None
         self._packed16_dirty = True
-        if self.wide or self.device.type != "cuda" or self.fwd.bias_floats > BIAS_LDS_FLOATS:
+        self.tiles16 = 16 if self.wide else 8
+        if self.device.type != "cuda":
             return
         steps = [(i, self.fwd.step[self.step_of[i]]) for i in range(len(self.layers))
                  if self.step_of[i] is not None]
@@ -516,7 +518,7 @@ class MlpProgram:
             # some of them on consumption by the next step)
             chain.step[self.step_of[i]].out_slot = self.slot_of.get(i, -1)
             self.pack16_jobs.append((i, kblocks, torch.tensor(cmap, dtype=torch.int32, device=self.device), off))
-            off += kblocks * 8 * 1024            # 8 tiles x (hi, lo) x 64 lanes x 8 bf16
+            off += kblocks * self.tiles16 * 1024     # tiles x (hi, lo) x 64 lanes x 8 bf16
         self.fwd16 = chain
         self.packed16 = torch.zeros((max(off, 1),), dtype=torch.int16, device=self.device)
 
@@ -601,14 +603,14 @@ class MlpProgram:
                         for g in range(kb) for h in range(2) for jj in range(8)]
                 cmap = [k if k < self.layers[c].out else -1 for k in cmap]
                 self.pack16_bwd_jobs.append((c, kb, torch.tensor(cmap, dtype=torch.int32, device=self.device), off))
-                off += kb * 8 * 1024
+                off += kb * self.tiles16 * 1024
             if heads:
                 c = heads[0]
                 rows = self.layers[c].to_logits[1]
                 cmap = [(jj if (g == 0 and h == 0 and jj < rows) else -1)
                         for g in range(2) for h in range(2) for jj in range(8)]
                 self.pack16_bwd_jobs.append((c, 2, torch.tensor(cmap, dtype=torch.int32, device=self.device), off))
-                off += 2 * 8 * 1024
+                off += 2 * self.tiles16 * 1024
         self.bwd16 = chain
         self.packed16_bwd = torch.zeros((max(off, 1),), dtype=torch.int16, device=self.device)
 
@@ -749,15 +751,15 @@ class MlpProgram:
         """(hi, lo) bf16 operand copies of the current weights for the split-bf16 kernel."""
         for (i, kblocks, cmap, off) in self.pack16_jobs:
             w = self.layers[i].weight.detach()
-            dst = self.packed16[off:off + kblocks * 8 * 1024]
+            dst = self.packed16[off:off + kblocks * self.tiles16 * 1024]
             _call("ffn_mlp_pack_bf16", _dev(w), c_i(w.shape[0]), c_i(w.shape[1]), c_i(w.stride(0)),
-                  _dev(cmap, torch.int32), c_i(kblocks), c_i(8), c_i(0), _dev(dst, torch.int16))
+                  _dev(cmap, torch.int32), c_i(kblocks), c_i(self.tiles16), c_i(0), _dev(dst, torch.int16))
         for (c, kblocks, cmap, off) in (self.pack16_bwd_jobs if self.bwd16 is not None else []):
             w = self.layers[c].weight.detach()
-            dst = self.packed16_bwd[off:off + kblocks * 8 * 1024]
+            dst = self.packed16_bwd[off:off + kblocks * self.tiles16 * 1024]
             # operand rows = the consumer's input channels (its activation part), K = its rows
             _call("ffn_mlp_pack_bf16", _dev(w), c_i(w.shape[0]), c_i(self.layers[c].act_in),
-                  c_i(w.stride(0)), _dev(cmap, torch.int32), c_i(kblocks), c_i(8), c_i(1),
+                  c_i(w.stride(0)), _dev(cmap, torch.int32), c_i(kblocks), c_i(self.tiles16), c_i(1),
                   _dev(dst, torch.int16))
         self._packed16_dirty = False
 
@@ -765,8 +767,7 @@ class MlpProgram:
         """Inference in the opt-in split-bf16 mode (3 bf16 matrix products per f32 product):
         positions (N,3) [views (N,3)] -> raw logits (N,4)."""
         if self.fwd16 is None:
-            raise NotImplementedError("the split-bf16 kernel covers chains of <= 256 channels whose "
-                                      "logits heads are fused")
+            raise NotImplementedError("the split-bf16 kernels cover chains whose logits heads are fused")
         if self._packed16_dirty:
             self.pack16()
         n = positions.shape[0]
@@ -905,8 +906,7 @@ class MlpProgram:
             if saved is None:
                 return self.forward16(positions, views)
             if self.fwd16 is None:
-                raise NotImplementedError("the split-bf16 kernel covers chains of <= 256 channels "
-                                          "whose logits heads are fused")
+                raise NotImplementedError("the split-bf16 kernels cover chains whose logits heads are fused")
             if self._packed16_dirty:
                 self.pack16()
             _call("ffn_mlp_forward_bf16x3_train", ctypes.byref(self.fwd16),

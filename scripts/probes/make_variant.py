@@ -25,7 +25,10 @@ def main(name, subs_path, source="mlp.hip"):
     with open(src, "w") as f:
         f.write(text)
     obj = src.replace(".hip", ".o")
+    sys.path.insert(0, ROOT)
+    from fourier_feature_nets_amd.build import SOURCES          # the product's per-file flags
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"), "-I", CSRC]
+    flags += SOURCES.get(source, [])
     subprocess.run(["/opt/rocm/bin/hipcc"] + flags + ["-c", src, "-o", obj], check=True)
     others = [os.path.join(CSRC, "build", o) for o in os.listdir(os.path.join(CSRC, "build"))
               if o.endswith(".o") and o != source.replace(".hip", ".o")]
