@@ -591,7 +591,11 @@ def config5_leg(device, bounds, rays_per_step=32768, samples=128, cameras=25, si
     out = {"workload": "trex_800-shaped 512-wide Gaussian-feature train step: GaussianFourierMLP(3,4,"
                        "10.0,num_channels=512), %d cams x %dx%d, %d samples/ray, %d rays/step, "
                        "exact-f32 MFMA (wide kernels)" % (cameras, size, size, samples, rays_per_step)}
-    for label, occ in (("full", None), ("with_occupancy_grid", grid)):
+    for label, occ in (("full", None), ("with_occupancy_grid", grid), ("split_bf16_training", None)):
+        # (third entry: the OPT-IN split-bf16 training kernels on the same 512-wide model --
+        # two-waves-per-SIMD chain kernels with two output tiles per wave, mlp_bf16_ws.hip; the
+        # weight gradients of a 512-wide model stay on the exact-f32 kernel)
+        model.train_precision = "bf16x3" if label == "split_bf16_training" else "f32"
         engine = ffn.TrainEngine(model, 0.0, None)
         engine.occupancy = occ
         timer = KernelTimer()
@@ -602,7 +606,7 @@ def config5_leg(device, bounds, rays_per_step=32768, samples=128, cameras=25, si
 
             run_step(0)
             torch.cuda.synchronize()
-            timer.on = occ is None
+            timer.on = label == "full"
             t0 = time.perf_counter()
             for step in range(1, 1 + steps):
                 run_step(step)
@@ -612,7 +616,12 @@ def config5_leg(device, bounds, rays_per_step=32768, samples=128, cameras=25, si
         finally:
             timer.close()
         entry = {"step_ms": round(step_ms, 3), "rays_per_s": round(rays_per_step / (step_ms * 1e-3), 1)}
-        if occ is None:
+        if label == "split_bf16_training":
+            entry["label"] = ("opt-in split-bf16 forward / backward-data kernels (3 bf16 matrix products "
+                              "per f32 product): not the exact-f32 parity mode")
+            entry["speedup_vs_exact_f32"] = round(out["full"]["step_ms"] / step_ms, 3)
+            model.train_precision = "f32"
+        elif occ is None:
             entry["kernels"] = timer.summary(prog, rays_per_step * samples)
         else:
             entry["evaluated_sample_fraction"] = round(engine.last_evaluated_fraction, 4)

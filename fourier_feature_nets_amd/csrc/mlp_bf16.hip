@@ -320,11 +320,13 @@ static int launch_forward16(const char* what, const ffn_mlp_chain* chain, const 
         kb_all += (L.act_groups + L.aux_groups) >> 1;
     }
     // Two organisations of the same arithmetic (bf16_ring.h): 512-wide chains exist only in the
-    // two-waves-per-SIMD one; of the narrow chains it is the faster one where the encoding is a
-    // large part of the work (tiny NeRF: -5 %), the ring kernels elsewhere (full NeRF: +6 %).
+    // two-waves-per-SIMD one.  Of the narrow chains it is the faster one for the training forward
+    // (tiny NeRF -7 %, full NeRF -3 %) and for inference where the encoding is a large part of the
+    // work (tiny NeRF -4 %); the ring kernels keep the inference of encoding-light chains (full
+    // NeRF: +6 % otherwise).  Measured on one box, interleaved (scripts/microbench_bf16_chain.py).
     // FFN_BF16_KERNELS=ring|ws overrides (the ring kernels need all biases in their LDS copy).
     const bool ring_ok = !wide && chain->bias_floats <= kBiasFloats16;
-    if (!ring_ok || prefer_ws_kernels(4 * kb_feat >= kb_all)) {
+    if (!ring_ok || prefer_ws_kernels(saved != nullptr || 4 * kb_feat >= kb_all)) {
         launch_forward16_ws(chain, packed_w, bias, positions, views, n, logits, saved, masks, stream);
         return check_launch(what);
     }

@@ -30,29 +30,42 @@
 
 namespace ffn {
 
-constexpr int kWsThreads = 512;
-constexpr int kWsWaves = 8;
 constexpr int kWsXBytes = 128 * 1024;
 constexpr int kWsBiasFloats = 4096;
 constexpr size_t kWsLdsBytes = (size_t)kWsXBytes + kEncTableBytes + kWsBiasFloats * 4;
 
-template <int TPW>
+// Geometry of a workgroup.  TPW_ tiles per wave (2 for 512-wide chains), SPLIT_ waves per output
+// tile: with SPLIT_ = 2 the workgroup is SIXTEEN waves (four per SIMD, <= 128 registers each) and
+// the two waves of a tile each take half of the pass's blocks -- twice the vector-instruction
+// issue rate per SIMD and four instruction streams to fill the matrix pipe from; the duplicate
+// weight requests of the two waves of a tile are served by the CU's L1.
+template <int TPW_, int SPLIT_>
 struct WsShape {
-    static constexpr int NB = 4 / TPW;            // 32-sample blocks per pass
-    static constexpr int TILES = 8 * TPW;         // output tiles of the operand packs
-    static constexpr int KBMAX = 16 * TPW;        // K blocks of one block's X image
+    static constexpr int TPW = TPW_;
+    static constexpr int SPLIT = SPLIT_;
+    static constexpr int WAVES = 8 * SPLIT_;
+    static constexpr int THREADS = 64 * WAVES;
+    static constexpr int NB = 4 / TPW_;           // 32-sample blocks per pass
+    static constexpr int NBW = NB / SPLIT_;       // ... per wave
+    static constexpr int TILES = 8 * TPW_;        // output tiles of the operand packs
+    static constexpr int KBMAX = 16 * TPW_;       // K blocks of one block's X image
     static constexpr int kKbVecs = NB * 128;      // float4 per K block of X: blocks x (hi, lo) x 64 lanes
+    // two alternating sets of hi operands (see ws_kblock)?  Not at 128 registers per wave: there
+    // the hi operands are refilled late, and the other three waves of the SIMD cover the round trip
+    static constexpr bool XH = SPLIT_ == 1;
 };
 
 // float4 index of (K block G, sample block b, part, lane 0) in the X image: K-block major, so that
 // the reads of one K block (every block, both parts) are ONE base register + immediate offsets
-template <int TPW>
+template <class S>
 __device__ __forceinline__ constexpr int ws_x_index(int G, int b, int part) {
-    return (G * WsShape<TPW>::NB + b) * 128 + part * 64;
+    return (G * S::NB + b) * 128 + part * 64;
 }
 
 struct WsWave {
     int lane, h, s, wave;
+    int tile;                  // wave % 8: the output tile(s) tile + 8 t of this wave
+    int b0;                    // first block (inside the pass) of this wave
     f32x4* xbuf;               // LDS: the B-operand images
     const f32x4* gw;           // the chain's operand packs (uniform)
     int total_chunks;          // pairs of K blocks in the whole chain
@@ -70,159 +83,187 @@ __device__ __forceinline__ void ws_barrier() {
 
 // the wave's slice of chunk c: K blocks 2c, 2c+1, its TPW tiles, (hi, lo): 1 KiB per load
 // (K block k of chunk c; ws_load_chunk = both)
-template <int TPW>
-__device__ __forceinline__ void ws_load_kblock(const WsWave& w, bf16x8 (&dst)[TPW][2], int c, int k) {
-    constexpr int TILES = WsShape<TPW>::TILES;
+template <class S>
+__device__ __forceinline__ void ws_load_kblock(const WsWave& w, bf16x8 (&dst)[S::TPW][2], int c, int k) {
+    constexpr int TILES = S::TILES, TPW = S::TPW;
     typedef const f32x4 __attribute__((address_space(1)))* gptr;
     // wave-uniform bases (one per K block and tile: the strides exceed the immediate offset) kept
     // in SGPRs; the lanes add 16 B each -- scalar-base addressing, no per-lane 64-bit pointers
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
-        gptr base = (gptr)(w.gw + ((int64_t)c * 2 + k) * (TILES * 128) + (w.wave + 8 * t) * 128);
+        gptr base = (gptr)(w.gw + ((int64_t)c * 2 + k) * (TILES * 128) + (w.tile + 8 * t) * 128);
         asm volatile("" : "+s"(base));
 #pragma unroll
         for (int part = 0; part < 2; ++part)
             dst[t][part] = __builtin_bit_cast(bf16x8, base[part * 64 + w.lane]);
     }
 }
-template <int TPW>
-__device__ __forceinline__ void ws_load_chunk(const WsWave& w, bf16x8 (&dst)[2][TPW][2], int c) {
-    ws_load_kblock<TPW>(w, dst[0], c, 0);
-    ws_load_kblock<TPW>(w, dst[1], c, 1);
+template <class S>
+__device__ __forceinline__ void ws_load_chunk(const WsWave& w, bf16x8 (&dst)[2][S::TPW][2], int c) {
+    ws_load_kblock<S>(w, dst[0], c, 0);
+    ws_load_kblock<S>(w, dst[1], c, 1);
 }
 
-// one part (0 = hi, 1 = lo) of the B operands of X K block G, every block of the pass
-template <int TPW>
-__device__ __forceinline__ void ws_read_x(const WsWave& w, bf16x8 (&x)[4 / TPW][2], int G, int part) {
-    constexpr int NB = WsShape<TPW>::NB;
-    const f32x4* p = w.xbuf + G * WsShape<TPW>::kKbVecs + part * 64 + w.lane;
+// one part (0 = hi, 1 = lo) of the B operands of X K block G, every block of this wave
+template <class S>
+__device__ __forceinline__ void ws_read_x(const WsWave& w, bf16x8 (&x)[S::NBW][2], int G, int part) {
+    constexpr int NBW = S::NBW;
+    const f32x4* p = w.xbuf + G * S::kKbVecs + w.b0 * 128 + part * 64 + w.lane;
 #pragma unroll
-    for (int b = 0; b < NB; ++b) x[b][part] = __builtin_bit_cast(bf16x8, p[b * 128]);
+    for (int b = 0; b < NBW; ++b) x[b][part] = __builtin_bit_cast(bf16x8, p[b * 128]);
 }
 
 // one product of a K block for every (tile, block): weight part WP times operand part XP;
 // consecutive matrix instructions hit different accumulators
-template <int TPW, int NT, int WP, int XP>
-__device__ __forceinline__ void ws_mma(f32x16 (&acc)[TPW][4 / TPW], const bf16x8 (&wk)[TPW][2],
-                                       const bf16x8 (&x)[4 / TPW][2]) {
-    constexpr int NB = WsShape<TPW>::NB;
+template <class S, int NT, int WP, int XP>
+__device__ __forceinline__ void ws_mma(f32x16 (&acc)[S::TPW][S::NBW], const bf16x8 (&wk)[S::TPW][2],
+                                       const bf16x8 (&x)[S::NBW][2]) {
+    constexpr int NBW = S::NBW;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int b = 0; b < NB; ++b)
+        for (int b = 0; b < NBW; ++b)
             acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wk[t][WP], x[b][XP], acc[t][b], 0, 0, 0);
 }
 
-// One K block against the operands in x, which are REPLACED by those of K block `next` as they
-// become free: per accumulator the products run w_hi x_lo, w_lo x_hi, w_hi x_hi (the ring
-// kernels' order), so the lo parts are free after the first third of the matrix instructions --
-// their successors are read right there -- and the hi parts after the last third; the next K
-// block consumes lo first, so the late hi reads still have a third of a K block (>= 128 cycles)
-// to land.  One operand set instead of two: 32 registers fewer per wave.
-// Issue order pinned: a ds_read behind the matrix instruction that frees its register, the NVM
-// weight requests of the chunk after next behind the middle third.
-template <int TPW, int NT, int NVM>
-__device__ __forceinline__ void ws_kblock(const WsWave& w, f32x16 (&acc)[TPW][4 / TPW],
-                                          const bf16x8 (&wk)[TPW][2], bf16x8 (&x)[4 / TPW][2], int next) {
-    ws_mma<TPW, NT, 0, 1>(acc, wk, x);
-    ws_read_x<TPW>(w, x, next, 1);
-    ws_mma<TPW, NT, 1, 0>(acc, wk, x);
-    ws_mma<TPW, NT, 0, 0>(acc, wk, x);
-    ws_read_x<TPW>(w, x, next, 0);
+// One K block.  Per accumulator the products run w_hi x_lo, w_lo x_hi, w_hi x_hi (the ring
+// kernels' order).  The lo operands x[b][1] are free after the first third of the matrix
+// instructions and are REPLACED right there by those of K block `next` (consumed two thirds of a
+// K block later); the hi operands are needed until the last matrix instruction, so they alternate
+// between two sets -- K block parity HB reads hi from (HB ? xh : x[b][0]) and fills the other set
+// for `next` early -- a late refill would leave a third of a K block (128 cycles) for an LDS
+// round trip.  48 operand registers instead of 64.
+// Issue order pinned: a ds_read behind each matrix instruction of the first third and of the
+// second third, the NVM weight requests behind the last third.
+template <class S, int NT, int HB>
+__device__ __forceinline__ void ws_kblock(const WsWave& w, f32x16 (&acc)[S::TPW][S::NBW],
+                                          const bf16x8 (&wk)[S::TPW][2], bf16x8 (&x)[S::NBW][2],
+                                          bf16x8 (&xh)[S::NBW], int next) {
+    constexpr int NBW = S::NBW;
+    const f32x4* p = w.xbuf + next * S::kKbVecs + w.b0 * 128 + w.lane;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int b = 0; b < NBW; ++b)
+            acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wk[t][0], x[b][1], acc[t][b], 0, 0, 0);
+#pragma unroll
+    for (int b = 0; b < NBW; ++b) x[b][1] = __builtin_bit_cast(bf16x8, p[b * 128 + 64]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int b = 0; b < NBW; ++b)
+            acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wk[t][1], (S::XH && HB) ? xh[b] : x[b][0], acc[t][b], 0, 0, 0);
+    if (S::XH) {
+#pragma unroll
+        for (int b = 0; b < NBW; ++b) {
+            if (HB) x[b][0] = __builtin_bit_cast(bf16x8, p[b * 128]);
+            else xh[b] = __builtin_bit_cast(bf16x8, p[b * 128]);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int b = 0; b < NBW; ++b)
+            acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wk[t][0], (S::XH && HB) ? xh[b] : x[b][0], acc[t][b], 0, 0, 0);
+    if (!S::XH) {
+#pragma unroll
+        for (int b = 0; b < NBW; ++b) x[b][0] = __builtin_bit_cast(bf16x8, p[b * 128]);
+    }
 }
 
-template <int TPW, int NT, int NVM>
+template <class S, int NT, int NVM>
 __device__ __forceinline__ void ws_pin_kblock() {
-    constexpr int NB = WsShape<TPW>::NB;
-    constexpr int third = NT * NB;
+    constexpr int NBW = S::NBW;
+    constexpr int third = NT * NBW;
 #pragma unroll
     for (int i = 0; i < third; ++i) {              // w_hi x_lo: block b's lo operand is free after
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // the last tile's instruction on it
-        if (i >= third - NB) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if (i >= third - NBW) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     }
 #pragma unroll
-    for (int i = 0; i < third; ++i) {              // w_lo x_hi, with the weight requests behind
+    for (int i = 0; i < third; ++i) {              // w_lo x_hi, the other hi set being refilled
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (S::XH && i >= third - NBW) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < third; ++i) {              // w_hi x_hi, with the weight requests behind
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (!S::XH && i >= third - NBW) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             if ((NVM * (i + 1)) / third - (NVM * i) / third > k) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         }
     }
-#pragma unroll
-    for (int i = 0; i < third; ++i) {              // w_hi x_hi
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if (i >= third - NB) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    }
 }
 
 // chunk in weight buffer P: K blocks g, g + 1 of the X image (operands of g already in x)
-template <int TPW, int NT, int P>
-__device__ __forceinline__ void ws_chunk(WsWave& w, f32x16 (&acc)[TPW][4 / TPW],
-                                         bf16x8 (&wreg)[2][2][TPW][2], bf16x8 (&x)[4 / TPW][2],
-                                         int g, int g_last) {      // (X K-block indices)
+template <class S, int NT, int P>
+__device__ __forceinline__ void ws_chunk(WsWave& w, f32x16 (&acc)[S::TPW][S::NBW],
+                                         bf16x8 (&wreg)[2][2][S::TPW][2], bf16x8 (&x)[S::NBW][2],
+                                         bf16x8 (&xh)[S::NBW], int g, int g_last) {      // (X K-block indices)
     int c2 = w.cpos + 2;                                   // (uniform; branch-free: the chunk stays
     c2 -= c2 >= w.total_chunks ? w.total_chunks : 0;       // one basic block whose issue order is
     c2 -= c2 >= w.total_chunks ? w.total_chunks : 0;       // pinned; twice for one-chunk toy chains)
     // the registers of a K block's weights are refilled (chunk after next, same buffer) as soon as
     // its matrix instructions have issued: every request has a chunk and a half -- 36 matrix
     // instructions of this wave, >= 1.1k cycles -- to come back from L2
-    ws_kblock<TPW, NT, 0>(w, acc, wreg[P][0], x, g + 1);
-    ws_load_kblock<TPW>(w, wreg[P][0], c2, 0);
+    ws_kblock<S, NT, 0>(w, acc, wreg[P][0], x, xh, g + 1);
+    ws_load_kblock<S>(w, wreg[P][0], c2, 0);
     const int nxt = g + 2 <= g_last ? g + 2 : g_last;     // (the last chunk re-reads, never consumed)
-    ws_kblock<TPW, NT, 2 * TPW>(w, acc, wreg[P][1], x, nxt);
-    ws_load_kblock<TPW>(w, wreg[P][1], c2, 1);
+    ws_kblock<S, NT, 1>(w, acc, wreg[P][1], x, xh, nxt);
+    ws_load_kblock<S>(w, wreg[P][1], c2, 1);
     w.cpos = w.cpos + 1 < w.total_chunks ? w.cpos + 1 : 0;
     if (NT > 0) {
         // (a K block's pattern carries the requests issued BEHIND THE PREVIOUS K block, whose
         // registers were free from its last matrix instruction on)
-        ws_pin_kblock<TPW, NT, 0>();
-        ws_pin_kblock<TPW, NT, 2 * TPW>();
+        ws_pin_kblock<S, NT, 0>();
+        ws_pin_kblock<S, NT, 2 * S::TPW>();
     }
 }
 
 // `count` K blocks (even) of the X image, from its K block g0.  Returns true when the segment had
 // an odd number of chunks: the two weight buffers then have to trade places before the next chunk.
-template <int TPW, int NT>
-__device__ __forceinline__ bool ws_segment(WsWave& w, f32x16 (&acc)[TPW][4 / TPW],
-                                           bf16x8 (&wreg)[2][2][TPW][2], bf16x8 (&xb)[4 / TPW][2],
-                                           int count, int g0 = 0) {
+template <class S, int NT>
+__device__ __forceinline__ bool ws_segment(WsWave& w, f32x16 (&acc)[S::TPW][S::NBW],
+                                           bf16x8 (&wreg)[2][2][S::TPW][2], bf16x8 (&xb)[S::NBW][2],
+                                           bf16x8 (&xh)[S::NBW], int count, int g0 = 0) {
     if (NT == 0) {                  // a wave without a tile in this step only keeps count
         w.cpos = (w.cpos + (count >> 1)) % w.total_chunks;
         w.stale = true;
         return false;
     }
     if (w.stale) {
-        ws_load_chunk<TPW>(w, wreg[0], w.cpos);
-        ws_load_chunk<TPW>(w, wreg[1], w.cpos + 1 < w.total_chunks ? w.cpos + 1 : 0);
+        ws_load_chunk<S>(w, wreg[0], w.cpos);
+        ws_load_chunk<S>(w, wreg[1], w.cpos + 1 < w.total_chunks ? w.cpos + 1 : 0);
         w.stale = false;
         // "Use" the last request here: the compiler then waits for these eight loads on THIS
         // (rare) path.  Otherwise its wait-count analysis merges this state -- every weight
         // register pending, the newest last -- into the loop head, and the steady state of the K
         // loop waits with vmcnt(0) for requests it issued a few instructions earlier.
-        asm volatile("" ::"v"(wreg[1][1][TPW - 1][1]));
+        asm volatile("" ::"v"(wreg[1][1][S::TPW - 1][1]));
     }
-    ws_read_x<TPW>(w, xb, g0, 1);
-    ws_read_x<TPW>(w, xb, g0, 0);
+    ws_read_x<S>(w, xb, g0, 1);
+    ws_read_x<S>(w, xb, g0, 0);
     // (pairs of chunks in ONE basic block per trip, the odd chunk outside the loop: with a
     // conditional second chunk inside it, hipcc builds a loop in which chunk<1> can follow
     // chunk<1>, and its wait-count analysis then makes every weight register wait for the four
     // newest requests -- the ones issued a few instructions earlier)
     int g = 0;
     for (; g + 4 <= count; g += 4) {
-        ws_chunk<TPW, NT, 0>(w, acc, wreg, xb, g0 + g, g0 + count - 1);
-        ws_chunk<TPW, NT, 1>(w, acc, wreg, xb, g0 + g + 2, g0 + count - 1);
+        ws_chunk<S, NT, 0>(w, acc, wreg, xb, xh, g0 + g, g0 + count - 1);
+        ws_chunk<S, NT, 1>(w, acc, wreg, xb, xh, g0 + g + 2, g0 + count - 1);
     }
     const bool odd = g < count;
-    if (odd) ws_chunk<TPW, NT, 0>(w, acc, wreg, xb, g0 + g, g0 + count - 1);
+    if (odd) ws_chunk<S, NT, 0>(w, acc, wreg, xb, xh, g0 + g, g0 + count - 1);
     return odd;
 }
 
-template <int TPW>
-__device__ __forceinline__ void ws_swap(bf16x8 (&wreg)[2][2][TPW][2]) {
+template <class S>
+__device__ __forceinline__ void ws_swap(bf16x8 (&wreg)[2][2][S::TPW][2]) {
 #pragma unroll
     for (int k = 0; k < 2; ++k)
 #pragma unroll
-        for (int t = 0; t < TPW; ++t)
+        for (int t = 0; t < S::TPW; ++t)
 #pragma unroll
             for (int part = 0; part < 2; ++part) {
                 const bf16x8 tmp = wreg[0][k][t][part];
@@ -239,70 +280,73 @@ __device__ __forceinline__ void ws_swap(bf16x8 (&wreg)[2][2][TPW][2]) {
 __device__ __forceinline__ int ws_mask_byte(int p, int per) {
     return per == 1 ? 0 : 4 * (p >> 1) + ((p & 1) ? 0 : 2);
 }
-template <int TPW>
+template <class S>
 __device__ __forceinline__ int64_t ws_mask_at(int slot, int64_t num_blocks, int64_t block, int lane, int o, int ot) {
+    constexpr int TPW = S::TPW;
     const int per = TPW == 1 ? ot : ot >> 1;          // tiles per record (a power of two)
     const int hf = TPW == 1 ? 0 : (o >= per ? 1 : 0);
     const int p = o - hf * per;
     return ((((int64_t)slot * num_blocks + block) * TPW + hf) * 64 + lane) * 16 + ws_mask_byte(p, per);
 }
-// the half-word slot (record t, position wave) this wave zero-fills when no tile of the step uses
-// it, so that whole records are defined like the ring / f32 kernels' (-1: the slot is in use)
-template <int TPW>
+// the half-word slot (record t, position `tile`) the wave of that tile zero-fills when no tile of the
+// step uses it, so that whole records are defined like the ring / f32 kernels' (-1: in use)
+template <class S>
 __device__ __forceinline__ int64_t ws_mask_idle_at(int slot, int64_t num_blocks, int64_t block, int lane,
-                                                   int t, int wave, int ot) {
+                                                   int t, int tile, int ot) {
+    constexpr int TPW = S::TPW;
     const int per = TPW == 1 ? ot : ot >> 1;
-    const int byte = 4 * (wave >> 1) + ((wave & 1) ? 0 : 2);
-    const bool used = per == 1 ? byte == 0 : wave < per;
+    const int byte = 4 * (tile >> 1) + ((tile & 1) ? 0 : 2);
+    const bool used = per == 1 ? byte == 0 : tile < per;
     if (used) return -1;
     return ((((int64_t)slot * num_blocks + block) * TPW + t) * 64 + lane) * 16 + byte;
 }
 
 // ---------------------------------------------------------------------------------- forward
-template <int TPW>
+template <class S>
 struct WsFwd : WsWave {
     float x0, x1, x2, v0, v1, v2;       // inputs of this wave's feature block (wave % NB)
-    float logit[4 / TPW][4];            // fused heads: partial sums over this wave's tiles
+    float logit[S::NBW][4];            // fused heads: partial sums over this wave's tiles
     int64_t block0, num_blocks;         // first block of the pass; blocks of the launch
     float* saved;
     char* masks;
 };
 
-template <int TPW, bool TRAIN, bool HWSIN>
+template <class S, bool TRAIN, bool HWSIN>
 __device__ __forceinline__ void ws_step_fwd(const ffn_mlp_chain& ch, const ffn_step& L, bool last_step,
-                                            WsFwd<TPW>& w, bf16x8 (&wreg)[2][2][TPW][2]) {
-    constexpr int NB = WsShape<TPW>::NB;
-    constexpr int KBMAX = WsShape<TPW>::KBMAX;
+                                            WsFwd<S>& w, bf16x8 (&wreg)[2][2][S::TPW][2]) {
+    constexpr int NB = S::NB, NBW = S::NBW, TPW = S::TPW;
+    constexpr int KBMAX = S::KBMAX;
     const int ot = L.out_tiles;
     const int kb_act = L.act_groups >> 1, kb_feat = L.aux_groups >> 1;
-    // tiles of this wave that exist in this step (uniform): wave + 8 t < ot
-    const int nt = ot > w.wave + 8 ? (TPW > 1 ? 2 : 1) : (ot > w.wave ? 1 : 0);
+    constexpr int WAVES = S::WAVES;
+    // tiles of this wave that exist in this step (uniform): tile + 8 t < ot
+    const int nt = ot > w.tile + 8 ? (TPW > 1 ? 2 : 1) : (ot > w.tile ? 1 : 0);
 
-    f32x16 acc[TPW][NB];
+    f32x16 acc[S::TPW][NBW];
     {
         const int room = L.b_off + 32 * ot <= kWsBiasFloats;
         const float* bsrc = room ? w.bias_lds : w.bias_glb;
 #pragma unroll
         for (int t = 0; t < TPW; ++t) {
-            const int o = w.wave + 8 * t;
+            const int o = w.tile + 8 * t;
             const float* bv = bsrc + L.b_off + 32 * (o < ot ? o : 0) + 4 * w.h;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 f32x4 b4 = *reinterpret_cast<const f32x4*>(bv + 8 * q);
                 if (o >= ot) b4 = (f32x4)(0.0f);
 #pragma unroll
-                for (int b = 0; b < NB; ++b)
+                for (int b = 0; b < NBW; ++b)
 #pragma unroll
                     for (int p = 0; p < 4; ++p) acc[t][b][4 * q + p] = b4[p];
             }
         }
     }
-    bf16x8 xb[NB][2];
+    bf16x8 xb[NBW][2], xh[NBW];
     bool swap_due = false;
     auto run = [&](int count, int g0) -> bool {
-        if (nt == 0) return ws_segment<TPW, 0>(w, acc, wreg, xb, count, g0);
-        if (TPW > 1 && nt == 1) return ws_segment<TPW, 1>(w, acc, wreg, xb, count, g0);
-        return ws_segment<TPW, TPW>(w, acc, wreg, xb, count, g0);
+        if (nt == 0) return ws_segment<S, 0>(w, acc, wreg, xb, xh, count, g0);
+        if (TPW > 1 && nt == 1) return ws_segment<S, 1>(w, acc, wreg, xb, xh, count, g0);
+        return ws_segment<S, TPW>(w, acc, wreg, xb, xh, count, g0);
     };
     if (kb_act > 0) swap_due = run(kb_act, 0);     // X holds the previous step's output (filled)
     if (kb_feat > 0) {
@@ -323,7 +367,7 @@ __device__ __forceinline__ void ws_step_fwd(const ffn_mlp_chain& ch, const ffn_s
                     (w.block0 + fb) * (int64_t)(ch.slot_channels[L.save_enc_slot] * 8);
         // feature K blocks c0 .. c0+count-1 of this wave's block into X K blocks x0 ..
         auto generate = [&](int c0, int count, int x0) {
-            for (int G = w.wave / NB; G < count; G += kWsWaves / NB) {
+            for (int G = w.wave / NB; G < count; G += WAVES / NB) {
                 float f[8];
                 if (HWSIN) {
                     if (c0 + G < g_trig) features16_hw<true>(enc, c0 + G, w.h, p0, p1, p2, f);
@@ -342,7 +386,7 @@ __device__ __forceinline__ void ws_step_fwd(const ffn_mlp_chain& ch, const ffn_s
                 }
                 bf16x8 fh, fl;
                 split8(f, fh, fl);
-                f32x4* dst = w.xbuf + ws_x_index<TPW>(x0 + G, fb, 0) + w.lane;
+                f32x4* dst = w.xbuf + ws_x_index<S>(x0 + G, fb, 0) + w.lane;
                 dst[0] = __builtin_bit_cast(f32x4, fh);
                 dst[64] = __builtin_bit_cast(f32x4, fl);
             }
@@ -355,7 +399,7 @@ __device__ __forceinline__ void ws_step_fwd(const ffn_mlp_chain& ch, const ffn_s
             // instructions while the other runs the sin/cos polynomials, then they trade.  One
             // barrier per segment ("k consumed, k+1 filled").
             constexpr int HALF = KBMAX / 2;
-            const bool k_first = w.wave < kWsWaves / 2;
+            const bool k_first = ((w.wave >> 2) & 1) == 0;      // (waves i, i + 4, i + 8, .. share a SIMD)
             ws_barrier();                          // every wave has consumed what X held
             generate(0, kb_feat < HALF ? kb_feat : HALF, 0);
             ws_barrier();
@@ -364,7 +408,7 @@ __device__ __forceinline__ void ws_step_fwd(const ffn_mlp_chain& ch, const ffn_s
                 const int count = kb_feat - c0 < HALF ? kb_feat - c0 : HALF;
                 const int c1 = c0 + HALF;
                 const int next = c1 >= kb_feat ? 0 : (kb_feat - c1 < HALF ? kb_feat - c1 : HALF);
-                if (swap_due) { ws_swap<TPW>(wreg); swap_due = false; }
+                if (swap_due) { ws_swap<S>(wreg); swap_due = false; }
                 if (k_first) {
                     swap_due = run(count, side * HALF);
                     if (next > 0) generate(c1, next, (side ^ 1) * HALF);
@@ -377,7 +421,7 @@ __device__ __forceinline__ void ws_step_fwd(const ffn_mlp_chain& ch, const ffn_s
         } else {
             for (int c0 = 0; c0 < kb_feat; c0 += KBMAX) {
                 const int count = kb_feat - c0 < KBMAX ? kb_feat - c0 : KBMAX;
-                if (swap_due) { ws_swap<TPW>(wreg); swap_due = false; }
+                if (swap_due) { ws_swap<S>(wreg); swap_due = false; }
                 ws_barrier();                      // every wave has consumed what X held
                 generate(c0, count, 0);
                 ws_barrier();                      // filled
@@ -389,10 +433,10 @@ __device__ __forceinline__ void ws_step_fwd(const ffn_mlp_chain& ch, const ffn_s
     // ---- epilogue: ReLU, sign bits, saves, fused head, the next step's operands into X
     const bool fused_head = L.head_off >= 0;
     const float* hw = w.bias_lds + (fused_head ? L.head_off : 0) + 4 + 16 * w.h;
-    if (fused_head && w.wave == 0 && w.h == 0) {
+    if (fused_head && w.tile == 0 && w.h == 0) {
         const f32x4 hb = *reinterpret_cast<const f32x4*>(w.bias_lds + L.head_off);
 #pragma unroll
-        for (int b = 0; b < NB; ++b)
+        for (int b = 0; b < NBW; ++b)
 #pragma unroll
             for (int c = 0; c < 4; ++c) w.logit[b][c] += hb[c];
     }
@@ -401,27 +445,28 @@ __device__ __forceinline__ void ws_step_fwd(const ffn_mlp_chain& ch, const ffn_s
     // leaves its K loops early (the older wave of a SIMD wins the matrix pipe) does its ReLU /
     // sign-bit / bf16-split / head arithmetic under the matrix instructions of the waves still
     // multiplying; after the barrier only the 16-byte LDS stores are left.
-    bf16x8 res[TPW][NB][2][2];
+    bf16x8 res[S::TPW][NBW][2][2];
     int save_s = w.s, save_h = w.h, e_lane = w.lane;
     asm volatile("" : "+v"(save_s), "+v"(save_h), "+v"(e_lane));     // (see mlp_bf16.hip: no hoisted address tables)
+    const int64_t blk0 = w.block0 + w.b0;          // this wave's first block of the launch
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
-        const int o = w.wave + 8 * t;
+        const int o = w.tile + 8 * t;
         if (TRAIN && L.relu && L.mask_slot >= 0) {
 #pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                const int64_t at = ws_mask_idle_at<TPW>(L.mask_slot, w.num_blocks, w.block0 + b, e_lane, t, w.wave, ot);
-                if (at >= 0 && w.block0 + b < w.num_blocks) *reinterpret_cast<uint16_t*>(w.masks + at) = (uint16_t)0;
+            for (int b = 0; b < NBW; ++b) {
+                const int64_t at = ws_mask_idle_at<S>(L.mask_slot, w.num_blocks, blk0 + b, e_lane, t, w.tile, ot);
+                if (at >= 0 && blk0 + b < w.num_blocks) *reinterpret_cast<uint16_t*>(w.masks + at) = (uint16_t)0;
             }
         }
         if (o >= ot) continue;
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const bool live = w.block0 + b < w.num_blocks;
+        for (int b = 0; b < NBW; ++b) {
+            const bool live = blk0 + b < w.num_blocks;
             f32x4* save_out = nullptr;
             if (TRAIN && L.out_slot >= 0 && live)
                 save_out = reinterpret_cast<f32x4*>(w.saved + ch.slot_offset[L.out_slot] * w.num_blocks * 32) +
-                           (w.block0 + b) * (int64_t)(ch.slot_channels[L.out_slot] * 8);
+                           (blk0 + b) * (int64_t)(ch.slot_channels[L.out_slot] * 8);
             unsigned sign_bits = 0u;
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
@@ -452,23 +497,23 @@ __device__ __forceinline__ void ws_step_fwd(const ffn_mlp_chain& ch, const ffn_s
                 if (!last_step) split8(y, res[t][b][half][0], res[t][b][half][1]);
             }
             if (TRAIN && L.relu && L.mask_slot >= 0 && live) {
-                *reinterpret_cast<uint16_t*>(w.masks + ws_mask_at<TPW>(L.mask_slot, w.num_blocks, w.block0 + b, e_lane, o, ot)) =
+                *reinterpret_cast<uint16_t*>(w.masks + ws_mask_at<S>(L.mask_slot, w.num_blocks, blk0 + b, e_lane, o, ot)) =
                     (uint16_t)(sign_bits & 0xffffu);
             }
         }
     }
-    if (swap_due) ws_swap<TPW>(wreg);
+    if (swap_due) ws_swap<S>(wreg);
     ws_barrier();                                  // every K loop of this step has read X
     if (!last_step) {
 #pragma unroll
         for (int t = 0; t < TPW; ++t) {
-            const int o = w.wave + 8 * t;
+            const int o = w.tile + 8 * t;
             if (o >= ot) continue;
 #pragma unroll
-            for (int b = 0; b < NB; ++b)
+            for (int b = 0; b < NBW; ++b)
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
-                    f32x4* dst = w.xbuf + ws_x_index<TPW>(2 * o + half, b, 0) + e_lane;
+                    f32x4* dst = w.xbuf + ws_x_index<S>(2 * o + half, w.b0 + b, 0) + e_lane;
                     dst[0] = __builtin_bit_cast(f32x4, res[t][b][half][0]);
                     dst[64] = __builtin_bit_cast(f32x4, res[t][b][half][1]);
                 }
@@ -477,26 +522,28 @@ __device__ __forceinline__ void ws_step_fwd(const ffn_mlp_chain& ch, const ffn_s
     }
 }
 
-template <int TPW, bool TRAIN, bool HWSIN>
-__global__ void __launch_bounds__(kWsThreads)
+template <class S, bool TRAIN, bool HWSIN>
+__global__ void __launch_bounds__(S::THREADS)
 mlp_forward_bf16_ws_kernel(const ffn_mlp_chain ch, const uint16_t* __restrict__ packed,
                            const float* __restrict__ bias, const float* __restrict__ positions,
                            const float* __restrict__ views, int64_t n, float* __restrict__ logits,
                            float* __restrict__ saved, uint32_t* __restrict__ masks) {
-    constexpr int NB = WsShape<TPW>::NB;
+    constexpr int NB = S::NB, NBW = S::NBW, TPW = S::TPW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* enc_table = reinterpret_cast<float*>(smem + kWsXBytes);
     float* bias_lds = reinterpret_cast<float*>(smem + kWsXBytes + kEncTableBytes);
-    stage_encoding_tables(ch.enc, enc_table, threadIdx.x, kWsThreads);
+    stage_encoding_tables(ch.enc, enc_table, threadIdx.x, S::THREADS);
     {
         const int staged = ch.bias_floats < kWsBiasFloats ? ch.bias_floats : kWsBiasFloats;
-        for (int i = threadIdx.x; i < staged; i += kWsThreads) bias_lds[i] = bias[i];
+        for (int i = threadIdx.x; i < staged; i += S::THREADS) bias_lds[i] = bias[i];
     }
-    WsFwd<TPW> w;
+    WsFwd<S> w;
     w.lane = threadIdx.x & 63;
     w.h = w.lane >> 5;
     w.s = w.lane & 31;
     w.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    w.tile = w.wave & 7;
+    w.b0 = (w.wave >> 3) * NBW;
     w.xbuf = reinterpret_cast<f32x4*>(smem);
     w.enc_table = enc_table;
     w.bias_lds = bias_lds;
@@ -511,7 +558,7 @@ mlp_forward_bf16_ws_kernel(const ffn_mlp_chain ch, const uint16_t* __restrict__ 
     w.masks = reinterpret_cast<char*>(masks);
     w.num_blocks = (n + 31) / 32;
     const int64_t passes = (w.num_blocks + NB - 1) / NB;
-    bf16x8 wreg[2][2][TPW][2];
+    bf16x8 wreg[2][2][S::TPW][2];
     __syncthreads();                               // tables and biases are staged
     const int fb = w.wave % NB;
     float in_next[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -532,28 +579,28 @@ mlp_forward_bf16_ws_kernel(const ffn_mlp_chain ch, const uint16_t* __restrict__ 
         w.v0 = in_next[3]; w.v1 = in_next[4]; w.v2 = in_next[5];
         request_inputs(pass + gridDim.x < passes ? pass + gridDim.x : pass);
 #pragma unroll
-        for (int b = 0; b < NB; ++b)
+        for (int b = 0; b < NBW; ++b)
 #pragma unroll
             for (int c = 0; c < 4; ++c) w.logit[b][c] = 0.0f;
         for (int li = 0; li < ch.num_steps; ++li)
-            ws_step_fwd<TPW, TRAIN, HWSIN>(ch, ch.step[li], li + 1 == ch.num_steps, w, wreg);
+            ws_step_fwd<S, TRAIN, HWSIN>(ch, ch.step[li], li + 1 == ch.num_steps, w, wreg);
         // the tiles' partial logits meet through X (free after the last step's K loops: the
-        // barrier in front of its epilogue), in a fixed order
+        // barrier in front of its epilogue), in a fixed order: [block][tile][sample]
         f32x4* scratch = w.xbuf;
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
+        for (int b = 0; b < NBW; ++b) {
             f32x4 part;
 #pragma unroll
             for (int c = 0; c < 4; ++c) part[c] = w.logit[b][c] + __shfl_xor(w.logit[b][c], 32);
-            if (w.h == 0) scratch[(b * kWsWaves + w.wave) * 32 + w.s] = part;
+            if (w.h == 0) scratch[((w.b0 + b) * 8 + w.tile) * 32 + w.s] = part;
         }
         ws_barrier();
         if (w.wave < NB && w.h == 0) {
             const int64_t block = w.block0 + w.wave;
             const int64_t sample = block * 32 + w.s;
-            f32x4 out = scratch[(w.wave * kWsWaves) * 32 + w.s];
+            f32x4 out = scratch[(w.wave * 8) * 32 + w.s];
 #pragma unroll
-            for (int k = 1; k < kWsWaves; ++k) out += scratch[(w.wave * kWsWaves + k) * 32 + w.s];
+            for (int k = 1; k < 8; ++k) out += scratch[(w.wave * 8 + k) * 32 + w.s];
             if (block < w.num_blocks && sample < n) reinterpret_cast<f32x4*>(logits)[sample] = out;
         }
         // (the next pass refills X only behind its own "all consumed" barrier)
@@ -561,7 +608,7 @@ mlp_forward_bf16_ws_kernel(const ffn_mlp_chain ch, const uint16_t* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------- backward data
-template <int TPW>
+template <class S>
 struct WsBwd : WsWave {
     f32x4 dl;                           // d(loss)/d(logits) of this wave's block (wave % NB), lane's sample
     int64_t block0, num_blocks;
@@ -569,50 +616,51 @@ struct WsBwd : WsWave {
     const char* masks;
 };
 
-template <int TPW>
+template <class S>
 __device__ __forceinline__ void ws_step_bwd(const ffn_mlp_chain& ch, const ffn_step& L, bool last_step,
-                                            WsBwd<TPW>& w, bf16x8 (&wreg)[2][2][TPW][2]) {
-    constexpr int NB = WsShape<TPW>::NB;
+                                            WsBwd<S>& w, bf16x8 (&wreg)[2][2][S::TPW][2]) {
+    constexpr int NB = S::NB, NBW = S::NBW, TPW = S::TPW;
     const int ot = L.out_tiles;
     const int kb_act = L.act_groups >> 1;
-    const int nt = ot > w.wave + 8 ? (TPW > 1 ? 2 : 1) : (ot > w.wave ? 1 : 0);
+    const int nt = ot > w.tile + 8 ? (TPW > 1 ? 2 : 1) : (ot > w.tile ? 1 : 0);
+    const int64_t blk0 = w.block0 + w.b0;          // this wave's first block of the launch
     // the sign masks of the layer being differentiated: requested now, used after the K loops
-    unsigned mbits[TPW][NB];
+    unsigned mbits[S::TPW][NBW];
 #pragma unroll
     for (int t = 0; t < TPW; ++t)
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
+        for (int b = 0; b < NBW; ++b) {
             mbits[t][b] = 0xffffu;
-            const int o = w.wave + 8 * t;
+            const int o = w.tile + 8 * t;
             if (L.mask_slot >= 0 && o < ot) {
-                int64_t blk = w.block0 + b;
+                int64_t blk = blk0 + b;
                 blk = blk < w.num_blocks ? blk : w.num_blocks - 1;
                 mbits[t][b] = *reinterpret_cast<const uint16_t*>(
-                    w.masks + ws_mask_at<TPW>(L.mask_slot, w.num_blocks, blk, w.lane, o, ot));
+                    w.masks + ws_mask_at<S>(L.mask_slot, w.num_blocks, blk, w.lane, o, ot));
             }
         }
-    f32x16 acc[TPW][NB];
+    f32x16 acc[S::TPW][NBW];
 #pragma unroll
     for (int t = 0; t < TPW; ++t)
 #pragma unroll
-        for (int b = 0; b < NB; ++b)
+        for (int b = 0; b < NBW; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][b][r] = 0.0f;
-    bf16x8 xb[NB][2];
+    bf16x8 xb[NBW][2], xh[NBW];
     bool swap_due = false;
     auto run = [&](int count) -> bool {
-        if (nt == 0) return ws_segment<TPW, 0>(w, acc, wreg, xb, count, 0);
-        if (TPW > 1 && nt == 1) return ws_segment<TPW, 1>(w, acc, wreg, xb, count, 0);
-        return ws_segment<TPW, TPW>(w, acc, wreg, xb, count, 0);
+        if (nt == 0) return ws_segment<S, 0>(w, acc, wreg, xb, xh, count, 0);
+        if (TPW > 1 && nt == 1) return ws_segment<S, 1>(w, acc, wreg, xb, xh, count, 0);
+        return ws_segment<S, TPW>(w, acc, wreg, xb, xh, count, 0);
     };
     if (kb_act > 0) swap_due = run(kb_act);
     if (L.aux_groups > 0) {
         // the d_logits term: one K block whose K rows 0..lg_n-1 (lane half 0) are logits columns
         // lg_col.., and a zero K block -- generated like a feature segment, one (block, K block)
         // item per wave (NB x 2 items)
-        if (swap_due) { ws_swap<TPW>(wreg); swap_due = false; }
+        if (swap_due) { ws_swap<S>(wreg); swap_due = false; }
         ws_barrier();
-        for (int item = w.wave; item < 2 * NB; item += kWsWaves) {
+        for (int item = w.wave; item < 2 * NB; item += S::WAVES) {
             const int G = item / NB;
             float v[8];
 #pragma unroll
@@ -624,7 +672,7 @@ __device__ __forceinline__ void ws_step_bwd(const ffn_mlp_chain& ch, const ffn_s
             }
             bf16x8 dh, dlo;
             split8(v, dh, dlo);
-            f32x4* dst = w.xbuf + ws_x_index<TPW>(G, item % NB, 0) + w.lane;
+            f32x4* dst = w.xbuf + ws_x_index<S>(G, item % NB, 0) + w.lane;
             dst[0] = __builtin_bit_cast(f32x4, dh);
             dst[64] = __builtin_bit_cast(f32x4, dlo);
         }
@@ -633,20 +681,20 @@ __device__ __forceinline__ void ws_step_bwd(const ffn_mlp_chain& ch, const ffn_s
     }
     // ---- epilogue: mask, save dZ, the next step's operands into X (arithmetic and global stores
     // before the "all consumed" barrier, the LDS stores after it: see the forward step)
-    bf16x8 res[TPW][NB][2][2];
+    bf16x8 res[S::TPW][NBW][2][2];
     int save_s = w.s, save_h = w.h, e_lane = w.lane;
     asm volatile("" : "+v"(save_s), "+v"(save_h), "+v"(e_lane));
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
-        const int o = w.wave + 8 * t;
+        const int o = w.tile + 8 * t;
         if (o >= ot) continue;
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const bool live = w.block0 + b < w.num_blocks;
+        for (int b = 0; b < NBW; ++b) {
+            const bool live = blk0 + b < w.num_blocks;
             f32x4* save_out = nullptr;
             if (L.out_slot >= 0 && live)
                 save_out = reinterpret_cast<f32x4*>(w.dz + ch.slot_offset[L.out_slot] * w.num_blocks * 32) +
-                           (w.block0 + b) * (int64_t)(ch.slot_channels[L.out_slot] * 8);
+                           (blk0 + b) * (int64_t)(ch.slot_channels[L.out_slot] * 8);
             const unsigned word = mbits[t][b];
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
@@ -670,18 +718,18 @@ __device__ __forceinline__ void ws_step_bwd(const ffn_mlp_chain& ch, const ffn_s
             }
         }
     }
-    if (swap_due) ws_swap<TPW>(wreg);
+    if (swap_due) ws_swap<S>(wreg);
     ws_barrier();
     if (!last_step) {
 #pragma unroll
         for (int t = 0; t < TPW; ++t) {
-            const int o = w.wave + 8 * t;
+            const int o = w.tile + 8 * t;
             if (o >= ot) continue;
 #pragma unroll
-            for (int b = 0; b < NB; ++b)
+            for (int b = 0; b < NBW; ++b)
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
-                    f32x4* dst = w.xbuf + ws_x_index<TPW>(2 * o + half, b, 0) + e_lane;
+                    f32x4* dst = w.xbuf + ws_x_index<S>(2 * o + half, w.b0 + b, 0) + e_lane;
                     dst[0] = __builtin_bit_cast(f32x4, res[t][b][half][0]);
                     dst[64] = __builtin_bit_cast(f32x4, res[t][b][half][1]);
                 }
@@ -690,18 +738,20 @@ __device__ __forceinline__ void ws_step_bwd(const ffn_mlp_chain& ch, const ffn_s
     }
 }
 
-template <int TPW>
-__global__ void __launch_bounds__(kWsThreads)
+template <class S>
+__global__ void __launch_bounds__(S::THREADS)
 mlp_backward_bf16_ws_kernel(const ffn_mlp_chain ch, const uint16_t* __restrict__ packed,
                             const float* __restrict__ d_logits, int64_t n,
                             const uint32_t* __restrict__ masks, float* __restrict__ dz) {
-    constexpr int NB = WsShape<TPW>::NB;
+    constexpr int NB = S::NB, NBW = S::NBW, TPW = S::TPW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    WsBwd<TPW> w;
+    WsBwd<S> w;
     w.lane = threadIdx.x & 63;
     w.h = w.lane >> 5;
     w.s = w.lane & 31;
     w.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    w.tile = w.wave & 7;
+    w.b0 = (w.wave >> 3) * NBW;
     w.xbuf = reinterpret_cast<f32x4*>(smem);
     w.enc_table = nullptr;
     w.bias_lds = nullptr;
@@ -717,7 +767,7 @@ mlp_backward_bf16_ws_kernel(const ffn_mlp_chain ch, const uint16_t* __restrict__
     w.masks = reinterpret_cast<const char*>(masks);
     w.num_blocks = (n + 31) / 32;
     const int64_t passes = (w.num_blocks + NB - 1) / NB;
-    bf16x8 wreg[2][2][TPW][2];
+    bf16x8 wreg[2][2][S::TPW][2];
     const int fb = w.wave % NB;
     f32x4 dl_next = (f32x4)(0.0f);
     auto request_inputs = [&](int64_t pass) {
@@ -734,7 +784,7 @@ mlp_backward_bf16_ws_kernel(const ffn_mlp_chain ch, const uint16_t* __restrict__
         w.dl = dl_next;
         request_inputs(pass + gridDim.x < passes ? pass + gridDim.x : pass);
         for (int li = 0; li < ch.num_steps; ++li)
-            ws_step_bwd<TPW>(ch, ch.step[li], li + 1 == ch.num_steps, w, wreg);
+            ws_step_bwd<S>(ch, ch.step[li], li + 1 == ch.num_steps, w, wreg);
         // (the next pass refills X only behind its own "all consumed" barrier)
     }
 }
@@ -749,15 +799,41 @@ static int64_t ws_grid(int64_t passes) {
     return passes < cus ? passes : cus;
 }
 
-template <int TPW, bool TRAIN, bool HWSIN>
-static void ws_launch_fwd(int64_t grid, const ffn_mlp_chain* chain, const uint16_t* packed_w, const float* bias,
+typedef WsShape<1, 1> WsNarrow8;      // 8 waves, a tile each, 4 blocks per wave
+typedef WsShape<1, 2> WsNarrow16;     // 16 waves, two per tile, 2 blocks per wave
+typedef WsShape<2, 1> WsWide8;        // 512-wide chains: 8 waves, two tiles each, 2 blocks per pass
+
+// FFN_BF16_WAVES=8|16: waves per workgroup of the narrow-chain kernels (A/B; default below)
+inline bool ws_sixteen_waves() {
+    const char* v = getenv("FFN_BF16_WAVES");
+    if (v != nullptr && v[0] == '8') return false;
+    if (v != nullptr && v[0] == '1') return true;
+    return false;
+}
+
+template <class S, bool TRAIN, bool HWSIN>
+static void ws_launch_fwd(const ffn_mlp_chain* chain, const uint16_t* packed_w, const float* bias,
                           const float* positions, const float* views, int64_t n, float* logits,
                           float* saved, uint32_t* masks, void* stream) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_forward_bf16_ws_kernel<TPW, TRAIN, HWSIN>),
+    const int64_t grid = ws_grid(((n + 31) / 32 + S::NB - 1) / S::NB);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_forward_bf16_ws_kernel<S, TRAIN, HWSIN>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWsLdsBytes);
-    hipLaunchKernelGGL((mlp_forward_bf16_ws_kernel<TPW, TRAIN, HWSIN>), dim3((unsigned)grid), dim3(kWsThreads),
+    hipLaunchKernelGGL((mlp_forward_bf16_ws_kernel<S, TRAIN, HWSIN>), dim3((unsigned)grid), dim3(S::THREADS),
                        kWsLdsBytes, (hipStream_t)stream, *chain, packed_w, bias, positions, views, n,
                        logits, saved, masks);
+}
+
+template <class S>
+static void ws_launch_fwd_modes(bool hw, const ffn_mlp_chain* chain, const uint16_t* packed_w, const float* bias,
+                                const float* positions, const float* views, int64_t n, float* logits,
+                                float* saved, uint32_t* masks, void* stream) {
+    if (saved != nullptr) {
+        if (hw) ws_launch_fwd<S, true, true>(chain, packed_w, bias, positions, views, n, logits, saved, masks, stream);
+        else ws_launch_fwd<S, true, false>(chain, packed_w, bias, positions, views, n, logits, saved, masks, stream);
+    } else {
+        if (hw) ws_launch_fwd<S, false, true>(chain, packed_w, bias, positions, views, n, logits, nullptr, nullptr, stream);
+        else ws_launch_fwd<S, false, false>(chain, packed_w, bias, positions, views, n, logits, nullptr, nullptr, stream);
+    }
 }
 
 int launch_forward16_ws(const ffn_mlp_chain* chain, const uint16_t* packed_w, const float* bias,
@@ -765,39 +841,30 @@ int launch_forward16_ws(const ffn_mlp_chain* chain, const uint16_t* packed_w, co
                         float* saved, uint32_t* masks, void* stream) {
     const bool hw = !use_poly_sincos();
     if (chain->wide) {             // 512-wide chains: two tiles per wave, two blocks per pass
-        const int64_t grid = ws_grid(((n + 31) / 32 + 1) / 2);
-        if (saved != nullptr) ws_launch_fwd<2, true, true>(grid, chain, packed_w, bias, positions, views, n, logits, saved, masks, stream);
-        else ws_launch_fwd<2, false, true>(grid, chain, packed_w, bias, positions, views, n, logits, nullptr, nullptr, stream);
+        if (saved != nullptr) ws_launch_fwd<WsWide8, true, true>(chain, packed_w, bias, positions, views, n, logits, saved, masks, stream);
+        else ws_launch_fwd<WsWide8, false, true>(chain, packed_w, bias, positions, views, n, logits, nullptr, nullptr, stream);
         return 0;
     }
-    const int64_t passes = ((n + 31) / 32 + 3) / 4;
-    const int64_t grid = ws_grid(passes);
-    if (saved != nullptr) {
-        if (hw) ws_launch_fwd<1, true, true>(grid, chain, packed_w, bias, positions, views, n, logits, saved, masks, stream);
-        else ws_launch_fwd<1, true, false>(grid, chain, packed_w, bias, positions, views, n, logits, saved, masks, stream);
-    } else {
-        if (hw) ws_launch_fwd<1, false, true>(grid, chain, packed_w, bias, positions, views, n, logits, nullptr, nullptr, stream);
-        else ws_launch_fwd<1, false, false>(grid, chain, packed_w, bias, positions, views, n, logits, nullptr, nullptr, stream);
-    }
+    if (ws_sixteen_waves()) ws_launch_fwd_modes<WsNarrow16>(hw, chain, packed_w, bias, positions, views, n, logits, saved, masks, stream);
+    else ws_launch_fwd_modes<WsNarrow8>(hw, chain, packed_w, bias, positions, views, n, logits, saved, masks, stream);
     return 0;
+}
+
+template <class S>
+static void ws_launch_bwd(const ffn_mlp_chain* chain, const uint16_t* packed_wt, const float* d_logits,
+                          int64_t n, const uint32_t* masks, float* dz, void* stream) {
+    const int64_t grid = ws_grid(((n + 31) / 32 + S::NB - 1) / S::NB);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_backward_bf16_ws_kernel<S>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWsXBytes);
+    hipLaunchKernelGGL((mlp_backward_bf16_ws_kernel<S>), dim3((unsigned)grid), dim3(S::THREADS), kWsXBytes,
+                       (hipStream_t)stream, *chain, packed_wt, d_logits, n, masks, dz);
 }
 
 int launch_backward16_ws(const ffn_mlp_chain* chain, const uint16_t* packed_wt, const float* d_logits,
                          int64_t n, const uint32_t* masks, float* dz, void* stream) {
-    if (chain->wide) {
-        const int64_t grid = ws_grid(((n + 31) / 32 + 1) / 2);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_backward_bf16_ws_kernel<2>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWsXBytes);
-        hipLaunchKernelGGL((mlp_backward_bf16_ws_kernel<2>), dim3((unsigned)grid), dim3(kWsThreads), kWsXBytes,
-                           (hipStream_t)stream, *chain, packed_wt, d_logits, n, masks, dz);
-        return 0;
-    }
-    const int64_t passes = ((n + 31) / 32 + 3) / 4;
-    const int64_t grid = ws_grid(passes);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_backward_bf16_ws_kernel<1>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWsXBytes);
-    hipLaunchKernelGGL((mlp_backward_bf16_ws_kernel<1>), dim3((unsigned)grid), dim3(kWsThreads), kWsXBytes,
-                       (hipStream_t)stream, *chain, packed_wt, d_logits, n, masks, dz);
+    if (chain->wide) ws_launch_bwd<WsWide8>(chain, packed_wt, d_logits, n, masks, dz, stream);
+    else if (ws_sixteen_waves()) ws_launch_bwd<WsNarrow16>(chain, packed_wt, d_logits, n, masks, dz, stream);
+    else ws_launch_bwd<WsNarrow8>(chain, packed_wt, d_logits, n, masks, dz, stream);
     return 0;
 }
 

@@ -199,31 +199,35 @@ def test_padded_widths_in_the_split_bf16_mode_and_the_fused_render(kind):
 
 # ----------------------------------------------------------------------------------- two waves per SIMD
 @contextlib.contextmanager
-def _bf16_kernels(which, sincos="poly"):
+def _bf16_kernels(which, sincos="poly", waves=None):
     """Selects the split-bf16 chain kernels ("ring" | "ws") and, for the two-waves-per-SIMD ones,
     the feature arithmetic ("poly": the f32 kernels' polynomials, bit-identical features; "hw":
     v_sin_f32 / v_cos_f32, the default) for the launches inside the block."""
-    old = {k: os.environ.get(k) for k in ("FFN_BF16_KERNELS", "FFN_BF16_SINCOS")}
+    old = {k: os.environ.get(k) for k in ("FFN_BF16_KERNELS", "FFN_BF16_SINCOS", "FFN_BF16_WAVES")}
     os.environ["FFN_BF16_KERNELS"] = which
     os.environ["FFN_BF16_SINCOS"] = sincos
+    if waves is not None:
+        os.environ["FFN_BF16_WAVES"] = str(waves)       # 8 | 16 waves per workgroup (narrow chains)
     try:
         yield
     finally:
         for k, v in old.items():
             if v is None:
-                del os.environ[k]
+                os.environ.pop(k, None)
             else:
                 os.environ[k] = v
 
 
+@pytest.mark.parametrize("waves", [8, 16])
 @pytest.mark.parametrize("name", ["mlp", "basic", "positional", "gaussian", "nerf", "nerf_small"])
-def test_two_waves_per_simd_kernels_equal_the_ring_kernels(golden, name):
+def test_two_waves_per_simd_kernels_equal_the_ring_kernels(golden, name, waves):
     """The split-bf16 chain kernels in their two-waves-per-SIMD organisation (mlp_bf16_ws.hip: a
     wave owns an output tile, activations as B operands in LDS, weights streamed into registers)
     against the one-wave-per-SIMD ring kernels on the same packs: the arithmetic per accumulator is
     the same, so saved activations / features, sign masks and every dZ slab are BIT-IDENTICAL; the
     fused heads' partial sums meet in a different order (logits within 2e-6).  Ragged sample
-    counts: a partial pass (fewer than 4 blocks), a partial block."""
+    counts: a partial pass (fewer than 4 blocks), a partial block.  `waves` = 8 (two per SIMD, a
+    wave per tile) or 16 (four per SIMD, two waves per tile with half of the pass's blocks each)."""
     from tests.test_kernels_gpu import _load_fourier, _load_nerf
     g = golden("models")
     if name.startswith("nerf"):
@@ -239,7 +243,7 @@ def test_two_waves_per_simd_kernels_equal_the_ring_kernels(golden, name):
         d_logits = torch.randn(n, 4, device=dev()) / n
         out = {}
         for which in ("ring", "ws"):
-            with _bf16_kernels(which):
+            with _bf16_kernels(which, waves=waves):
                 buf = torch.zeros((prog.saved_floats(n),), dtype=torch.float32, device=dev())
                 infer = prog.forward16(x, views)
                 logits = prog.forward(x, views, buf, precision="bf16x3")
