@@ -240,13 +240,14 @@ __device__ __forceinline__ void team_barrier() {
 //   1 slab destination, no fused head, no output save   (hidden layers; dgrad steps)
 //   2 slab destination, output saved                    (forward: fused head + save; dgrad: last step)
 //   3 slab destination, fused head, no save             (forward inference)
-template <int OT, int MODE, bool WIDE, int FLAV>
+template <int OT, int MODE, int TWP, int FLAV>
 __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step& L,
                                          const ffn_step* next, WaveCtx& w,
                                          const float* __restrict__ packed_w,
                                          f32x4 (&pre)[16],               // groups 0,1 weights, prefetched
                                          float* __restrict__ slab_out) { // fwd: saved; bwd: dZ
-    constexpr int TW = WIDE ? 2 : 1;              // waves sharing a step's output tiles
+    constexpr bool WIDE = TWP > 1;
+    constexpr int TW = TWP;                       // waves sharing a step's output tiles (1, 2 or 4)
     constexpr int kChunk = WIDE ? 64 : 32;        // K groups the slab holds
     const int half = WIDE ? w.half : 0;
     // accumulators start at the bias (forward) or zero (backward): the 32 LDS reads go out
@@ -341,9 +342,13 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
             }
             if (WIDE) team_barrier();
         }
-        // wide mode: each wave of the pair saves half of what both consume
-        const bool save_lo = MODE != kInfer && save != nullptr && (!WIDE || half == 0);
-        const bool save_hi = MODE != kInfer && save != nullptr && (!WIDE || half == 1);
+        // team mode: each wave of the team saves its share of what all consume (of the four K groups
+        // of a trip: a pair's waves two each, a quad's waves one each)
+        const bool saving = MODE != kInfer && save != nullptr;
+        const bool save_0 = saving && (TW == 1 || half == 0);
+        const bool save_1 = saving && (TW == 1 || half == (TW == 2 ? 0 : 1));
+        const bool save_2 = saving && (TW == 1 || half == (TW == 2 ? 1 : 2));
+        const bool save_3 = saving && (TW == 1 || half == (TW == 2 ? 1 : 3));
         // byte offset of this lane's float4 of K group g inside a saved block:
         //   16 * ((2g + h) * 32 + (s ^ ((2g + h) & 15)))  =  g * 1024  +  (lane_part ^ (((2g) & 15) << 4))
         // with lane_part = h * 512 + ((s ^ h) << 4): one v_xor with a scalar per store, the rest
@@ -394,10 +399,8 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
                 load_group<OT>(wb1, wnext + kGroupStride, w.lane);
                 x2 = xa[128];
                 x3 = xa[192];
-                if (save_lo) {
-                    FFN_SAVE(g, x0);
-                    FFN_SAVE(g + 1, x1);
-                }
+                if (save_0) FFN_SAVE(g, x0);
+                if (save_1) FFN_SAVE(g + 1, x1);
                 mma_group<OT>(acc, wa0, x0);
                 mma_group<OT>(acc, wa1, x1);
                 gnext = gnext + 2 < glast ? gnext + 2 : glast;      // clamp at the end of the panel
@@ -409,10 +412,8 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
                     x0 = xa[0];
                     x1 = xa[64];
                 }
-                if (save_hi) {
-                    FFN_SAVE(g + 2, x2);
-                    FFN_SAVE(g + 3, x3);
-                }
+                if (save_2) FFN_SAVE(g + 2, x2);
+                if (save_3) FFN_SAVE(g + 3, x3);
                 mma_group<OT>(acc, wb0, x2);
                 mma_group<OT>(acc, wb1, x3);
                 gnext = gnext + 2 < glast ? gnext + 2 : glast;
@@ -549,11 +550,12 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
     if (WIDE) team_barrier();        // the step's output is in the slab
 }
 
-template <int MODE, bool WIDE>
+template <int MODE, int TWP>
 __device__ __forceinline__ void run_chain(const ffn_mlp_chain& ch, WaveCtx& w,
                                           const float* __restrict__ packed_w,
                                           float* __restrict__ slab_out) {
-    constexpr int TW = WIDE ? 2 : 1;
+    constexpr bool WIDE = TWP > 1;
+    constexpr int TW = TWP;
     f32x4 pre[16];
     {
         const ffn_step& first = ch.step[0];
@@ -570,7 +572,7 @@ __device__ __forceinline__ void run_chain(const ffn_mlp_chain& ch, WaveCtx& w,
         const ffn_step& L = ch.step[li];
         const ffn_step* next = li + 1 < ch.num_steps ? &ch.step[li + 1] : nullptr;
         const int ot = L.out_tiles / TW;
-        if (ot == 8) {
+        if (TWP < 4 && ot == 8) {
             // the 256-channel steps (all the time of every supported model) get a specialised
             // epilogue; the flavour is a property of the step, known before its K loops start.
             // (Only as many specialisations as the register allocator digests: every inlined
@@ -578,13 +580,13 @@ __device__ __forceinline__ void run_chain(const ffn_mlp_chain& ch, WaveCtx& w,
             const bool saves = MODE != kInfer && L.save_out_slot >= 0 && w.active;
             const bool head = MODE != kBackward && L.head_off >= 0;
             if (MODE == kBackward) {
-                if (saves) run_step<8, MODE, WIDE, 2>(ch, L, next, w, packed_w, pre, slab_out);
-                else run_step<8, MODE, WIDE, 1>(ch, L, next, w, packed_w, pre, slab_out);
-            } else if (!head && L.dst == 0) run_step<8, MODE, WIDE, 1>(ch, L, next, w, packed_w, pre, slab_out);
-            else run_step<8, MODE, WIDE, 0>(ch, L, next, w, packed_w, pre, slab_out);
-        } else if (ot == 4) run_step<4, MODE, WIDE, 0>(ch, L, next, w, packed_w, pre, slab_out);
-        else if (ot == 2) run_step<2, MODE, WIDE, 0>(ch, L, next, w, packed_w, pre, slab_out);
-        else run_step<1, MODE, WIDE, 0>(ch, L, next, w, packed_w, pre, slab_out);
+                if (saves) run_step<8, MODE, TWP, 2>(ch, L, next, w, packed_w, pre, slab_out);
+                else run_step<8, MODE, TWP, 1>(ch, L, next, w, packed_w, pre, slab_out);
+            } else if (!head && L.dst == 0) run_step<8, MODE, TWP, 1>(ch, L, next, w, packed_w, pre, slab_out);
+            else run_step<8, MODE, TWP, 0>(ch, L, next, w, packed_w, pre, slab_out);
+        } else if (TWP < 4 && ot == 4) run_step<4, MODE, TWP, 0>(ch, L, next, w, packed_w, pre, slab_out);
+        else if (ot == 2) run_step<2, MODE, TWP, 0>(ch, L, next, w, packed_w, pre, slab_out);
+        else run_step<1, MODE, TWP, 0>(ch, L, next, w, packed_w, pre, slab_out);
     }
 }
 
@@ -593,17 +595,18 @@ __device__ __forceinline__ void run_chain(const ffn_mlp_chain& ch, WaveCtx& w,
 // SIMDs idling until the slowest sibling wave retires.  Wide mode: two pairs of waves per
 // workgroup, every pair runs the same number of passes (the barriers are workgroup-wide);
 // a pair past the end re-runs the last block with its stores switched off.
-constexpr int kTeamScratchBytes = 2048;    // wide mode: partial logits of the odd waves
+constexpr int kTeamScratchBytes = 3072;    // team modes: partial logits of a team's waves 1.. (pairs: 2 x 1 KiB; a quad: 3 KiB)
 
-template <bool WIDE>
+template <int TWP>
 __device__ __forceinline__ void wave_setup(WaveCtx& w, char* smem, int64_t n, int64_t& stride) {
+    constexpr bool WIDE = TWP > 1;
     w.lane = threadIdx.x & 63;
     w.h = w.lane >> 5;
     w.s = w.lane & 31;
     const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int teams = WIDE ? 2 : kWavesPerBlock;
-    const int team = WIDE ? wave_in_block >> 1 : wave_in_block;
-    w.half = WIDE ? (wave_in_block & 1) : 0;
+    const int teams = kWavesPerBlock / TWP;
+    const int team = wave_in_block / TWP;
+    w.half = WIDE ? (wave_in_block % TWP) : 0;
     stride = (int64_t)gridDim.x * teams;
     w.act = lds_slab(smem + team * (kActBytesPerWave * kWavesPerBlock / teams));
     w.enc_table = reinterpret_cast<const float*>(smem + kWavesPerBlock * kActBytesPerWave);
@@ -615,7 +618,7 @@ __device__ __forceinline__ void wave_setup(WaveCtx& w, char* smem, int64_t n, in
     w.active = true;
 }
 
-template <int MODE, bool WIDE>
+template <int MODE, int TWP>
 __global__ void __launch_bounds__(256, 1)
 mlp_forward_kernel(const ffn_mlp_chain ch, const float* __restrict__ packed_w,
                    const float* __restrict__ bias, const float* __restrict__ positions,
@@ -631,14 +634,16 @@ mlp_forward_kernel(const ffn_mlp_chain ch, const float* __restrict__ packed_w,
         for (int i = threadIdx.x; i < staged; i += 256) bl[i] = bias[i];
     }
     __syncthreads();                  // narrow mode: the only barrier of the kernel
+    constexpr bool WIDE = TWP > 1;
     WaveCtx w;
     int64_t stride;
-    wave_setup<WIDE>(w, smem, n, stride);
+    wave_setup<TWP>(w, smem, n, stride);
     w.bias_glb = bias;
     if (slab_blocks > 0) { w.slab_block0 = slab_block0; w.slab_blocks = slab_blocks; }
     w.masks = reinterpret_cast<uint4*>(masks);
+    // (team scratch: the partial logits of a team's waves 1 .. TWP-1, 1 KiB each)
     f32x4* scratch = reinterpret_cast<f32x4*>(smem + kWavesPerBlock * kActBytesPerWave + kEncTableBytes +
-                                              kBiasLdsFloats * 4) + (threadIdx.x >> 7) * 64;
+                                              kBiasLdsFloats * 4) + ((threadIdx.x >> 6) / TWP) * (TWP - 1) * 64;
     const int64_t passes = WIDE ? (w.num_blocks + stride - 1) / stride : 0;
     const int64_t first = w.block;
     // the inputs of a block are requested one block ahead: a lone wave has nothing else to
@@ -665,15 +670,18 @@ mlp_forward_kernel(const ffn_mlp_chain ch, const float* __restrict__ packed_w,
         w.v0 = in_next[3]; w.v1 = in_next[4]; w.v2 = in_next[5];
         request_inputs(first + (pass + 1) * stride);
         w.logit[0] = w.logit[1] = w.logit[2] = w.logit[3] = 0.0f;
-        run_chain<MODE, WIDE>(ch, w, packed_w, saved);
+        run_chain<MODE, TWP>(ch, w, packed_w, saved);
         f32x4 out;
 #pragma unroll
         for (int c = 0; c < 4; ++c)   // MFMA heads leave their rows on h == 0, fused heads on both halves
             out[c] = w.logit[c] + __shfl_xor(w.logit[c], 32);
-        if (WIDE) {                   // the two waves of a pair hold partial sums
-            if (w.half == 1) scratch[w.lane] = out;
+        if (WIDE) {                   // the waves of a team hold partial sums: added in wave order
+            if (w.half > 0) scratch[(w.half - 1) * 64 + w.lane] = out;
             team_barrier();
-            if (w.half == 0) out += scratch[w.lane];
+            if (w.half == 0) {
+#pragma unroll
+                for (int k = 1; k < TWP; ++k) out += scratch[(k - 1) * 64 + w.lane];
+            }
         }
         if (w.h == 0 && w.half == 0 && w.active && sample < n) {
             reinterpret_cast<f32x4*>(logits)[sample] = out;
@@ -729,7 +737,7 @@ render_fused_kernel(const ffn_mlp_chain ch, const float* __restrict__ packed_w,
     __syncthreads();
     WaveCtx w;
     int64_t stride;
-    wave_setup<WIDE>(w, smem, kSamplesPerWave, stride);
+    wave_setup<(WIDE ? 2 : 1)>(w, smem, kSamplesPerWave, stride);
     w.bias_glb = bias;
     w.block = 0;                       // nothing is saved in inference: slab addressing is unused
     w.masks = nullptr;
@@ -819,7 +827,7 @@ render_fused_kernel(const ffn_mlp_chain ch, const float* __restrict__ packed_w,
                 w.x2 = mul_add_rn(t, dz, sz);
                 w.v0 = dx; w.v1 = dy; w.v2 = dz;
                 w.logit[0] = w.logit[1] = w.logit[2] = w.logit[3] = 0.0f;
-                run_chain<kInfer, WIDE>(ch, w, packed_w, nullptr);
+                run_chain<kInfer, (WIDE ? 2 : 1)>(ch, w, packed_w, nullptr);
                 f32x4 out;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) out[c] = w.logit[c] + __shfl_xor(w.logit[c], 32);
@@ -888,7 +896,7 @@ focus_fused_kernel(const ffn_mlp_chain ch, const float* __restrict__ packed_w,
     __syncthreads();
     WaveCtx w;
     int64_t stride;
-    wave_setup<false>(w, smem, kSamplesPerWave, stride);
+    wave_setup<1>(w, smem, kSamplesPerWave, stride);
     w.bias_glb = bias;
     w.block = 0;
     w.masks = nullptr;
@@ -914,7 +922,7 @@ focus_fused_kernel(const ffn_mlp_chain ch, const float* __restrict__ packed_w,
             w.x2 = mul_add_rn(t, dz, sz);
             w.v0 = dx; w.v1 = dy; w.v2 = dz;
             w.logit[0] = w.logit[1] = w.logit[2] = w.logit[3] = 0.0f;
-            run_chain<kInfer, false>(ch, w, packed_w, nullptr);
+            run_chain<kInfer, 1>(ch, w, packed_w, nullptr);
             const float out = w.logit[3] + __shfl_xor(w.logit[3], 32);
             if (w.h == hb) sigma_logit = out;
         }
@@ -935,16 +943,17 @@ focus_fused_kernel(const ffn_mlp_chain ch, const float* __restrict__ packed_w,
 
 // Backward-data chain: consumes d_logits (N,4) and the saved forward activations, writes
 // dZ of every hidden layer (block layout) for the weight-gradient kernel.
-template <bool WIDE>
+template <int TWP>
 __global__ void __launch_bounds__(256, 1)
 mlp_backward_data_kernel(const ffn_mlp_chain ch, const float* __restrict__ packed_wt,
                          const float* __restrict__ d_logits, int64_t n,
                          uint32_t* __restrict__ masks, float* __restrict__ dz, int64_t slab_block0,
                          int64_t slab_blocks) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr bool WIDE = TWP > 1;
     WaveCtx w;
     int64_t stride;
-    wave_setup<WIDE>(w, smem, n, stride);
+    wave_setup<TWP>(w, smem, n, stride);
     w.bias_glb = nullptr;              // (a backward chain has no biases)
     if (slab_blocks > 0) { w.slab_block0 = slab_block0; w.slab_blocks = slab_blocks; }
     w.masks = reinterpret_cast<uint4*>(masks);
@@ -969,7 +978,7 @@ mlp_backward_data_kernel(const ffn_mlp_chain ch, const float* __restrict__ packe
         }
         w.dl = dl_next;
         request_dl(first + (pass + 1) * stride);
-        run_chain<kBackward, WIDE>(ch, w, packed_wt, dz);
+        run_chain<kBackward, TWP>(ch, w, packed_wt, dz);
         if (!WIDE) w.block += stride;
     }
 }
@@ -1001,9 +1010,11 @@ static int validate_chain(const ffn_mlp_chain* ch, bool backward, bool train = f
     if (ch == nullptr || ch->num_steps < 1 || ch->num_steps > FFN_MAX_STEPS) return 1;
     if (ch->bias_floats < 0) return 1;
     const bool wide = ch->wide != 0;
+    const bool quad = ch->wide == 2;       // four waves per block: narrow chains of >= 128 channels
     for (int i = 0; i < ch->num_steps; ++i) {
         const ffn_step& L = ch->step[i];
         const int ot = L.out_tiles;
+        if (quad && (!(ot == 4 || ot == 8) || L.act_groups > 32 || L.dst != 0)) return 1;
         if (wide ? !(ot == 2 || ot == 4 || ot == 8 || ot == 16) : !(ot == 1 || ot == 2 || ot == 4 || ot == 8)) return 1;
         if (L.act_groups < 0 || L.aux_groups < 0 || L.act_groups > (wide ? 64 : 32)) return 1;
         if ((L.act_groups & 3) || (L.aux_groups & 3) || L.act_groups + L.aux_groups == 0) return 1;
@@ -1050,15 +1061,15 @@ static void allow_big_lds(K kernel, size_t bytes = kLdsBytes) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-template <int MODE, bool WIDE>
+template <int MODE, int TWP>
 static void launch_forward(const ffn_mlp_chain* chain, const float* packed_w, const float* bias,
                            const float* positions, const float* views, int64_t n, float* logits,
                            float* saved, uint32_t* masks, int64_t slab_block0, int64_t slab_blocks,
                            void* stream) {
     const int64_t blocks32 = (n + kSamplesPerWave - 1) / kSamplesPerWave;
-    const int64_t grid = persistent_grid(blocks32, WIDE ? 2 : kWavesPerBlock);
-    allow_big_lds(&mlp_forward_kernel<MODE, WIDE>);
-    hipLaunchKernelGGL((mlp_forward_kernel<MODE, WIDE>), dim3((unsigned)grid), dim3(256), kLdsBytes,
+    const int64_t grid = persistent_grid(blocks32, kWavesPerBlock / TWP);
+    allow_big_lds(&mlp_forward_kernel<MODE, TWP>);
+    hipLaunchKernelGGL((mlp_forward_kernel<MODE, TWP>), dim3((unsigned)grid), dim3(256), kLdsBytes,
                        (hipStream_t)stream, *chain, packed_w, bias, positions, views, n, logits, saved,
                        masks, slab_block0, slab_blocks);
 }
@@ -1075,12 +1086,15 @@ extern "C" int ffn_mlp_forward(const ffn_mlp_chain* chain, const float* packed_w
     if (slab_blocks != 0 && (slab_block0 < 0 || slab_block0 + (n + 31) / 32 > slab_blocks))
         return fail_arg("ffn_mlp_forward: the launch's blocks must lie inside [0, slab_blocks)");
     const bool train = saved != nullptr;
-    if (chain->wide) {
-        if (train) launch_forward<kTrainFwd, true>(chain, packed_w, bias, positions, views, n, logits, saved, masks, slab_block0, slab_blocks, stream);
-        else launch_forward<kInfer, true>(chain, packed_w, bias, positions, views, n, logits, saved, masks, slab_block0, slab_blocks, stream);
+    if (chain->wide == 2) {            // four waves per block: training launches (a batch's short last round)
+        if (!train) return fail_arg("ffn_mlp_forward: four-waves-per-block chains (wide == 2) are training-only");
+        launch_forward<kTrainFwd, 4>(chain, packed_w, bias, positions, views, n, logits, saved, masks, slab_block0, slab_blocks, stream);
+    } else if (chain->wide) {
+        if (train) launch_forward<kTrainFwd, 2>(chain, packed_w, bias, positions, views, n, logits, saved, masks, slab_block0, slab_blocks, stream);
+        else launch_forward<kInfer, 2>(chain, packed_w, bias, positions, views, n, logits, saved, masks, slab_block0, slab_blocks, stream);
     } else {
-        if (train) launch_forward<kTrainFwd, false>(chain, packed_w, bias, positions, views, n, logits, saved, masks, slab_block0, slab_blocks, stream);
-        else launch_forward<kInfer, false>(chain, packed_w, bias, positions, views, n, logits, saved, masks, slab_block0, slab_blocks, stream);
+        if (train) launch_forward<kTrainFwd, 1>(chain, packed_w, bias, positions, views, n, logits, saved, masks, slab_block0, slab_blocks, stream);
+        else launch_forward<kInfer, 1>(chain, packed_w, bias, positions, views, n, logits, saved, masks, slab_block0, slab_blocks, stream);
     }
     return check_launch("ffn_mlp_forward");
 }
@@ -1149,14 +1163,14 @@ extern "C" int ffn_focus_fused(const ffn_mlp_chain* chain, const float* packed_w
     return check_launch("ffn_focus_fused");
 }
 
-template <bool WIDE>
+template <int TWP>
 static void launch_backward(const ffn_mlp_chain* chain, const float* packed_wt, const float* d_logits,
                             int64_t n, uint32_t* masks, float* dz, int64_t slab_block0,
                             int64_t slab_blocks, void* stream) {
     const int64_t blocks32 = (n + kSamplesPerWave - 1) / kSamplesPerWave;
-    const int64_t grid = persistent_grid(blocks32, WIDE ? 2 : kWavesPerBlock);
-    allow_big_lds(&mlp_backward_data_kernel<WIDE>);
-    hipLaunchKernelGGL((mlp_backward_data_kernel<WIDE>), dim3((unsigned)grid), dim3(256), kLdsBytes,
+    const int64_t grid = persistent_grid(blocks32, kWavesPerBlock / TWP);
+    allow_big_lds(&mlp_backward_data_kernel<TWP>);
+    hipLaunchKernelGGL((mlp_backward_data_kernel<TWP>), dim3((unsigned)grid), dim3(256), kLdsBytes,
                        (hipStream_t)stream, *chain, packed_wt, d_logits, n, masks, dz, slab_block0, slab_blocks);
 }
 
@@ -1168,7 +1182,8 @@ extern "C" int ffn_mlp_backward_data(const ffn_mlp_chain* chain, const float* pa
     if (n < 0 || validate_chain(chain, true)) return fail_arg("ffn_mlp_backward_data: bad chain or size");
     if (slab_blocks != 0 && (slab_block0 < 0 || slab_block0 + (n + 31) / 32 > slab_blocks))
         return fail_arg("ffn_mlp_backward_data: the launch's blocks must lie inside [0, slab_blocks)");
-    if (chain->wide) launch_backward<true>(chain, packed_wt, d_logits, n, masks, dz, slab_block0, slab_blocks, stream);
-    else launch_backward<false>(chain, packed_wt, d_logits, n, masks, dz, slab_block0, slab_blocks, stream);
+    if (chain->wide == 2) launch_backward<4>(chain, packed_wt, d_logits, n, masks, dz, slab_block0, slab_blocks, stream);
+    else if (chain->wide) launch_backward<2>(chain, packed_wt, d_logits, n, masks, dz, slab_block0, slab_blocks, stream);
+    else launch_backward<1>(chain, packed_wt, d_logits, n, masks, dz, slab_block0, slab_blocks, stream);
     return check_launch("ffn_mlp_backward_data");
 }

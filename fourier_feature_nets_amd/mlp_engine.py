@@ -51,12 +51,15 @@ if os.environ.get("FFN_UNIT_COST"):       # "full,half,quarter,head" -- calibrat
 
 # A training launch whose block count leaves the persistent grid a short last round (every one of
 # the 4 x CUs resident wavefronts owns whole 32-sample blocks, so 3.1 blocks per wavefront cost 4
-# rounds) is split: the full rounds on the one-wave-per-block kernels, the remainder on the
-# two-waves-per-block ("wide") kernels, whose round takes ~0.57 of the time.  At the reference's
-# default batch (1024 rays x 128 samples, ~3170 blocks) that is 3.57 instead of 4 rounds for the
-# forward and backward-data kernels.  Training launches only (inference keeps its bit-exact
-# batch independence: the two kernels sum a fused head's partial products in different orders).
+# rounds) is split: the full rounds on the one-wave-per-block kernels, the remainder on kernels
+# that put a TEAM of waves on a block -- four waves per block (one team per CU: a round takes ~0.3
+# of the time) when the remainder is at most one block per CU, else two waves per block (~0.57)
+# when it is at most half a round.  At the reference's default batch (1024 rays x 128 samples,
+# ~3170 blocks = 3 rounds + 98 blocks) that is 3.3 instead of 4 rounds for the forward and
+# backward-data kernels.  Training launches only (inference keeps its bit-exact batch
+# independence: the team kernels sum a fused head's partial products in different orders).
 TAIL_PAIRS = os.environ.get("FFN_TAIL_PAIRS", "1") == "1"
+TAIL_QUADS = os.environ.get("FFN_TAIL_QUADS", "1") == "1"
 TAIL_MAX_FULL_ROUNDS = 16       # beyond that the tail is < 3 % of the launch
 
 
@@ -455,20 +458,27 @@ class MlpProgram:
         self.bias_buf = torch.zeros((b_off,), dtype=torch.float32, device=self.device)
 
     def _build_pair_chains(self):
-        """Copies of the forward / backward-data chains flagged for the two-waves-per-block
-        kernels (same operand packs, same slabs), for chains those kernels accept: every logits
-        head fused, every step 64..256 channels wide."""
-        ok = not self.wide
+        """Copies of the forward / backward-data chains flagged for the team kernels -- two waves
+        per block (``wide = 1``) and four waves per block (``wide = 2``) -- on the same operand
+        packs and slabs, for chains those kernels accept: every logits head fused, every step
+        64..256 (four waves: 128..256) channels wide."""
+        ok = quad = not self.wide
         for chain in (self.fwd, self.bwd):
             for k in range(chain.num_steps):
                 st = chain.step[k]
                 ok = ok and st.out_tiles in (2, 4, 8) and st.dst == 0
+                quad = quad and st.out_tiles in (4, 8) and st.dst == 0
         self.pair_chain_ok = bool(ok and self.bwd.num_steps > 0)
-        self.fwd_pair = self.bwd_pair = None
+        self.quad_chain_ok = bool(quad and self.pair_chain_ok and TAIL_QUADS)
+        self.fwd_pair = self.bwd_pair = self.fwd_quad = self.bwd_quad = None
         if self.pair_chain_ok:
             self.fwd_pair = FfnMlpChain.from_buffer_copy(bytes(self.fwd))
             self.bwd_pair = FfnMlpChain.from_buffer_copy(bytes(self.bwd))
             self.fwd_pair.wide = self.bwd_pair.wide = 1
+        if self.quad_chain_ok:
+            self.fwd_quad = FfnMlpChain.from_buffer_copy(bytes(self.fwd))
+            self.bwd_quad = FfnMlpChain.from_buffer_copy(bytes(self.bwd))
+            self.fwd_quad.wide = self.bwd_quad.wide = 2
 
     def _build_forward16(self):
         """Chain + operand buffer of the OPT-IN split-bf16 kernels (mlp_bf16.hip, mlp_bf16_ws.hip):
@@ -868,20 +878,28 @@ class MlpProgram:
         return self._waves
 
     def _tail_mask_floats(self) -> int:
+        """Mask region of a launch's tail: 512 words per slot and block on wave pairs (at most
+        waves / 2 blocks), 1024 on quads (at most waves / 4): the same size."""
         if not (TAIL_PAIRS and self.pair_chain_ok) or self.device.type != "cuda":
             return 0
         return self.fwd.num_slots * 512 * (self._resident_waves() // 2)
 
-    def _tail_split(self, n: int) -> Optional[int]:
-        """Blocks the one-wave-per-block launch keeps when the rest goes to the wave-pair
-        kernels, or None: at least one full round, a remainder of at most half a round."""
+    def _tail_plan(self, n: int):
+        """(blocks the one-wave-per-block launch keeps, waves per block of the tail kernels: 2 | 4),
+        or None: at least one full round, a remainder of at most half a round."""
         if not (TAIL_PAIRS and self.pair_chain_ok):
             return None
         blocks = (n + 31) // 32
-        full, rest = divmod(blocks, self._resident_waves())
-        if full < 1 or full > TAIL_MAX_FULL_ROUNDS or rest == 0 or 2 * rest > self._resident_waves():
+        waves = self._resident_waves()
+        full, rest = divmod(blocks, waves)
+        if full < 1 or full > TAIL_MAX_FULL_ROUNDS or rest == 0 or 2 * rest > waves:
             return None
-        return full * self._resident_waves()
+        team = 4 if (self.quad_chain_ok and 4 * rest <= waves) else 2
+        return full * waves, team
+
+    def _tail_split(self, n: int) -> Optional[int]:
+        plan = self._tail_plan(n)
+        return None if plan is None else plan[0]
 
     def _tail_masks(self, saved: torch.Tensor, n: int) -> torch.Tensor:
         blocks = (n + 31) // 32
@@ -900,7 +918,7 @@ class MlpProgram:
             # what `backward` must match: the f32 forward writes the tail blocks' sign masks into
             # their own region when the launch is split (`_tail_split`), the split-bf16 kernels
             # know one mask region only
-            split = self._tail_split(n) if precision == "f32" else None
+            split = self._tail_plan(n) if precision == "f32" else None
             self._fwd_record = (saved.data_ptr(), n, precision, split)
         if precision == "bf16x3":
             if saved is None:
@@ -916,22 +934,25 @@ class MlpProgram:
             return logits
         if precision != "f32":
             raise ValueError("precision is 'f32' or 'bf16x3'")
-        head = None if saved is None else self._tail_split(n)
+        plan = None if saved is None else self._tail_plan(n)
+        head = None if plan is None else plan[0]
         if head is None:
             _call("ffn_mlp_forward", ctypes.byref(self.fwd), _dev(self.packed_fwd),
                   _dev(self.bias_buf), _dev(positions, name="positions"),
                   _dev(views, name="views"), c_i64(n), _dev(logits), _dev(acts), _dev(masks),
                   c_i64(0), c_i64(0))
             return logits
-        # full rounds on the one-wave-per-block kernel, the short last round on wave pairs; both
-        # write the batch's slabs (block ids of the whole batch), each its own mask region
+        # full rounds on the one-wave-per-block kernel, the short last round on teams of two / four
+        # waves per block; both write the batch's slabs (block ids of the whole batch), each its
+        # own mask region
+        tail_chain = self.fwd_quad if plan[1] == 4 else self.fwd_pair
         blocks, cut = (n + 31) // 32, head * 32
         v_head = None if views is None else views[:cut]
         v_tail = None if views is None else views[cut:]
         _call("ffn_mlp_forward", ctypes.byref(self.fwd), _dev(self.packed_fwd), _dev(self.bias_buf),
               _dev(positions[:cut], name="positions"), _dev(v_head, name="views"), c_i64(cut),
               _dev(logits[:cut]), _dev(acts), _dev(masks), c_i64(0), c_i64(blocks))
-        _call("ffn_mlp_forward", ctypes.byref(self.fwd_pair), _dev(self.packed_fwd), _dev(self.bias_buf),
+        _call("ffn_mlp_forward", ctypes.byref(tail_chain), _dev(self.packed_fwd), _dev(self.bias_buf),
               _dev(positions[cut:], name="positions"), _dev(v_tail, name="views"), c_i64(n - cut),
               _dev(logits[cut:]), _dev(acts), _dev(self._tail_masks(saved, n)), c_i64(head),
               c_i64(blocks))
@@ -1018,7 +1039,7 @@ class MlpProgram:
             return grads.zero_()
         record = getattr(self, "_fwd_record", None)
         if record is not None and record[0] == saved.data_ptr() and record[1] == n:
-            split = self._tail_split(n) if precision == "f32" else None
+            split = self._tail_plan(n) if precision == "f32" else None
             if record[2] != precision or record[3] != split:
                 raise RuntimeError("MlpProgram.backward: `saved` was filled by a %s forward (tail "
                                    "split %s) but the backward was asked for %s (tail split %s)"
@@ -1035,16 +1056,18 @@ class MlpProgram:
                   _dev(self.packed16_bwd, torch.int16), _dev(d_logits), c_i64(n), _dev(masks),
                   _dev(ws.dz))
         elif self.bwd.num_steps > 0:
-            head = self._tail_split(n) if precision == "f32" else None
+            plan = self._tail_plan(n) if precision == "f32" else None
+            head = None if plan is None else plan[0]
             if head is None:
                 _call("ffn_mlp_backward_data", ctypes.byref(self.bwd), _dev(self.packed_bwd),
                       _dev(d_logits), c_i64(n), _dev(masks), _dev(ws.dz), c_i64(0), c_i64(0))
             else:           # the split of the matching forward call
+                tail_chain = self.bwd_quad if plan[1] == 4 else self.bwd_pair
                 blocks, cut = (n + 31) // 32, head * 32
                 _call("ffn_mlp_backward_data", ctypes.byref(self.bwd), _dev(self.packed_bwd),
                       _dev(d_logits[:cut]), c_i64(cut), _dev(masks), _dev(ws.dz), c_i64(0),
                       c_i64(blocks))
-                _call("ffn_mlp_backward_data", ctypes.byref(self.bwd_pair), _dev(self.packed_bwd),
+                _call("ffn_mlp_backward_data", ctypes.byref(tail_chain), _dev(self.packed_bwd),
                       _dev(d_logits[cut:]), c_i64(n - cut), _dev(self._tail_masks(whole, n)),
                       _dev(ws.dz), c_i64(head), c_i64(blocks))
         _call("ffn_mlp_wgrad_units_bf16x3" if wgrad16 else "ffn_mlp_wgrad_units",

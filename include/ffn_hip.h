@@ -273,11 +273,18 @@ typedef struct ffn_mlp_chain {
                                               first 4096 floats in LDS; every head block must lie
                                               inside that copy, a step bias beyond it is read
                                               from global memory                              */
-    int32_t wide;                          /* != 0: some layer is wider than 256 channels:
-                                              two waves share a 32-sample block and a 64 KiB
-                                              slab, out_tiles may be 16 and must be even,
-                                              act_groups <= 64, heads must be fused; the mask
-                                              buffer holds 512 uint32 per slot and block     */
+    int32_t wide;                          /* waves per 32-sample block of the exact-f32 chain
+                                              kernels.  0: one.  1: TWO waves share a block and a
+                                              64 KiB slab (required when some layer is wider than
+                                              256 channels: out_tiles may be 16 and must be even,
+                                              act_groups <= 64, heads must be fused); the mask
+                                              buffer holds 512 uint32 per slot and block.  2: FOUR
+                                              waves share a block (one team per workgroup; narrow
+                                              chains whose steps have 4 or 8 output tiles, heads
+                                              fused; training / backward launches only): 1024
+                                              uint32 of masks per slot and block.  The host runs
+                                              the short last round of a training launch on the
+                                              team kernels (same packs, same slabs)            */
     int32_t slot_channels[FFN_MAX_STEPS];  /* channels of each slab (multiple of 32)  */
     int64_t slot_offset[FFN_MAX_STEPS];    /* sum of channels of the slabs before it  */
 } ffn_mlp_chain;

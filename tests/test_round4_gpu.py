@@ -382,3 +382,62 @@ def test_split_bf16_mode_on_512_wide_chains(golden, kind):
         # mode the difference is ReLU decisions of near-zero pre-activations that fall the other
         # way in the split forward -- 1.1e-2 for the sigma = 10 Gaussian features, 512 wide)
         assert float((g32 - g16).norm()) <= 3e-2 * float(g32.norm()) + 1e-7
+
+
+# ----------------------------------------------------------------------------------- short last round on teams
+@pytest.mark.parametrize("name,rest", [("positional", 77), ("nerf", 77), ("positional", 256), ("positional", 300)])
+def test_tail_of_a_training_launch_on_four_waves_per_block(golden, name, rest):
+    """The short last round of a training launch runs on FOUR waves per block (one team per CU,
+    `ffn_mlp_chain.wide == 2`) when the remainder is at most one block per CU, on wave pairs up to
+    half a round (mlp_engine._tail_plan).  Against the unsplit launch on the same inputs: every
+    saved activation and dZ slab bit for bit, the head part's logits bit for bit, the tail's logits
+    within 2e-6 (a fused head's partial products meet per wave, then over the team), gradients
+    within 2e-6 of their scale -- for the quad kernels and, on the same remainder, the pair kernels."""
+    from fourier_feature_nets_amd import mlp_engine
+    from tests.test_kernels_gpu import _load_fourier, _load_nerf
+    g = golden("models")
+    if name == "nerf":
+        model, _ = _load_nerf(g, name, [4], True)
+    else:
+        model, _ = _load_fourier(g, name)
+    prog = model.program()
+    waves = prog._resident_waves()
+    n = 32 * (waves + rest) - 9
+    assert prog.quad_chain_ok
+    expected_team = 4 if 4 * rest <= waves else 2
+    assert prog._tail_plan(n) == (waves, expected_team)
+    gen = torch.Generator(device=dev()).manual_seed(7)
+    x = torch.rand((n, 3), generator=gen, device=dev()) * 2 - 1
+    v = torch.nn.functional.normalize(torch.randn((n, 3), generator=gen, device=dev()), dim=1) if name == "nerf" else None
+    d_logits = torch.randn((n, 4), generator=gen, device=dev()) / n
+
+    def run():
+        saved = torch.zeros((prog.saved_floats(n),), dtype=torch.float32, device=dev())
+        logits = prog.forward(x, v, saved)
+        grads = torch.zeros((prog.num_grad_floats,), dtype=torch.float32, device=dev())
+        prog.workspace(n).dz.zero_()
+        prog.backward(d_logits, x, v, saved, grads)
+        acts, _ = prog._split_saved(saved, n)
+        return logits, acts.clone(), prog.workspace(n).dz.clone(), grads
+
+    out = {}
+    try:
+        out["default"] = run()
+        prog.quad_chain_ok = False                 # the same remainder on wave pairs
+        assert prog._tail_plan(n) == (waves, 2)
+        out["pairs"] = run()
+        mlp_engine.TAIL_PAIRS = False              # the unsplit launch
+        assert prog._tail_plan(n) is None
+        out["whole"] = run()
+    finally:
+        mlp_engine.TAIL_PAIRS = True
+        prog.quad_chain_ok = True
+    lw, aw, dw, gw = out["whole"]
+    scale, gs = max(1.0, float(lw.abs().max())), float(gw.abs().max())
+    for key in ("default", "pairs"):
+        l, a, d, gr = out[key]
+        assert torch.equal(a, aw), (key, "saved activations")
+        assert torch.equal(d, dw), (key, "dZ slabs")
+        assert torch.equal(l[:32 * waves], lw[:32 * waves]), key
+        assert float((l - lw).abs().max()) <= 2e-6 * scale, key
+        assert gs > 0 and float((gr - gw).abs().max()) <= 2e-6 * gs, key
