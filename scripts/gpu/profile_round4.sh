@@ -47,6 +47,24 @@ for rep in range(2):
 print(json.dumps(out, indent=1))
 PY
 python scripts/microbench_hbm.py > $OUT/hbm_microbench.json 2> $OUT/hbm_microbench.err
+# kernel timeline of one optimisation step at the reference's default batch (1024 x 128, tiny NeRF)
+rocprofv3 --kernel-trace --stats -d $OUT/small -o small --output-format csv -- python scripts/probes/default_batch.py tiny 200 > $OUT/small.log 2>&1
+python - <<'PY' > gpurun_out/prof4/r04_default_batch_timeline.txt
+import csv, glob
+f = [p for p in glob.glob("gpurun_out/prof4/small/**/*kernel_trace.csv", recursive=True)][0]
+rows = list(csv.DictReader(open(f)))
+names = [r["Kernel_Name"].split("(")[0] for r in rows]
+idx = [i for i, n in enumerate(names) if "norm_adam" in n]
+i0, i1 = idx[100], idx[101]
+t0 = int(rows[i0]["End_Timestamp"])
+print("# one optimisation step at the reference's default batch (1024 rays x 128 samples, tiny NeRF): rocprofv3 --kernel-trace timeline")
+print("# (scripts/gpu/profile_round4.sh; ideal at the large-batch rate: forward 428, backward data 206, weight gradients 384 us)")
+print("--- one default-batch step (us since previous step's Adam end): start, duration, kernel")
+for r in rows[i0 + 1:i1 + 1]:
+    print("%9.1f %8.2f  %s" % ((int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, r["Kernel_Name"].split("(")[0][:80]))
+PY
+rm -rf $OUT/small
+cat $OUT/r04_default_batch_timeline.txt | tail -22
 rm -f $OUT/*_kernel_trace.csv $OUT/*counter_collection.csv
 ls $OUT | head -50
 head -8 $OUT/r04_kernel_stats_stats.csv; head -6 $OUT/r04_kernel_stats_northstar.csv; head -6 $OUT/r04_kernel_stats_config5.csv; head -9 $OUT/r04_kernel_stats_train.csv

@@ -441,3 +441,48 @@ def test_tail_of_a_training_launch_on_four_waves_per_block(golden, name, rest):
         assert torch.equal(l[:32 * waves], lw[:32 * waves]), key
         assert float((l - lw).abs().max()) <= 2e-6 * scale, key
         assert gs > 0 and float((gr - gw).abs().max()) <= 2e-6 * gs, key
+
+
+# ----------------------------------------------------------------------------------- the reference's own fit, several seeds
+def test_fit_against_the_references_own_fit_small_ensemble(tmp_path):
+    """Short version of tests/psnr_ensemble.py: the REFERENCE's `Raycaster.fit` (run in the build
+    container from /root/reference; only its per-seed PSNR curves are committed:
+    tests/golden/psnr_ensemble_reference_small.json) against this package's `fit` under the same
+    protocol -- 3 seeds x 60 steps of the tiny NeRF on a 12 + 2 camera 64x64 scene, crop phase,
+    annealed stratified sampling, seed k fixing the initial weights, the epoch permutations
+    (np.random) and the jitter (the CPU generator: `noise_source = "host"`).  At 60 steps the
+    trajectories have not decorrelated yet: every report of every seed within 0.05 dB -- BASELINE's
+    bound -- and the ensemble means within 0.02 dB."""
+    import argparse
+    import json
+    from tests import psnr_ensemble
+    import fourier_feature_nets_amd as ffn
+    with open(os.path.join(GOLDEN, "psnr_ensemble_reference_small.json")) as f:
+        ref = json.load(f)
+    proto = ref["protocol"]
+    args = argparse.Namespace(seeds=3, steps=proto["steps"], rays=proto["rays_per_step"],
+                              samples=proto["samples_per_ray"], size=64, cameras=12, val_cameras=2,
+                              crop_steps=proto["crop_steps"], report_interval=proto["report_interval"],
+                              anneal_steps=proto["num_anneal_steps"], workdir=str(tmp_path), resume=False)
+    assert psnr_ensemble.protocol_of(args) == proto
+    real_load = ffn.ImageDataset.load
+
+    def load_with_host_noise(*a, **k):
+        ds = real_load(*a, **k)
+        ds.sampler.noise_source = "host"       # consume the CPU generator like the reference
+        return ds
+
+    ffn.ImageDataset.load = staticmethod(load_with_host_noise)
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            doc = psnr_ensemble.run_protocol(ffn, args, dev(), str(tmp_path / "hip.json"), "hip")
+    finally:
+        ffn.ImageDataset.load = staticmethod(real_load)
+    worst = 0.0
+    for mine, theirs in zip(doc["runs"], ref["runs"]):
+        assert mine["seed"] == theirs["seed"]
+        assert [r["step"] for r in mine["reports"]] == [r["step"] for r in theirs["reports"]]
+        for a, b in zip(mine["reports"], theirs["reports"]):
+            worst = max(worst, abs(a["val_psnr"] - b["val_psnr"]), abs(a["train_psnr"] - b["train_psnr"]))
+    assert worst < 0.05, worst
+    assert abs(doc["final_val_psnr"]["mean"] - ref["final_val_psnr"]["mean"]) < 0.02
