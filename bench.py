@@ -40,9 +40,11 @@ TRAFFIC_PROFILE = "profiles/r04_hbm_traffic.json"
 KERNEL_OF = {"ffn_mlp_forward": "mlp_forward_kernel<train>",
              "ffn_mlp_backward_data": "mlp_backward_data_kernel",
              "ffn_mlp_wgrad_units": "wgrad_unit_kernel"}
-SYMBOL_OF = {"mlp_forward_kernel<train>": "ffn::mlp_forward_kernel<1, false>",
-             "mlp_backward_data_kernel": "ffn::mlp_backward_data_kernel<false>",
-             "wgrad_unit_kernel": "ffn::wgrad_unit_kernel"}
+# (kernel symbols as rocprofv3 prints them; the second template argument of the chain kernels is
+# the number of waves per block: round 3's profiles call the same kernels <1, false> / <false>)
+SYMBOL_OF = {"mlp_forward_kernel<train>": ("ffn::mlp_forward_kernel<1, 1>", "ffn::mlp_forward_kernel<1, false>"),
+             "mlp_backward_data_kernel": ("ffn::mlp_backward_data_kernel<1>", "ffn::mlp_backward_data_kernel<false>"),
+             "wgrad_unit_kernel": ("ffn::wgrad_unit_kernel",)}
 
 
 def parse_args():
@@ -314,7 +316,10 @@ def traffic_of(kernel_name, args):
     source["profiled_commit"] = doc.get("commit")
     if doc.get("config") != {"rays": args.rays, "samples": args.samples} or args.model != "tiny":
         return None, source
-    return doc["kernels"].get(SYMBOL_OF[kernel_name], {}).get("hbm_bytes"), source
+    for symbol in SYMBOL_OF[kernel_name]:
+        if symbol in doc["kernels"]:
+            return doc["kernels"][symbol].get("hbm_bytes"), source
+    return None, source
 
 
 def target_shape_leg(device):
@@ -763,9 +768,10 @@ def bf16_train_leg(device, dataset, rays_per_step, samples, steps=6):
             "first_step_gradient_max_abs_error": err, "first_step_gradient_max_abs": scale,
             "first_step_gradient_relative_l2_error": rel_l2,
             "loss_after_%d_steps" % (steps + 2): losses,
-            "bound": "instruction issue of one in-order wave per SIMD (matrix + conversion + staging "
-                     "instructions in sequence), not HBM: 74 GB per step at ~3.6 TB/s average where the "
-                     "kernels' own staging pattern streams 7.2 TB/s (DESIGN: split-bf16 section)"}
+            "bound": "forward / backward data (two waves per SIMD, mlp_bf16_ws.hip): matrix pipe busy "
+                     "0.43-0.53 at a power-limited 1.8-1.9 GHz, phases separated by workgroup barriers and "
+                     "bursts of slab stores; weight gradients: instruction issue and the 39 GB they read "
+                     "(DESIGN: split-bf16 sections)"}
 
 
 def render_leg(args, caster, sampler, world, rank, barrier):
