@@ -150,6 +150,34 @@ def test_chain_and_wgrad_plans(make):
         assert len(plan["unit_starts"]) == 257 and plan["unit_starts"][-1] == len(plan["unit_segments"])
 
 
+def test_tail_plan_of_a_training_launch():
+    """Which kernels run a launch's short last round (mlp_engine._tail_plan): four waves per block
+    while the remainder is at most one block per CU, wave pairs up to half a round, nothing for
+    exact rounds / long remainders / tiny or huge launches; chains with a 64-wide step have no
+    quad kernels, 512-wide chains no team tail at all."""
+    prog = _plan(ffn.PositionalFourierMLP(3, 4, 5.5))
+    prog._waves = 1024                                  # 256 CUs x 4 resident wavefronts
+    assert prog.pair_chain_ok and prog.quad_chain_ok
+    blocks = lambda k: 32 * k                            # noqa: E731
+    assert prog._tail_plan(blocks(3 * 1024 + 98)) == (3072, 4)      # the reference's default batch
+    assert prog._tail_plan(blocks(1024 + 256)) == (1024, 4)
+    assert prog._tail_plan(blocks(1024 + 257)) == (1024, 2)
+    assert prog._tail_plan(blocks(1024 + 512)) == (1024, 2)
+    assert prog._tail_plan(blocks(1024 + 513)) is None
+    assert prog._tail_plan(blocks(2048)) is None and prog._tail_plan(blocks(700)) is None
+    assert prog._tail_plan(blocks(17 * 1024 + 5)) is None
+    assert prog._tail_split(blocks(3 * 1024 + 98) - 7) == 3072     # (ragged last block)
+    narrow = _plan(ffn.NeRF(4, 64, 5, 6, 2, 3, [2], False))       # hidden_view: 32 channels = 1 tile
+    narrow._waves = 1024
+    assert not narrow.pair_chain_ok and narrow._tail_plan(blocks(1024 + 98)) is None
+    mid = _plan(ffn.MLP(3, 4, num_channels=64))
+    mid._waves = 1024
+    assert mid.pair_chain_ok and not mid.quad_chain_ok and mid._tail_plan(blocks(1024 + 98)) == (1024, 2)
+    wide = _plan(ffn.GaussianFourierMLP(3, 4, 10.0, num_channels=512))
+    wide._waves = 1024
+    assert wide._tail_plan(blocks(1024 + 98)) is None
+
+
 def test_unsupported_shapes_raise_not_fall_back():
     with pytest.raises(NotImplementedError):
         _plan(ffn.GaussianFourierMLP(3, 4, 10.0, num_channels=1024))
