@@ -598,8 +598,8 @@ def config5_leg(device, bounds, rays_per_step=32768, samples=128, cameras=25, si
                        "exact-f32 MFMA (wide kernels)" % (cameras, size, size, samples, rays_per_step)}
     for label, occ in (("full", None), ("with_occupancy_grid", grid), ("split_bf16_training", None)):
         # (third entry: the OPT-IN split-bf16 training kernels on the same 512-wide model --
-        # two-waves-per-SIMD chain kernels with two output tiles per wave, mlp_bf16_ws.hip; the
-        # weight gradients of a 512-wide model stay on the exact-f32 kernel)
+        # two-waves-per-SIMD chain kernels with two output tiles per wave, mlp_bf16_ws.hip, and
+        # the split-bf16 weight-gradient units, 256 x 256 windows of the 512-wide layers)
         model.train_precision = "bf16x3" if label == "split_bf16_training" else "f32"
         engine = ffn.TrainEngine(model, 0.0, None)
         engine.occupancy = occ
@@ -622,7 +622,7 @@ def config5_leg(device, bounds, rays_per_step=32768, samples=128, cameras=25, si
             timer.close()
         entry = {"step_ms": round(step_ms, 3), "rays_per_s": round(rays_per_step / (step_ms * 1e-3), 1)}
         if label == "split_bf16_training":
-            entry["label"] = ("opt-in split-bf16 forward / backward-data kernels (3 bf16 matrix products "
+            entry["label"] = ("opt-in split-bf16 forward / backward-data / weight-gradient kernels (3 bf16 matrix products "
                               "per f32 product): not the exact-f32 parity mode")
             entry["speedup_vs_exact_f32"] = round(out["full"]["step_ms"] / step_ms, 3)
             model.train_precision = "f32"

@@ -1045,7 +1045,7 @@ class MlpProgram:
                                    "split %s) but the backward was asked for %s (tail split %s)"
                                    % (record[2], record[3], precision, split))
         ws = self.workspace(n)
-        wgrad16 = precision == "bf16x3" and not self.wide
+        wgrad16 = precision == "bf16x3"     # (units are <= 256 x 256 windows at any layer width)
         ws.use_plan("bf16x3" if wgrad16 else "f32")
         whole = saved
         saved, masks = self._split_saved(saved, n)
