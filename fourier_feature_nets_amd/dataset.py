@@ -67,19 +67,27 @@ class RayDataset(ABC):
         return image.cpu().numpy()
 
     def sample_cameras(self, num_cameras: int, num_samples: int, stratified: bool) -> "RayDataset":
-        """Farthest-point subset of the cameras (ray_dataset.py:185-216)."""
+        """Farthest-point subset of the cameras, IN THE REFERENCE'S ORDER (ray_dataset.py:185-216).
+
+        The reference keeps its picks in a Python ``set`` and hands ``list(set)`` to ``subset``:
+        the subset's camera order is the set's iteration order (0, 42, 12, 77, 55, 91, 28 for the
+        100-camera rig of tests/psnr_ensemble.py -- not sorted), and that order decides which
+        pixels of which camera ``Raycaster._validate``'s evenly spaced rays hit, i.e. the
+        ``psnr_train`` column of every report line.  The same container types, element types
+        (0 as an int, every later pick as a numpy integer) and operations are used here so that
+        the order -- and the tie-break among equidistant candidates, which follows the iteration
+        order of the set difference -- is CPython's, as in the reference."""
         if self.num_cameras < num_cameras:
             chosen = list(range(self.num_cameras))
         else:
             pos = np.concatenate([cam.position for cam in self.sampler.cameras])
-            chosen = [0]
-            while len(chosen) < num_cameras:
-                dist = np.square(pos[:, None, :] - pos[None, chosen, :]).sum(-1).min(-1)
-                dist = np.array(dist, np.float32)
-                dist[chosen] = -1
-                rest = [i for i in range(len(pos)) if i not in chosen]
-                chosen.append(rest[int(np.argmax(dist[rest]))])
-            chosen = sorted(chosen)
+            everyone = set(range(len(pos)))
+            picked = set([0])
+            while len(picked) < num_cameras:
+                gap = np.square(pos[:, None, :] - pos[list(picked)][None, :, :]).sum(-1).min(-1)
+                left = np.array(list(everyone - picked))
+                picked.add(left[np.array(gap[left], np.float32).argmax()])
+            chosen = list(picked)
         return self.subset(chosen, num_samples, stratified, self.label)
 
 

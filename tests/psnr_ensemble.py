@@ -82,6 +82,7 @@ def run_protocol(ffn, args, device, out_path, half, extra=None):
             val = ffn.ImageDataset.load(npz, "val", args.samples, True, False, None, 4096, "RGB", **kwargs)
         if device is not None:
             model = model.to(device)
+            model.train_precision = getattr(args, "precision", "f32")
         caster = ffn.Raycaster(model)
         tee = Tee()
         t0 = time.time()
@@ -151,7 +152,7 @@ def run_hip(args):
     with contextlib.suppress(OSError):
         git = open(os.path.join(ROOT, ".git_head")).read().split()[0]
     doc = run_protocol(ffn, args, device, args.out, "hip (fourier_feature_nets_amd, MI355X)",
-                       {"commit": git, "train_precision": "f32"})
+                       {"commit": git, "train_precision": args.precision})
     if args.reference:
         compare(doc, args.reference, args.out)
     return doc
@@ -173,8 +174,15 @@ def compare(doc, reference_path, out_path):
         if mine and theirs:
             curve.append({"step": s, "hip_mean": float(np.mean(mine)), "ref_mean": float(np.mean(theirs)),
                           "delta_db": float(np.mean(mine) - np.mean(theirs))})
+    # the two halves share their seeds (initial weights, permutations, jitter): the per-seed
+    # differences are reported too -- trajectories decorrelate within a few hundred steps, so the
+    # pairing removes little variance; the verdict stays on the unpaired means
+    paired = [x - y for x, y in zip(a["values"], b["values"])]
     doc["against_reference"] = {
         "file": os.path.relpath(reference_path, ROOT), "reference_final": b, "hip_final": a,
+        "per_seed_delta_db": paired,
+        "per_seed_delta_mean_db": float(np.mean(paired)) if paired else None,
+        "per_seed_delta_stderr_db": float(np.std(paired, ddof=1) / np.sqrt(len(paired))) if len(paired) > 1 else None,
         "delta_mean_db": delta, "stderr_of_delta_db": se,
         "within_0p05_db": abs(delta) < 0.05, "within_2_stderr": abs(delta) < 2 * se,
         "protocol_matches": ref["protocol"] == doc["protocol"], "mean_curves": curve,
@@ -204,6 +212,8 @@ def main():
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--workdir", default=os.path.join(os.environ.get("TMPDIR", "/tmp"), "ffn_psnr_ensemble"))
     ap.add_argument("--resume", action="store_true", help="continue an interrupted --out file")
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3"],
+                    help="hip half: training kernels (bf16x3 = the opt-in split-bf16 mode)")
     args = ap.parse_args()
     if args.half == "reference":
         run_reference(args)

@@ -400,3 +400,27 @@ def test_host_ycrcb_conversion_equals_the_oracle():
     assert check_color_space("YCrCb") == "YCrCb"
     with pytest.raises(NotImplementedError):
         check_color_space("HSV")
+
+
+def test_sample_cameras_keeps_the_reference_order():
+    """`RayDataset.sample_cameras` against the subsets the REFERENCE's own method picked
+    (tests/golden/camera_subsets.json, written by make_camera_subsets.py from
+    ray_dataset.py:185-216): the reference iterates a Python set, so the ORDER of the subset --
+    which decides the pixels `_validate` draws for the psnr_train column -- is not sorted
+    (0, 42, 12, 77, 55, 91, 28 on the 100-camera PSNR rig); rings hold many equidistant ties."""
+    import json
+    from types import SimpleNamespace
+    from tests.golden.make_camera_subsets import rig_positions
+    with open(os.path.join(os.path.dirname(__file__), "golden", "camera_subsets.json")) as f:
+        cases = json.load(f)["cases"]
+    assert len(cases) >= 8
+    unsorted = 0
+    for case in cases:
+        pos = rig_positions(case["rig"], case["cameras"], case["seed"])
+        cams = [SimpleNamespace(position=p[None, :]) for p in pos]
+        stand_in = SimpleNamespace(num_cameras=case["cameras"], sampler=SimpleNamespace(cameras=cams),
+                                   label="x", subset=lambda cameras, *_: [int(c) for c in cameras])
+        chosen = ffn.RayDataset.sample_cameras(stand_in, case["pick"], 64, False)
+        assert chosen == case["chosen"], (case, chosen)
+        unsorted += chosen != sorted(chosen)
+    assert unsorted >= 4
