@@ -486,3 +486,72 @@ def test_fit_against_the_references_own_fit_small_ensemble(tmp_path):
             worst = max(worst, abs(a["val_psnr"] - b["val_psnr"]), abs(a["train_psnr"] - b["train_psnr"]))
     assert worst < 0.05, worst
     assert abs(doc["final_val_psnr"]["mean"] - ref["final_val_psnr"]["mean"]) < 0.02
+
+
+# ----------------------------------------------------------------------------------- fit across the crop removal
+def test_fit_schedule_across_the_crop_removal(tmp_path):
+    """`Raycaster.fit` replayed ACROSS the removal of the centre crop against the reference's own
+    run (tests/golden/fit_schedule.npz from make_fit_schedule.py; ray_caster.py:301-370): 15
+    optimiser steps on a 20 + 10 camera 128x128 rig with crop_steps = 5 -- at the report of step 5
+    the reference prints "Removing center crop...", puts the three datasets back into Full mode,
+    advances the step and abandons the epoch for a fresh permutation.  Every training batch (the
+    dataset indices, in order) must equal the reference's EXACTLY; losses to 3e-4 relative, the
+    psnr_train / val_psnr columns to 5e-3 dB (the trainval subset in the reference's camera
+    order), final weights to 2e-4."""
+    import fourier_feature_nets_amd as ffn
+    from tests.golden.make_fit_schedule import (BATCH, CROP_STEPS, MODEL, NUM_STEPS, REPORT, SAMPLES,
+                                                 SIZE, TRAIN_CAMS, VAL_CAMS)
+    from tests.psnr_ensemble import write_npz
+    g = np.load(os.path.join(GOLDEN, "fit_schedule.npz"))
+    npz = write_npz(str(tmp_path / "scene.npz"), TRAIN_CAMS, VAL_CAMS, SIZE)
+    model = ffn.PositionalFourierMLP(3, 4, 5.5, **MODEL)
+    model.load_state_dict({k[len("init/"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("init/")})
+    model = model.to(dev())
+    train = _quiet(ffn.ImageDataset.load, npz, "train", SAMPLES, True, True, anneal_start=0.2,
+                   num_anneal_steps=8)
+    val = _quiet(ffn.ImageDataset.load, npz, "val", SAMPLES, True, False)
+    train.sampler.noise_source = "host"
+    torch.manual_seed(777)
+    np.random.seed(777)
+    caster = ffn.Raycaster(model)
+    batches, modes = [], []
+    orig_init, orig_step = ffn.TrainEngine.__init__, ffn.TrainEngine.train_step
+
+    def recording_init(self, *a, **k):
+        orig_init(self, *a, **k)
+        self.loss_history = []
+
+    def recording_step(self, dataset, batch, step, lr, rays=None):
+        batches.append(torch.as_tensor(batch).cpu().numpy().astype(np.int64))
+        modes.append(int(dataset.mode.value))
+        return orig_step(self, dataset, batch, step, lr, rays=rays)
+
+    ffn.TrainEngine.__init__, ffn.TrainEngine.train_step = recording_init, recording_step
+    buf = io.StringIO()
+    try:
+        with contextlib.redirect_stdout(buf):
+            log = caster.fit(train, val, BATCH, 5e-4, NUM_STEPS, CROP_STEPS, REPORT, 0.1, 25000, 0.0, [])
+    finally:
+        ffn.TrainEngine.__init__, ffn.TrainEngine.train_step = orig_init, orig_step
+    assert modes == g["modes"].tolist() and modes[5] == 2 and modes[6] == 0
+    assert len(batches) == len(g["batches"]) == NUM_STEPS + 1
+    for step, (mine, theirs) in enumerate(zip(batches, g["batches"])):
+        assert np.array_equal(mine, theirs), step
+    losses = [float(x) for x in caster.engine.loss_history]
+    np.testing.assert_allclose(losses, g["losses"], rtol=3e-4, atol=1e-7)
+    assert [e.step for e in log] == g["log_steps"].tolist()
+    np.testing.assert_allclose([e.train_psnr for e in log], g["log_train_psnr"], atol=5e-3)
+    np.testing.assert_allclose([e.val_psnr for e in log], g["log_val_psnr"], atol=5e-3)
+    mine = [ln for ln in buf.getvalue().splitlines() if ln[:7].isdigit() or ln.startswith("Removing")]
+    theirs = [ln for ln in str(g["stdout"]).splitlines() if ln[:7].isdigit() or ln.startswith("Removing")]
+    assert len(mine) == len(theirs)
+    for a, b in zip(mine, theirs):
+        if a.startswith("Removing"):
+            assert a == b
+            continue
+        a, b = a.split(), b.split()
+        assert a[0] == b[0] and abs(float(a[4]) - float(b[4])) < 5e-3 and abs(float(a[6]) - float(b[6])) < 5e-3
+    for key in g.files:
+        if key.startswith("final/"):
+            got = dict(model.state_dict())[key[len("final/"):]].detach().cpu().numpy()
+            np.testing.assert_allclose(got, g[key], rtol=0, atol=2e-4)
