@@ -173,11 +173,17 @@ class TrainEngine:
             else:
                 saved = self._saved_buffer(prog, pos.shape[0])
                 logits = prog.forward(pos, views, saved, precision=precision)
-            color, alpha, _ = ops.composite_fwd(logits, t, False, self.nan_flag)
-            part, d_color, d_alpha = ops.mse_loss(color, alpha, dataset.colors, alphas, chunk,
-                                                  1.0 / (3 * global_count), aw / global_count,
-                                                  sums_out=sums if first else None)
-            d_logits = ops.composite_bwd(logits, t, d_color, d_alpha).view(-1, 4)
+            # composite forward, ground-truth gather + loss sums, composite backward: one launch
+            d_logits, partials = ops.composite_train(logits, t, dataset.colors, alphas, chunk,
+                                                     1.0 / (3 * global_count), aw / global_count,
+                                                     self.nan_flag)
+            d_logits = d_logits.view(-1, 4)
+            # one launch on one device: the loss comes straight from the partial sums at the end
+            solo = self.group is None and count <= per_launch
+            part = None
+            if not solo:
+                part = sums if first else torch.empty_like(sums)
+                ops.loss_from_partials(partials, global_count, aw, sums_out=part, want_loss=False)
             if index is not None:
                 d_logits = ops.gather_logits(d_logits, index)
             if first:
@@ -202,7 +208,10 @@ class TrainEngine:
                       norm_out=self.grad_norm)
         self.model.invalidate_packed()
         # (a fresh tensor: the reduce buffer is overwritten by the next step)
-        loss = ops.loss_value(sums, global_count, aw)
+        if self.group is None and count <= per_launch:
+            loss = ops.loss_from_partials(partials, global_count, aw)
+        else:
+            loss = ops.loss_value(sums, global_count, aw)
         if self.loss_history is not None:
             self.loss_history.append(loss)
         return loss

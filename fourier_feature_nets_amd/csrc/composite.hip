@@ -135,6 +135,41 @@ blend_weights_bwd_kernel(const float* __restrict__ t, const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------- K5b
+// One row of the backward walk (shared by K5b and the training composite K5t): d(loss)/d(logits)
+// of the row's sample from the ray's d(loss)/d(colour), d(loss)/d(alpha); `tail` carries
+// sum of g*w over all later rows.
+__device__ __forceinline__ float4 composite_bwd_row(const SampleTerms& p, float T, float dcr, float dcg,
+                                                    float dcb, float da, int s, int S, int lane,
+                                                    float& tail) {
+    // every product and sum rounded on its own (ATen's autograd evaluates them one op at a time;
+    // and the two kernels that inline this row must not contract it differently)
+#pragma clang fp contract(off)
+    const bool active = s < S;
+    const float w = p.alpha * T;
+    const float g = active ? (dcr * p.r + dcg * p.g + dcb * p.b) + (s < S - 1 ? da : 0.0f)
+                           : 0.0f;
+    const float gw = g * w;
+    const float incl = wave_suffix_add(gw, lane);
+    const float Q = (incl - gw) + tail;          // strictly-after sum
+    tail += __shfl(incl, 0, 64);
+    float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (active) {
+        // tau = min(1, u): gradient 1 below the clamp, 1/2 on a tie, 0 above it
+        const float dtau_du = p.u < 1.0f ? 1.0f : (p.u == 1.0f ? 0.5f : 0.0f);
+        const float dL_dtau = (s < S - 1) ? Q / p.tau : 0.0f;
+        const float dL_dalpha = g * T - dtau_du * dL_dtau;
+        const float dL_dsigma = dL_dalpha * p.e * p.delta;
+        const float x = p.sigma_logit;
+        const float z = expf(x);
+        const float dsig = x > 20.0f ? 1.0f : z / (z + 1.0f);   // softplus' as torch: z/(z+1)
+        out.x = w * dcr * p.r * (1.0f - p.r);
+        out.y = w * dcg * p.g * (1.0f - p.g);
+        out.z = w * dcb * p.b * (1.0f - p.b);
+        out.w = dL_dsigma * dsig;
+    }
+    return out;
+}
+
 // Recomputes the forward terms (cheaper than storing 12 B/sample) and walks the rows in
 // reverse to form Q_s = sum_{j>s} g_j w_j, the quantity cumprod's backward needs.
 template <int ROWS>
@@ -166,31 +201,97 @@ composite_bwd_kernel(const float4* __restrict__ logits, const float* __restrict_
 #pragma unroll
         for (int row = ROWS - 1; row >= 0; --row) {
             const int s = row * 64 + lane;
-            const bool active = s < S;
-            const SampleTerms& p = q[row];
-            const float w = p.alpha * T[row];
-            const float g = active ? (dcr * p.r + dcg * p.g + dcb * p.b) + (s < S - 1 ? da : 0.0f)
-                                   : 0.0f;
-            const float gw = g * w;
-            const float incl = wave_suffix_add(gw, lane);
-            const float Q = (incl - gw) + tail;          // strictly-after sum
-            tail += __shfl(incl, 0, 64);
-            if (active) {
-                // tau = min(1, u): gradient 1 below the clamp, 1/2 on a tie, 0 above it
-                const float dtau_du = p.u < 1.0f ? 1.0f : (p.u == 1.0f ? 0.5f : 0.0f);
-                const float dL_dtau = (s < S - 1) ? Q / p.tau : 0.0f;
-                const float dL_dalpha = g * T[row] - dtau_du * dL_dtau;
-                const float dL_dsigma = dL_dalpha * p.e * p.delta;
-                const float x = p.sigma_logit;
-                const float z = expf(x);
-                const float dsig = x > 20.0f ? 1.0f : z / (z + 1.0f);   // softplus' as torch: z/(z+1)
-                float4 out;
-                out.x = w * dcr * p.r * (1.0f - p.r);
-                out.y = w * dcg * p.g * (1.0f - p.g);
-                out.z = w * dcb * p.b * (1.0f - p.b);
-                out.w = dL_dsigma * dsig;
-                d_logits[(int64_t)ray * S + s] = out;
-            }
+            const float4 out = composite_bwd_row(q[row], T[row], dcr, dcg, dcb, da, s, S, lane, tail);
+            if (s < S) d_logits[(int64_t)ray * S + s] = out;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------- K5t
+// The training step's composite: K5 (forward), K6 (ground-truth gather, residuals, loss sums)
+// and K5b (backward) of a batch in ONE launch -- one wave per ray keeps the ray's sample terms in
+// registers between the forward reduction and the backward walk, the colour / alpha / d_colour /
+// d_alpha round trip through HBM and three launches go away (14 us of the 1.2 ms step at the
+// reference's default batch).  Same expressions in the same order as the three kernels above:
+// d_logits is bit-identical to theirs.  Loss sums leave as one pair per workgroup
+// (`partials`), summed in a fixed order by ffn_loss_from_partials.
+template <int ROWS>
+__global__ void __launch_bounds__(256)
+composite_train_kernel(const float4* __restrict__ logits, const float* __restrict__ t,
+                       const float* __restrict__ gt_colors, const float* __restrict__ gt_alphas,
+                       const int64_t* __restrict__ ray_index, int R, int S, float color_scale,
+                       float alpha_scale, float4* __restrict__ d_logits,
+                       float* __restrict__ partials, int32_t* nan_flag) {
+    __shared__ float red[2][4];
+    const int lane = lane_id();
+    const int wave = (int)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6);
+    const int waves = (int)((gridDim.x * (int64_t)blockDim.x) >> 6);
+    float ec = 0.0f, ea = 0.0f;
+    for (int ray = wave; ray < R; ray += waves) {
+        const float4* lg = logits + (int64_t)ray * S;
+        const float* tr = t + (int64_t)ray * S;
+        SampleTerms q[ROWS];
+        float T[ROWS];
+        RayAccum acc;
+        acc.reset();
+#pragma unroll
+        for (int row = 0; row < ROWS; ++row) {
+            const int s = row * 64 + lane;
+            q[row] = load_terms(lg, tr, s, S, s < S, nan_flag);
+            T[row] = acc.row(q[row], lane, s, s < S - 1);
+        }
+        acc.finish();
+        const float cr = acc.cr, cg = acc.cg, cb = acc.cb, asum = acc.asum;
+        // K6 on this ray
+        const int64_t gt = ray_index[ray];
+        float gr = gt_colors[gt * 3 + 0], gg = gt_colors[gt * 3 + 1], gb = gt_colors[gt * 3 + 2];
+        float da = 0.0f;
+        if (gt_alphas != nullptr) {
+            const float ga = gt_alphas[gt];
+            if (!(ga > 0.0f)) { gr = 0.f; gg = 0.f; gb = 0.f; }
+            const float diff = asum - ga;
+            ea += diff * diff;
+            da = alpha_scale * 2.0f * diff;
+        }
+        const float d0 = cr - gr, d1 = cg - gg, d2 = cb - gb;
+        ec += (d0 * d0 + d1 * d1) + d2 * d2;
+        float dcr = color_scale * 2.0f * d0, dcg = color_scale * 2.0f * d1, dcb = color_scale * 2.0f * d2;
+        // (opaque to the optimiser, like K5b's loads of d_colour / d_alpha: the backward rows see
+        // plain values in both kernels)
+        asm volatile("" : "+v"(dcr), "+v"(dcg), "+v"(dcb), "+v"(da));
+        // K5b on the terms still in registers
+        float tail = 0.0f;
+#pragma unroll
+        for (int row = ROWS - 1; row >= 0; --row) {
+            const int s = row * 64 + lane;
+            const float4 out = composite_bwd_row(q[row], T[row], dcr, dcg, dcb, da, s, S, lane, tail);
+            if (s < S) d_logits[(int64_t)ray * S + s] = out;
+        }
+    }
+    const int w = threadIdx.x >> 6;
+    if (lane == 0) { red[0][w] = ec; red[1][w] = ea; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partials[blockIdx.x * 2 + 0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        partials[blockIdx.x * 2 + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+}
+
+// sums of K5t's / K6's per-workgroup partials, and (optionally) the scalar loss from them:
+//   loss = sums[0] / colour_count + alpha_weight * (sums[1] / alpha_count)   (image_dataset.py:237-242)
+__global__ void __launch_bounds__(64)
+loss_from_partials_kernel(const float* __restrict__ partials, int blocks, float colour_count,
+                          float alpha_count, float alpha_weight, float* __restrict__ sums,
+                          float* __restrict__ loss) {
+    float ec = 0.0f, ea = 0.0f;
+    for (int i = threadIdx.x; i < blocks; i += 64) { ec += partials[i * 2]; ea += partials[i * 2 + 1]; }
+    ec = wave_sum(ec); ea = wave_sum(ea);
+    if (threadIdx.x == 0) {
+        if (sums != nullptr) { sums[0] = ec; sums[1] = ea; }
+        if (loss != nullptr) {
+            const float colour = ec / colour_count;
+            const float alpha = alpha_weight != 0.0f ? alpha_weight * (ea / alpha_count) : 0.0f;
+            loss[0] = colour + alpha;
         }
     }
 }
@@ -329,4 +430,43 @@ extern "C" int ffn_mse_loss(const float* color, const float* alpha, const float*
     hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scratch, blocks,
                        sums);
     return check_launch("ffn_mse_loss");
+}
+
+extern "C" int ffn_composite_train_blocks(int num_rays) { return num_rays > 0 ? ray_grid(num_rays) : 0; }
+
+extern "C" int ffn_composite_train(const float* logits, const float* t, int num_rays, int num_samples,
+                                   const float* gt_colors, const float* gt_alphas,
+                                   const int64_t* ray_index, float color_scale, float alpha_scale,
+                                   float* d_logits, float* partials, int32_t* nan_flag, void* stream) {
+    if (num_rays <= 0 || num_samples < 1) return fail_arg("ffn_composite_train: shape");
+    if (logits == nullptr || t == nullptr || gt_colors == nullptr || ray_index == nullptr ||
+        d_logits == nullptr || partials == nullptr)
+        return fail_arg("ffn_composite_train: null argument");
+    const int rows = (num_samples + 63) / 64;
+    const dim3 grid(ray_grid(num_rays)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define FFN_CT(ROWS)                                                                           \
+    hipLaunchKernelGGL(composite_train_kernel<ROWS>, grid, block, 0, st, (const float4*)logits, t, \
+                       gt_colors, gt_alphas, ray_index, num_rays, num_samples, color_scale,    \
+                       alpha_scale, (float4*)d_logits, partials, nan_flag)
+    switch (rows) {
+        case 1: FFN_CT(1); break;
+        case 2: FFN_CT(2); break;
+        case 3: FFN_CT(3); break;
+        case 4: FFN_CT(4); break;
+        case 5: case 6: case 7: case 8: FFN_CT(8); break;
+        default: return fail_arg("ffn_composite_train: num_samples > 512");
+    }
+#undef FFN_CT
+    return check_launch("ffn_composite_train");
+}
+
+extern "C" int ffn_loss_from_partials(const float* partials, int num_blocks, float colour_count,
+                                      float alpha_count, float alpha_weight, float* sums,
+                                      float* loss_out, void* stream) {
+    if (partials == nullptr || num_blocks < 1 || (sums == nullptr && loss_out == nullptr))
+        return fail_arg("ffn_loss_from_partials: arguments");
+    hipLaunchKernelGGL(loss_from_partials_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partials,
+                       num_blocks, colour_count, alpha_count, alpha_weight, sums, loss_out);
+    return check_launch("ffn_loss_from_partials");
 }

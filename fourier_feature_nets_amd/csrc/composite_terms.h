@@ -129,17 +129,24 @@ struct RayAccum {
         best_w = -1.0f;       // weights are >= 0, so -1 means "none yet"
         best_s = 0;
     }
-    __device__ __forceinline__ void row(const SampleTerms& q, int lane, int index, bool inner) {
+    // Returns the sample's transmittance T.  The roundings are spelled out (no contraction left to
+    // the compiler's context-dependent choice): the weight w = alpha * T is a rounded product --
+    // `asum + alpha * T` as one fused operation differs in the last bit once a ray has more than
+    // one row -- and the colour sums take w * c with one rounding.  Every kernel that composites
+    // (K5, the fused render, the training composite K5t) therefore produces the same bits.
+    __device__ __forceinline__ float row(const SampleTerms& q, int lane, int index, bool inner) {
+#pragma clang fp contract(off)
         const float incl = wave_scan_mul(q.tau, lane);
         const float excl = wave_shift_up(incl, 1.0f);
         const float T = carry * excl;
         const float w = q.alpha * T;
-        cr += w * q.r; cg += w * q.g; cb += w * q.b;
+        cr = __builtin_fmaf(w, q.r, cr); cg = __builtin_fmaf(w, q.g, cg); cb = __builtin_fmaf(w, q.b, cb);
         if (inner) {
-            asum += w;
+            asum = asum + w;
             if (w > best_w) { best_w = w; best_s = index; }
         }
         carry *= wave_last(incl);
+        return T;
     }
     // after this every lane holds the ray's colour / alpha; best_s / best_w the depth pick
     __device__ __forceinline__ void finish() {

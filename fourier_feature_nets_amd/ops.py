@@ -215,6 +215,31 @@ def mse_loss(color, alpha, gt_colors, gt_alphas, ray_index, color_scale, alpha_s
     return sums, d_color, d_alpha
 
 
+def composite_train(logits, t, gt_colors, gt_alphas, ray_index, color_scale, alpha_scale,
+                    nan_flag: Optional[torch.Tensor] = None):
+    """K5t: K5 + K6 + K5b of one training batch in one launch.  logits (R,S,4), t (R,S) ->
+    (d_logits (R,S,4), partials (blocks,2)): d_logits bit-identical to ``composite_fwd`` ->
+    ``mse_loss`` -> ``composite_bwd``; the loss sums per workgroup go to ``loss_from_partials``."""
+    rays, count = t.shape
+    blocks = int(_lib.load().ffn_composite_train_blocks(c_i(rays)))
+    d_logits = torch.empty((rays, count, 4), dtype=torch.float32, device=t.device)
+    partials = torch.empty((blocks, 2), dtype=torch.float32, device=t.device)
+    _call("ffn_composite_train", _dev(logits), _dev(t), c_i(rays), c_i(count), _dev(gt_colors),
+          _dev(gt_alphas), _dev(ray_index, torch.int64), c_f(color_scale), c_f(alpha_scale),
+          _dev(d_logits), _dev(partials), _dev(nan_flag, torch.int32))
+    return d_logits, partials
+
+
+def loss_from_partials(partials: torch.Tensor, rays: int, alpha_weight: float,
+                       sums_out: Optional[torch.Tensor] = None, want_loss: bool = True):
+    """Fixed-order sum of K5t's per-workgroup pairs: into ``sums_out`` (2 floats, for the
+    data-parallel all-reduce) and / or the scalar loss (a fresh device scalar)."""
+    loss = torch.empty((), dtype=torch.float32, device=partials.device) if want_loss else None
+    _call("ffn_loss_from_partials", _dev(partials), c_i(partials.shape[0]), c_f(3.0 * rays),
+          c_f(float(rays)), c_f(alpha_weight), _dev(sums_out), _dev(loss))
+    return loss
+
+
 def loss_value(sums: torch.Tensor, rays: int, alpha_weight: float) -> torch.Tensor:
     """sums[0] / (3 rays) + alpha_weight * sums[1] / rays as a fresh device scalar (one launch)."""
     out = torch.empty((), dtype=torch.float32, device=sums.device)

@@ -172,6 +172,26 @@ int ffn_clip_adam(float* params, float* grads, float* exp_avg, float* exp_avg_sq
                   float inv_sqrt_bc2, float beta1, float beta2, float eps,
                   float weight_decay, float* scratch, float* grad_norm_out, void* stream);
 
+/* K5t  The training step's K5 + K6 + K5b in one launch: Raycaster.render (ray_caster.py:66-93),
+ * ImageDataset.render / .loss (image_dataset.py:224-262) and their autograd for one batch.
+ *   logits (R,S,4), t (R,S); gt_colors / gt_alphas (or NULL) / ray_index / the two scales as in
+ *   ffn_mse_loss; d_logits (R,S,4) out -- bit-identical to ffn_composite_fwd -> ffn_mse_loss ->
+ *   ffn_composite_bwd; partials: 2 * ffn_composite_train_blocks(R) floats out, one
+ *   (sum((c-c_gt)^2), sum((a-a_gt)^2)) pair per workgroup, for ffn_loss_from_partials.
+ *   nan_flag as in ffn_composite_fwd (may be NULL).  S <= 512, R >= 1. */
+int ffn_composite_train_blocks(int num_rays);
+int ffn_composite_train(const float* logits, const float* t, int num_rays, int num_samples,
+                        const float* gt_colors, const float* gt_alphas, const int64_t* ray_index,
+                        float color_scale, float alpha_scale, float* d_logits, float* partials,
+                        int32_t* nan_flag, void* stream);
+
+/* Fixed-order sum of K5t's partials into sums (2 floats; may be NULL) and / or the scalar loss
+ *   loss = sums[0] / colour_count + alpha_weight * (sums[1] / alpha_count)
+ * into loss_out (may be NULL) (image_dataset.py:237-242). */
+int ffn_loss_from_partials(const float* partials, int num_blocks, float colour_count,
+                           float alpha_count, float alpha_weight, float* sums, float* loss_out,
+                           void* stream);
+
 /* The scalar loss from K6's two sums (possibly all-reduced over the ranks in between):
  *   loss = sums[0] / colour_count + alpha_weight * (sums[1] / alpha_count)
  * (image_dataset.py:237-242: colour_count = 3 * rays, alpha_count = rays); one launch instead

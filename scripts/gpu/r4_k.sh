@@ -1,3 +1,5 @@
 mkdir -p gpurun_out/r4k
-timeout 600 python -m pytest tests/test_round4_gpu.py -m gpu -q -k "small_ensemble" > gpurun_out/r4k/ens.log 2>&1; echo "rc=$?" >> gpurun_out/r4k/ens.log
-grep -v "^  \|^$" gpurun_out/r4k/ens.log | tail -12
+S=$(date +%s); timeout 1500 python -m pytest tests -m gpu -q -x > gpurun_out/r4k/all.log 2>&1; echo "pytest rc=$? $(( $(date +%s) - S ))s"
+tail -4 gpurun_out/r4k/all.log
+bash scripts/gpu/r4_bench.sh
+cp gpurun_out/r4bench/bench.json gpurun_out/r4k/bench.json

@@ -555,3 +555,42 @@ def test_fit_schedule_across_the_crop_removal(tmp_path):
         if key.startswith("final/"):
             got = dict(model.state_dict())[key[len("final/"):]].detach().cpu().numpy()
             np.testing.assert_allclose(got, g[key], rtol=0, atol=2e-4)
+
+
+# ----------------------------------------------------------------------------------- fused training composite
+@pytest.mark.parametrize("samples", [2, 64, 65, 128, 200, 256, 400])
+@pytest.mark.parametrize("with_alpha", [True, False])
+def test_training_composite_in_one_launch(samples, with_alpha):
+    """K5t (`ffn_composite_train`: composite forward + ground-truth gather / loss sums + composite
+    backward in one launch, ray_caster.py:66-93 + image_dataset.py:224-262 and their autograd)
+    against the three launches it replaces: d_logits BIT-identical, the loss sums to 1e-6
+    relative (the partial sums are grouped per workgroup instead of per 256 rays), the scalar
+    loss against the oracle's loss of the unfused colours."""
+    from fourier_feature_nets_amd import ops
+    torch.manual_seed(samples + 7 * with_alpha)
+    rays, total = 1237, 5000
+    logits = torch.randn(rays, samples, 4, device=dev()) * 2.0
+    logits[3, :, 3] = 30.0                       # softplus' threshold branch
+    logits[5, :, 3] = -40.0                      # an empty ray
+    t = torch.sort(torch.rand(rays, samples, device=dev()) * 4 + 2, dim=1).values.contiguous()
+    gt_colors = torch.rand(total, 3, device=dev())
+    gt_alphas = (torch.rand(total, device=dev()) > 0.4).float() if with_alpha else None
+    index = torch.randint(0, total, (rays,), device=dev())
+    cs, al = 1.0 / (3 * rays), (0.1 / rays if with_alpha else 0.0)
+    color, alpha, _ = ops.composite_fwd(logits, t, False, None)
+    sums, d_color, d_alpha = ops.mse_loss(color, alpha, gt_colors, gt_alphas, index, cs, al)
+    want = ops.composite_bwd(logits, t, d_color, d_alpha)
+    got, partials = ops.composite_train(logits, t, gt_colors, gt_alphas, index, cs, al, None)
+    assert torch.equal(got, want)
+    mine = torch.zeros(2, device=dev())
+    loss = ops.loss_from_partials(partials, rays, 0.1 if with_alpha else 0.0, sums_out=mine)
+    np.testing.assert_allclose(mine.cpu().numpy(), sums.cpu().numpy(), rtol=1e-6)
+    gc, ga = orc.ground_truth(gt_colors.cpu(), None if gt_alphas is None else gt_alphas.cpu(), index.cpu())
+    ref = orc.mse_loss(color.cpu(), alpha.cpu(), gc, ga, 0.1)
+    assert abs(float(loss) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
+    # the NaN flag of the forward kernel is raised here too
+    flag = torch.zeros(1, dtype=torch.int32, device=dev())
+    bad = logits.clone()
+    bad[11, samples // 2, 1] = float("nan")
+    ops.composite_train(bad, t, gt_colors, gt_alphas, index, cs, al, flag)
+    assert int(flag.item()) == 1
