@@ -178,14 +178,36 @@ def compare(doc, reference_path, out_path):
     # differences are reported too -- trajectories decorrelate within a few hundred steps, so the
     # pairing removes little variance; the verdict stays on the unpaired means
     paired = [x - y for x, y in zip(a["values"], b["values"])]
+    # seed-by-seed at every report: until the trajectories decorrelate (a few hundred steps) the
+    # PAIRED differences pin the clause far tighter than any ensemble mean can
+    by_seed = {run["seed"]: run for run in ref["runs"]}
+    paired_reports = []
+    for s in steps:
+        deltas = []
+        for run in doc["runs"]:
+            other = by_seed.get(run["seed"])
+            if other is None:
+                continue
+            x = [r["val_psnr"] for r in run["reports"] if r["step"] == s]
+            y = [r["val_psnr"] for r in other["reports"] if r["step"] == s]
+            if x and y:
+                deltas.append(x[0] - y[0])
+        if deltas:
+            paired_reports.append({"step": s, "seeds": len(deltas), "mean_delta_db": float(np.mean(deltas)),
+                                   "max_abs_delta_db": float(np.max(np.abs(deltas)))})
     doc["against_reference"] = {
+        "paired_val_psnr_by_report": paired_reports,
         "file": os.path.relpath(reference_path, ROOT), "reference_final": b, "hip_final": a,
         "per_seed_delta_db": paired,
         "per_seed_delta_mean_db": float(np.mean(paired)) if paired else None,
         "per_seed_delta_stderr_db": float(np.std(paired, ddof=1) / np.sqrt(len(paired))) if len(paired) > 1 else None,
         "delta_mean_db": delta, "stderr_of_delta_db": se,
         "within_0p05_db": abs(delta) < 0.05, "within_2_stderr": abs(delta) < 2 * se,
-        "protocol_matches": ref["protocol"] == doc["protocol"], "mean_curves": curve,
+        # (the HIP half may run MORE seeds than the reference half: the reference's are a prefix)
+        "protocol_matches": ({k: v for k, v in ref["protocol"].items() if k != "seeds"} ==
+                             {k: v for k, v in doc["protocol"].items() if k != "seeds"} and
+                             set(ref["protocol"]["seeds"]) <= set(doc["protocol"]["seeds"])),
+        "mean_curves": curve,
         "verdict": "pass" if (abs(delta) < 0.05 or abs(delta) < 2 * se) else "fail"}
     with open(out_path, "w") as f:
         json.dump(doc, f, indent=1)
