@@ -43,6 +43,12 @@ def main():
     d_alpha = torch.randn(R, device=dev)
     sec = timed(lambda: ops.composite_bwd(logits, t, d_color, d_alpha))
     out["composite_bwd"] = (R * (20 * S + 16 * S + 16), sec)
+    # K5t: forward + ground-truth gather / loss sums + backward of a training batch in one launch
+    gt_colors = torch.rand(4 * R, 3, device=dev)
+    gt_alphas = (torch.rand(4 * R, device=dev) > 0.4).float()
+    index = torch.randint(0, 4 * R, (R,), device=dev)
+    sec = timed(lambda: ops.composite_train(logits, t, gt_colors, gt_alphas, index, 1.0 / (3 * R), 0.1 / R))
+    out["composite_train (K5 + K6 + K5b in one launch)"] = (R * (20 * S + 16 * S + 8 + 16), sec)
     n = R * S
     x = torch.rand(n, 3, device=dev) * 2 - 1
     b = ffn.PositionalFourierMLP(3, 4, 5.5).b_values.data.clone().contiguous().to(dev)
