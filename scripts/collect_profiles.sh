@@ -1,4 +1,4 @@
-# copies what scripts/gpu/profile_round4.sh, r4_quality.sh and r4_j.sh left under gpurun_out/ (scratch)
+# copies what scripts/gpu/profile_round4.sh, r4_quality.sh and r4_tests_and_scale.sh left under gpurun_out/ (scratch)
 # into profiles/ (tracked)
 set -e
 cd "$(dirname "$0")/.."
@@ -17,8 +17,7 @@ cp $P/r04_sq_counters_bf16_ring.json $P/r04_sq_counters_bf16_ws.json profiles/
 cp $P/r04_sq_counters_bf16_ring_waits.json $P/r04_sq_counters_bf16_ws_waits.json profiles/
 cp $P/hbm_microbench.json profiles/r04_hbm_microbench.json
 cp $P/r04_default_batch_timeline.txt profiles/
-cp $Q/psnr_parity_bf16x3.json profiles/r04_psnr_parity_bf16x3.json
+[ -f $Q/psnr_parity_bf16x3.json ] && cp $Q/psnr_parity_bf16x3.json profiles/r04_psnr_parity_bf16x3.json
 [ -f $Q/psnr_parity_config3.json ] && cp $Q/psnr_parity_config3.json profiles/r04_psnr_parity_config3.json
-[ -f $Q/psnr_ensemble.json ] && cp $Q/psnr_ensemble.json profiles/r04_psnr_ensemble.json
-cp gpurun_out/r4j/scale_curve_shared_gpu_functional.json profiles/r04_scale_curve_shared_gpu_functional.json
+[ -f gpurun_out/r4j/scale_curve_shared_gpu_functional.json ] && cp gpurun_out/r4j/scale_curve_shared_gpu_functional.json profiles/r04_scale_curve_shared_gpu_functional.json
 grep -h '"commit"' profiles/r04_hbm_traffic.json profiles/r04_sq_counters.json profiles/r04_bf16_chain_kernels.json | head -4
