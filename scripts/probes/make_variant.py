@@ -16,24 +16,31 @@ OUT = os.path.join(ROOT, "scripts", "probes", "variants")
 def main(name, subs_path, source="mlp.hip"):
     scope = {}
     exec(open(subs_path).read(), scope)
-    text = open(os.path.join(CSRC, source)).read()
-    for old, new in scope["SUBS"]:
-        assert old in text, old
-        text = text.replace(old, new)
+    subs = scope["SUBS"]
+    if not isinstance(subs, dict):          # one source file (argv) or several (a dict in the file)
+        subs = {source: subs}
     os.makedirs(OUT, exist_ok=True)
-    src = os.path.join(OUT, "%s_%s" % (name, source))
-    with open(src, "w") as f:
-        f.write(text)
-    obj = src.replace(".hip", ".o")
     sys.path.insert(0, ROOT)
     from fourier_feature_nets_amd.build import SOURCES          # the product's per-file flags
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"), "-I", CSRC]
-    flags += SOURCES.get(source, [])
-    subprocess.run(["/opt/rocm/bin/hipcc"] + flags + ["-c", src, "-o", obj], check=True)
+    objs = []
+    for src_name, pairs in subs.items():
+        text = open(os.path.join(CSRC, src_name)).read()
+        for old, new in pairs:
+            assert old in text, (src_name, old)
+            text = text.replace(old, new)
+        src = os.path.join(OUT, "%s_%s" % (name, src_name))
+        with open(src, "w") as f:
+            f.write(text)
+        obj = src.replace(".hip", ".o")
+        flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"), "-I", CSRC]
+        flags += SOURCES.get(src_name, [])
+        subprocess.run(["/opt/rocm/bin/hipcc"] + flags + ["-c", src, "-o", obj], check=True)
+        objs.append(obj)
+    replaced = {s.replace(".hip", ".o") for s in subs}
     others = [os.path.join(CSRC, "build", o) for o in os.listdir(os.path.join(CSRC, "build"))
-              if o.endswith(".o") and o != source.replace(".hip", ".o")]
+              if o.endswith(".o") and o not in replaced]
     lib = os.path.join(OUT, "libffn_%s.so" % name)
-    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + others + [obj],
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + others + objs,
                    check=True)
     print("built", lib)
 
