@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # FFN_HIP_LIBRARY points at an alternative build of the same ABI (kernel experiments)
 LIB_PATH = os.environ.get("FFN_HIP_LIBRARY") or os.path.join(_HERE, "libffn_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ffn_hip.h")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _lib = None
 

@@ -65,7 +65,9 @@ def build_library(force=False, verbose=True):
     for name, extra in SOURCES.items():
         src = os.path.join(CSRC, name)
         if not os.path.exists(src):
-            continue
+            # a kernel file that went missing must fail the BUILD, not surface later as an
+            # AttributeError on a symbol the smaller library does not export
+            raise RuntimeError("source file listed in SOURCES is missing: %s" % src)
         obj = os.path.join(obj_dir, name.replace(".hip", ".o"))
         objects.append(obj)
         if force or _stale(obj, [src] + headers):

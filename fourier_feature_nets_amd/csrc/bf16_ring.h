@@ -25,6 +25,20 @@ __device__ __forceinline__ void split8(const float (&x)[8], bf16x8& hi, bf16x8& 
     }
 }
 
+// Three-way split: x = hi + mid + lo EXACTLY (8 + 8 + 8 significand bits cover f32's 24; both
+// remainders are exact f32 subtractions).  The operands of the f32-accurate "bf16x6" mode.
+__device__ __forceinline__ void split8x3(const float (&x)[8], bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 h = (__bf16)x[j];
+        const float r = x[j] - (float)h;
+        const __bf16 m = (__bf16)r;
+        hi[j] = h;
+        mid[j] = m;
+        lo[j] = (__bf16)(r - (float)m);
+    }
+}
+
 struct Ring16 {
     int lane, tid;
     f32x4* wbuf;              // LDS: ring of kRingBlocks16 weight K blocks
@@ -251,6 +265,14 @@ int launch_forward16_ws(const ffn_mlp_chain* chain, const uint16_t* packed_w, co
                         float* saved, uint32_t* masks, void* stream);
 int launch_backward16_ws(const ffn_mlp_chain* chain, const uint16_t* packed_wt, const float* d_logits,
                          int64_t n, const uint32_t* masks, float* dz, void* stream);
+// The f32-accurate split mode ("bf16x6": three bf16 parts per operand, six partial products per
+// f32 product, f32 accumulation; mlp_bf16_ws.hip).  products = 6 or 9 (9 = every partial product:
+// measurement only).
+int launch_forward_bf16x6(const ffn_mlp_chain* chain, const uint16_t* packed_w, const float* bias,
+                          const float* positions, const float* views, int64_t n, float* logits,
+                          float* saved, uint32_t* masks, void* stream);
+int launch_backward_bf16x6(const ffn_mlp_chain* chain, const uint16_t* packed_wt, const float* d_logits,
+                           int64_t n, const uint32_t* masks, float* dz, void* stream);
 inline bool prefer_ws_kernels(bool by_default) {     // read per launch: tests flip it inside one process
     const char* v = getenv("FFN_BF16_KERNELS");
     if (v != nullptr && v[0] == 'r') return false;

@@ -26,13 +26,14 @@ constexpr int kBiasFloats16 = 4096;
 constexpr size_t kLdsBytes16 = (size_t)kRingBlocks16 * kBlockVecs16 * 16 + kEncTableBytes + kBiasFloats16 * 4;
 
 // ---------------------------------------------------------------------------------- pack
-// dst[(((G*tiles + o)*2 + part)*64 + lane)*8 + j] = part(src[32*o + (lane & 31)][col_map[16*G + 8*(lane >> 5) + j]])
+// dst[(((G*tiles + o)*parts + part)*64 + lane)*8 + j] = part(src[32*o + (lane & 31)][col_map[16*G + 8*(lane >> 5) + j]])
 // (rows past the matrix are zero: the forward kernel always runs tiles = 8)
-// part 0 = bf16(v) (round to nearest even), part 1 = bf16(v - float(part 0)).
+// part 0 = bf16(v) (round to nearest even), part p = bf16(v - float(part 0) - .. - float(part p-1));
+// parts = 2: the (hi, lo) operands of the bf16x3 kernels, parts = 3: (hi, mid, lo), exactly v (bf16x6).
 // transpose: the operand is src^T -- tile rows walk src's columns, col_map maps K to src's rows.
 __global__ void __launch_bounds__(256)
 pack_bf16_kernel(const float* __restrict__ src, int rows, int cols, int ld,
-                 const int32_t* __restrict__ col_map, int kblocks, int tiles, int transpose,
+                 const int32_t* __restrict__ col_map, int kblocks, int tiles, int transpose, int parts,
                  uint16_t* __restrict__ dst) {
     const int64_t total = (int64_t)kblocks * tiles * 64 * 8;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
@@ -50,11 +51,12 @@ pack_bf16_kernel(const float* __restrict__ src, int rows, int cols, int ld,
         } else if (c >= 0 && c < rows && r < cols) {
             v = src[(int64_t)c * ld + r];
         }
-        const __bf16 hi = (__bf16)v;
-        const __bf16 lo = (__bf16)(v - (float)hi);
-        const int64_t base = ((go * 2) * 64 + lane) * 8 + j;
-        dst[base] = __builtin_bit_cast(uint16_t, hi);
-        dst[base + 64 * 8] = __builtin_bit_cast(uint16_t, lo);
+        const int64_t base = ((go * parts) * 64 + lane) * 8 + j;
+        for (int p = 0; p < parts; ++p) {
+            const __bf16 part = (__bf16)v;
+            dst[base + (int64_t)p * 64 * 8] = __builtin_bit_cast(uint16_t, part);
+            v -= (float)part;
+        }
     }
 }
 
@@ -286,15 +288,27 @@ mlp_forward_bf16_kernel(const ffn_mlp_chain ch, const uint16_t* __restrict__ pac
 
 using namespace ffn;
 
-extern "C" int ffn_mlp_pack_bf16(const float* src, int rows, int cols, int ld, const int32_t* col_map,
-                                 int kblocks, int tiles, int transpose, uint16_t* dst, void* stream) {
-    if (kblocks <= 0 || tiles <= 0 || col_map == nullptr) return fail_arg("ffn_mlp_pack_bf16: shape");
+static int pack_bf16(const char* what, const float* src, int rows, int cols, int ld, const int32_t* col_map,
+                     int kblocks, int tiles, int transpose, int parts, uint16_t* dst, void* stream) {
+    if (kblocks <= 0 || tiles <= 0 || col_map == nullptr || parts < 2 || parts > 3) return fail_arg(what);
     const int64_t total = (int64_t)kblocks * tiles * 512;
     int64_t grid = (total + 255) / 256;
     if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL(pack_bf16_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, src, rows,
-                       cols, ld, col_map, kblocks, tiles, transpose, dst);
-    return check_launch("ffn_mlp_pack_bf16");
+                       cols, ld, col_map, kblocks, tiles, transpose, parts, dst);
+    return check_launch(what);
+}
+
+extern "C" int ffn_mlp_pack_bf16(const float* src, int rows, int cols, int ld, const int32_t* col_map,
+                                 int kblocks, int tiles, int transpose, uint16_t* dst, void* stream) {
+    return pack_bf16("ffn_mlp_pack_bf16: shape", src, rows, cols, ld, col_map, kblocks, tiles, transpose, 2, dst, stream);
+}
+
+extern "C" int ffn_mlp_pack_bf16_parts(const float* src, int rows, int cols, int ld, const int32_t* col_map,
+                                       int kblocks, int tiles, int transpose, int parts, uint16_t* dst,
+                                       void* stream) {
+    return pack_bf16("ffn_mlp_pack_bf16_parts: shape or parts (2 or 3)", src, rows, cols, ld, col_map, kblocks,
+                     tiles, transpose, parts, dst, stream);
 }
 
 static int launch_forward16(const char* what, const ffn_mlp_chain* chain, const uint16_t* packed_w,

@@ -39,17 +39,31 @@ constexpr size_t kWsLdsBytes = (size_t)kWsXBytes + kEncTableBytes + kWsBiasFloat
 // the two waves of a tile each take half of the pass's blocks -- twice the vector-instruction
 // issue rate per SIMD and four instruction streams to fill the matrix pipe from; the duplicate
 // weight requests of the two waves of a tile are served by the CU's L1.
-template <int TPW_, int SPLIT_>
+//
+// PARTS_ = 3 is the F32-ACCURATE mode ("bf16x6"): every f32 operand is THREE bf16 parts (hi, mid,
+// lo: 24 significand bits, the operand exactly) and every f32 product SIX matrix instructions --
+// all partial products down to 2^-16 of the leading one: h.l, l.h, m.m, h.m, m.h, h.h, smallest
+// first (PRODUCTS_ = 9 adds m.l, l.m, l.l: measurement only) -- 12 matrix cycles per K where
+// v_mfma_f32_32x32x2_f32 takes 32.  The X image then holds three parts per value, so a pass is TWO
+// blocks (96 KiB): the same number of matrix instructions per pass and weight byte as the
+// two-part kernels' four blocks.
+template <int TPW_, int SPLIT_, int PARTS_ = 2, int PRODUCTS_ = (PARTS_ == 2 ? 3 : 6)>
 struct WsShape {
+    static_assert(PARTS_ == 2 || (PARTS_ == 3 && TPW_ == 1 && SPLIT_ == 1), "three-part chains: narrow, eight waves");
+    static_assert(PARTS_ == 2 ? PRODUCTS_ == 3 : (PRODUCTS_ == 6 || PRODUCTS_ == 9), "partial products");
     static constexpr int TPW = TPW_;
     static constexpr int SPLIT = SPLIT_;
+    static constexpr int PARTS = PARTS_;          // bf16 parts per f32 operand
+    static constexpr int PRODUCTS = PRODUCTS_;    // matrix instructions per f32 product
     static constexpr int WAVES = 8 * SPLIT_;
     static constexpr int THREADS = 64 * WAVES;
-    static constexpr int NB = 4 / TPW_;           // 32-sample blocks per pass
+    static constexpr int NB = (PARTS_ == 3 ? 2 : 4) / TPW_;      // 32-sample blocks per pass
     static constexpr int NBW = NB / SPLIT_;       // ... per wave
     static constexpr int TILES = 8 * TPW_;        // output tiles of the operand packs
     static constexpr int KBMAX = 16 * TPW_;       // K blocks of one block's X image
-    static constexpr int kKbVecs = NB * 128;      // float4 per K block of X: blocks x (hi, lo) x 64 lanes
+    static constexpr int kBlkVecs = 64 * PARTS_;  // float4 per (K block, block) of X: parts x 64 lanes
+    static constexpr int kKbVecs = NB * kBlkVecs; // float4 per K block of X
+    static constexpr int kTileVecs = 64 * PARTS_; // float4 per (K block, tile) of the weight packs
     // two alternating sets of hi operands (see ws_kblock)?  Not at 128 registers per wave: there
     // the hi operands are refilled late, and the other three waves of the SIMD cover the round trip
     static constexpr bool XH = SPLIT_ == 1;
@@ -59,7 +73,7 @@ struct WsShape {
 // the reads of one K block (every block, both parts) are ONE base register + immediate offsets
 template <class S>
 __device__ __forceinline__ constexpr int ws_x_index(int G, int b, int part) {
-    return (G * S::NB + b) * 128 + part * 64;
+    return (G * S::NB + b) * S::kBlkVecs + part * 64;
 }
 
 struct WsWave {
@@ -84,46 +98,48 @@ __device__ __forceinline__ void ws_barrier() {
 // the wave's slice of chunk c: K blocks 2c, 2c+1, its TPW tiles, (hi, lo): 1 KiB per load
 // (K block k of chunk c; ws_load_chunk = both)
 template <class S>
-__device__ __forceinline__ void ws_load_kblock(const WsWave& w, bf16x8 (&dst)[S::TPW][2], int c, int k) {
+__device__ __forceinline__ void ws_load_kblock(const WsWave& w, bf16x8 (&dst)[S::TPW][S::PARTS], int c, int k) {
     constexpr int TILES = S::TILES, TPW = S::TPW;
     typedef const f32x4 __attribute__((address_space(1)))* gptr;
     // wave-uniform bases (one per K block and tile: the strides exceed the immediate offset) kept
     // in SGPRs; the lanes add 16 B each -- scalar-base addressing, no per-lane 64-bit pointers
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
-        gptr base = (gptr)(w.gw + ((int64_t)c * 2 + k) * (TILES * 128) + (w.tile + 8 * t) * 128);
+        gptr base = (gptr)(w.gw + ((int64_t)c * 2 + k) * (TILES * S::kTileVecs) + (w.tile + 8 * t) * S::kTileVecs);
         asm volatile("" : "+s"(base));
 #pragma unroll
-        for (int part = 0; part < 2; ++part)
+        for (int part = 0; part < S::PARTS; ++part)
             dst[t][part] = __builtin_bit_cast(bf16x8, base[part * 64 + w.lane]);
     }
 }
 template <class S>
-__device__ __forceinline__ void ws_load_chunk(const WsWave& w, bf16x8 (&dst)[2][S::TPW][2], int c) {
+__device__ __forceinline__ void ws_load_chunk(const WsWave& w, bf16x8 (&dst)[2][S::TPW][S::PARTS], int c) {
     ws_load_kblock<S>(w, dst[0], c, 0);
     ws_load_kblock<S>(w, dst[1], c, 1);
 }
 
-// one part (0 = hi, 1 = lo) of the B operands of X K block G, every block of this wave
+// The B-operand registers of a wave.  Two parts: the lo operands and two alternating sets of hi
+// operands (see ws_kblock); three parts: two complete sets x[K block parity][block][part] -- with
+// two blocks per wave there is room for a plain double buffer.
+template <class S, int PARTS = S::PARTS>
+struct WsOps;
 template <class S>
-__device__ __forceinline__ void ws_read_x(const WsWave& w, bf16x8 (&x)[S::NBW][2], int G, int part) {
-    constexpr int NBW = S::NBW;
-    const f32x4* p = w.xbuf + G * S::kKbVecs + w.b0 * 128 + part * 64 + w.lane;
-#pragma unroll
-    for (int b = 0; b < NBW; ++b) x[b][part] = __builtin_bit_cast(bf16x8, p[b * 128]);
-}
+struct WsOps<S, 2> {
+    bf16x8 xb[S::NBW][2];
+    bf16x8 xh[S::NBW];
+};
+template <class S>
+struct WsOps<S, 3> {
+    bf16x8 x[2][S::NBW][3];
+};
 
-// one product of a K block for every (tile, block): weight part WP times operand part XP;
-// consecutive matrix instructions hit different accumulators
-template <class S, int NT, int WP, int XP>
-__device__ __forceinline__ void ws_mma(f32x16 (&acc)[S::TPW][S::NBW], const bf16x8 (&wk)[S::TPW][2],
-                                       const bf16x8 (&x)[S::NBW][2]) {
+// one part (0 = hi, .. PARTS-1 = lo) of the B operands of X K block G, every block of this wave
+template <class S, int COLS>
+__device__ __forceinline__ void ws_read_x(const WsWave& w, bf16x8 (&x)[S::NBW][COLS], int G, int part) {
     constexpr int NBW = S::NBW;
+    const f32x4* p = w.xbuf + G * S::kKbVecs + w.b0 * S::kBlkVecs + part * 64 + w.lane;
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int b = 0; b < NBW; ++b)
-            acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wk[t][WP], x[b][XP], acc[t][b], 0, 0, 0);
+    for (int b = 0; b < NBW; ++b) x[b][part] = __builtin_bit_cast(bf16x8, p[b * S::kBlkVecs]);
 }
 
 // One K block.  Per accumulator the products run w_hi x_lo, w_lo x_hi, w_hi x_hi (the ring
@@ -136,9 +152,9 @@ __device__ __forceinline__ void ws_mma(f32x16 (&acc)[S::TPW][S::NBW], const bf16
 // Issue order pinned: a ds_read behind each matrix instruction of the first third and of the
 // second third, the NVM weight requests behind the last third.
 template <class S, int NT, int HB>
-__device__ __forceinline__ void ws_kblock(const WsWave& w, f32x16 (&acc)[S::TPW][S::NBW],
-                                          const bf16x8 (&wk)[S::TPW][2], bf16x8 (&x)[S::NBW][2],
-                                          bf16x8 (&xh)[S::NBW], int next) {
+__device__ __forceinline__ void ws_kblock2(const WsWave& w, f32x16 (&acc)[S::TPW][S::NBW],
+                                           const bf16x8 (&wk)[S::TPW][2], bf16x8 (&x)[S::NBW][2],
+                                           bf16x8 (&xh)[S::NBW], int next) {
     constexpr int NBW = S::NBW;
     const f32x4* p = w.xbuf + next * S::kKbVecs + w.b0 * 128 + w.lane;
 #pragma unroll
@@ -171,9 +187,64 @@ __device__ __forceinline__ void ws_kblock(const WsWave& w, f32x16 (&acc)[S::TPW]
     }
 }
 
+// The partial products of the three-part mode, smallest first (the large terms meet an accumulator
+// that already holds the small ones): (weight part, operand part), 0 = hi, 1 = mid, 2 = lo.  Six
+// products drop m.l, l.m, l.l -- each below 2^-24 of the leading term.
+template <int PRODUCTS> struct WsProducts;
+template <> struct WsProducts<6> {
+    static constexpr int W[6] = {0, 2, 1, 0, 1, 0};
+    static constexpr int X[6] = {2, 0, 1, 1, 0, 0};
+};
+template <> struct WsProducts<9> {
+    static constexpr int W[9] = {2, 1, 2, 0, 2, 1, 0, 1, 0};
+    static constexpr int X[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0};
+};
+
+// One K block of the three-part mode: K block parity HB multiplies out of operand set HB while
+// the set of K block `next` streams from LDS into the other one.
+template <class S, int NT, int HB>
+__device__ __forceinline__ void ws_kblock3(const WsWave& w, f32x16 (&acc)[S::TPW][S::NBW],
+                                           const bf16x8 (&wk)[S::TPW][3], bf16x8 (&x)[2][S::NBW][3], int next) {
+    constexpr int NBW = S::NBW;
+    typedef WsProducts<S::PRODUCTS> P;
+    const f32x4* p = w.xbuf + next * S::kKbVecs + w.b0 * S::kBlkVecs + w.lane;
+#pragma unroll
+    for (int q = 0; q < S::PRODUCTS; ++q) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int b = 0; b < NBW; ++b)
+                acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wk[t][P::W[q]], x[HB][b][P::X[q]], acc[t][b], 0, 0, 0);
+        if (q < 3) {
+#pragma unroll
+            for (int b = 0; b < NBW; ++b)
+                x[HB ^ 1][b][2 - q] = __builtin_bit_cast(bf16x8, p[b * S::kBlkVecs + (2 - q) * 64]);
+        }
+    }
+}
+
+template <class S, int NT, int HB>
+__device__ __forceinline__ void ws_kblock(const WsWave& w, f32x16 (&acc)[S::TPW][S::NBW],
+                                          const bf16x8 (&wk)[S::TPW][S::PARTS], WsOps<S>& ops, int next) {
+    if constexpr (S::PARTS == 2) ws_kblock2<S, NT, HB>(w, acc, wk, ops.xb, ops.xh, next);
+    else ws_kblock3<S, NT, HB>(w, acc, wk, ops.x, next);
+}
+
 template <class S, int NT, int NVM>
 __device__ __forceinline__ void ws_pin_kblock() {
     constexpr int NBW = S::NBW;
+    if constexpr (S::PARTS == 3) {
+        // a ds_read behind each of the first 3 NBW matrix instructions (the other operand set), the
+        // NVM weight requests behind the last ones
+        constexpr int total = S::PRODUCTS * NT * NBW;
+#pragma unroll
+        for (int i = 0; i < total; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (i < 3 * NBW) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (i >= total - NVM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        return;
+    }
     constexpr int third = NT * NBW;
 #pragma unroll
     for (int i = 0; i < third; ++i) {              // w_hi x_lo: block b's lo operand is free after
@@ -199,25 +270,25 @@ __device__ __forceinline__ void ws_pin_kblock() {
 // chunk in weight buffer P: K blocks g, g + 1 of the X image (operands of g already in x)
 template <class S, int NT, int P>
 __device__ __forceinline__ void ws_chunk(WsWave& w, f32x16 (&acc)[S::TPW][S::NBW],
-                                         bf16x8 (&wreg)[2][2][S::TPW][2], bf16x8 (&x)[S::NBW][2],
-                                         bf16x8 (&xh)[S::NBW], int g, int g_last) {      // (X K-block indices)
+                                         bf16x8 (&wreg)[2][2][S::TPW][S::PARTS], WsOps<S>& ops,
+                                         int g, int g_last) {      // (X K-block indices)
     int c2 = w.cpos + 2;                                   // (uniform; branch-free: the chunk stays
     c2 -= c2 >= w.total_chunks ? w.total_chunks : 0;       // one basic block whose issue order is
     c2 -= c2 >= w.total_chunks ? w.total_chunks : 0;       // pinned; twice for one-chunk toy chains)
     // the registers of a K block's weights are refilled (chunk after next, same buffer) as soon as
     // its matrix instructions have issued: every request has a chunk and a half -- 36 matrix
     // instructions of this wave, >= 1.1k cycles -- to come back from L2
-    ws_kblock<S, NT, 0>(w, acc, wreg[P][0], x, xh, g + 1);
+    ws_kblock<S, NT, 0>(w, acc, wreg[P][0], ops, g + 1);
     ws_load_kblock<S>(w, wreg[P][0], c2, 0);
     const int nxt = g + 2 <= g_last ? g + 2 : g_last;     // (the last chunk re-reads, never consumed)
-    ws_kblock<S, NT, 1>(w, acc, wreg[P][1], x, xh, nxt);
+    ws_kblock<S, NT, 1>(w, acc, wreg[P][1], ops, nxt);
     ws_load_kblock<S>(w, wreg[P][1], c2, 1);
     w.cpos = w.cpos + 1 < w.total_chunks ? w.cpos + 1 : 0;
-    if (NT > 0) {
+    if constexpr (NT > 0) {
         // (a K block's pattern carries the requests issued BEHIND THE PREVIOUS K block, whose
         // registers were free from its last matrix instruction on)
         ws_pin_kblock<S, NT, 0>();
-        ws_pin_kblock<S, NT, 2 * S::TPW>();
+        ws_pin_kblock<S, NT, S::PARTS * S::TPW>();
     }
 }
 
@@ -225,8 +296,8 @@ __device__ __forceinline__ void ws_chunk(WsWave& w, f32x16 (&acc)[S::TPW][S::NBW
 // an odd number of chunks: the two weight buffers then have to trade places before the next chunk.
 template <class S, int NT>
 __device__ __forceinline__ bool ws_segment(WsWave& w, f32x16 (&acc)[S::TPW][S::NBW],
-                                           bf16x8 (&wreg)[2][2][S::TPW][2], bf16x8 (&xb)[S::NBW][2],
-                                           bf16x8 (&xh)[S::NBW], int count, int g0 = 0) {
+                                           bf16x8 (&wreg)[2][2][S::TPW][S::PARTS], WsOps<S>& ops,
+                                           int count, int g0 = 0) {
     if (NT == 0) {                  // a wave without a tile in this step only keeps count
         w.cpos = (w.cpos + (count >> 1)) % w.total_chunks;
         w.stale = true;
@@ -236,40 +307,53 @@ __device__ __forceinline__ bool ws_segment(WsWave& w, f32x16 (&acc)[S::TPW][S::N
         ws_load_chunk<S>(w, wreg[0], w.cpos);
         ws_load_chunk<S>(w, wreg[1], w.cpos + 1 < w.total_chunks ? w.cpos + 1 : 0);
         w.stale = false;
-        // "Use" the last request here: the compiler then waits for these eight loads on THIS
+        // "Use" the last request here: the compiler then waits for these loads on THIS
         // (rare) path.  Otherwise its wait-count analysis merges this state -- every weight
         // register pending, the newest last -- into the loop head, and the steady state of the K
         // loop waits with vmcnt(0) for requests it issued a few instructions earlier.
-        asm volatile("" ::"v"(wreg[1][1][S::TPW - 1][1]));
+        asm volatile("" ::"v"(wreg[1][1][S::TPW - 1][S::PARTS - 1]));
     }
-    ws_read_x<S>(w, xb, g0, 1);
-    ws_read_x<S>(w, xb, g0, 0);
+    if constexpr (S::PARTS == 2) {
+        ws_read_x<S>(w, ops.xb, g0, 1);
+        ws_read_x<S>(w, ops.xb, g0, 0);
+    } else {
+        ws_read_x<S>(w, ops.x[0], g0, 2);
+        ws_read_x<S>(w, ops.x[0], g0, 1);
+        ws_read_x<S>(w, ops.x[0], g0, 0);
+    }
     // (pairs of chunks in ONE basic block per trip, the odd chunk outside the loop: with a
     // conditional second chunk inside it, hipcc builds a loop in which chunk<1> can follow
     // chunk<1>, and its wait-count analysis then makes every weight register wait for the four
     // newest requests -- the ones issued a few instructions earlier)
     int g = 0;
     for (; g + 4 <= count; g += 4) {
-        ws_chunk<S, NT, 0>(w, acc, wreg, xb, xh, g0 + g, g0 + count - 1);
-        ws_chunk<S, NT, 1>(w, acc, wreg, xb, xh, g0 + g + 2, g0 + count - 1);
+        ws_chunk<S, NT, 0>(w, acc, wreg, ops, g0 + g, g0 + count - 1);
+        ws_chunk<S, NT, 1>(w, acc, wreg, ops, g0 + g + 2, g0 + count - 1);
     }
     const bool odd = g < count;
-    if (odd) ws_chunk<S, NT, 0>(w, acc, wreg, xb, xh, g0 + g, g0 + count - 1);
+    if (odd) ws_chunk<S, NT, 0>(w, acc, wreg, ops, g0 + g, g0 + count - 1);
     return odd;
 }
 
 template <class S>
-__device__ __forceinline__ void ws_swap(bf16x8 (&wreg)[2][2][S::TPW][2]) {
+__device__ __forceinline__ void ws_swap(bf16x8 (&wreg)[2][2][S::TPW][S::PARTS]) {
 #pragma unroll
     for (int k = 0; k < 2; ++k)
 #pragma unroll
         for (int t = 0; t < S::TPW; ++t)
 #pragma unroll
-            for (int part = 0; part < 2; ++part) {
+            for (int part = 0; part < S::PARTS; ++part) {
                 const bf16x8 tmp = wreg[0][k][t][part];
                 wreg[0][k][t][part] = wreg[1][k][t][part];
                 wreg[1][k][t][part] = tmp;
             }
+}
+
+// eight f32 values as the S::PARTS bf16 operand parts of the mode
+template <class S>
+__device__ __forceinline__ void ws_split(const float (&v)[8], bf16x8 (&part)[S::PARTS]) {
+    if constexpr (S::PARTS == 2) split8(v, part[0], part[1]);
+    else split8x3(v, part[0], part[1], part[2]);
 }
 
 // Sign masks (mlp.hip's format): per (slot, block) TPW records of 64 lanes x 16 bytes -- a narrow
@@ -313,7 +397,7 @@ struct WsFwd : WsWave {
 
 template <class S, bool TRAIN, bool HWSIN>
 __device__ __forceinline__ void ws_step_fwd(const ffn_mlp_chain& ch, const ffn_step& L, bool last_step,
-                                            WsFwd<S>& w, bf16x8 (&wreg)[2][2][S::TPW][2]) {
+                                            WsFwd<S>& w, bf16x8 (&wreg)[2][2][S::TPW][S::PARTS]) {
     constexpr int NB = S::NB, NBW = S::NBW, TPW = S::TPW;
     constexpr int KBMAX = S::KBMAX;
     const int ot = L.out_tiles;
@@ -341,12 +425,12 @@ __device__ __forceinline__ void ws_step_fwd(const ffn_mlp_chain& ch, const ffn_s
             }
         }
     }
-    bf16x8 xb[NBW][2], xh[NBW];
+    WsOps<S> ops;
     bool swap_due = false;
     auto run = [&](int count, int g0) -> bool {
-        if (nt == 0) return ws_segment<S, 0>(w, acc, wreg, xb, xh, count, g0);
-        if (TPW > 1 && nt == 1) return ws_segment<S, 1>(w, acc, wreg, xb, xh, count, g0);
-        return ws_segment<S, TPW>(w, acc, wreg, xb, xh, count, g0);
+        if (nt == 0) return ws_segment<S, 0>(w, acc, wreg, ops, count, g0);
+        if (TPW > 1 && nt == 1) return ws_segment<S, 1>(w, acc, wreg, ops, count, g0);
+        return ws_segment<S, TPW>(w, acc, wreg, ops, count, g0);
     };
     if (kb_act > 0) swap_due = run(kb_act, 0);     // X holds the previous step's output (filled)
     if (kb_feat > 0) {
@@ -384,11 +468,11 @@ __device__ __forceinline__ void ws_step_fwd(const ffn_mlp_chain& ch, const ffn_s
                     __builtin_nontemporal_store(f0, &fsave[saved_index16(cq, w.s)]);
                     __builtin_nontemporal_store(f1, &fsave[saved_index16(cq + 1, w.s)]);
                 }
-                bf16x8 fh, fl;
-                split8(f, fh, fl);
+                bf16x8 fp[S::PARTS];
+                ws_split<S>(f, fp);
                 f32x4* dst = w.xbuf + ws_x_index<S>(x0 + G, fb, 0) + w.lane;
-                dst[0] = __builtin_bit_cast(f32x4, fh);
-                dst[64] = __builtin_bit_cast(f32x4, fl);
+#pragma unroll
+                for (int part = 0; part < S::PARTS; ++part) dst[64 * part] = __builtin_bit_cast(f32x4, fp[part]);
             }
         };
         if (kb_act == 0) {
@@ -445,7 +529,7 @@ __device__ __forceinline__ void ws_step_fwd(const ffn_mlp_chain& ch, const ffn_s
     // leaves its K loops early (the older wave of a SIMD wins the matrix pipe) does its ReLU /
     // sign-bit / bf16-split / head arithmetic under the matrix instructions of the waves still
     // multiplying; after the barrier only the 16-byte LDS stores are left.
-    bf16x8 res[S::TPW][NBW][2][2];
+    bf16x8 res[S::TPW][NBW][2][S::PARTS];
     int save_s = w.s, save_h = w.h, e_lane = w.lane;
     asm volatile("" : "+v"(save_s), "+v"(save_h), "+v"(e_lane));     // (see mlp_bf16.hip: no hoisted address tables)
     const int64_t blk0 = w.block0 + w.b0;          // this wave's first block of the launch
@@ -494,7 +578,7 @@ __device__ __forceinline__ void ws_step_fwd(const ffn_mlp_chain& ch, const ffn_s
                         for (int c = 0; c < 4; ++c) w.logit[b][c] = __builtin_fmaf(y[j], w4[c], w.logit[b][c]);
                     }
                 }
-                if (!last_step) split8(y, res[t][b][half][0], res[t][b][half][1]);
+                if (!last_step) ws_split<S>(y, res[t][b][half]);
             }
             if (TRAIN && L.relu && L.mask_slot >= 0 && live) {
                 *reinterpret_cast<uint16_t*>(w.masks + ws_mask_at<S>(L.mask_slot, w.num_blocks, blk0 + b, e_lane, o, ot)) =
@@ -514,8 +598,9 @@ __device__ __forceinline__ void ws_step_fwd(const ffn_mlp_chain& ch, const ffn_s
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
                     f32x4* dst = w.xbuf + ws_x_index<S>(2 * o + half, w.b0 + b, 0) + e_lane;
-                    dst[0] = __builtin_bit_cast(f32x4, res[t][b][half][0]);
-                    dst[64] = __builtin_bit_cast(f32x4, res[t][b][half][1]);
+#pragma unroll
+                    for (int part = 0; part < S::PARTS; ++part)
+                        dst[64 * part] = __builtin_bit_cast(f32x4, res[t][b][half][part]);
                 }
         }
         ws_barrier();                              // the step's output is in X
@@ -558,7 +643,7 @@ mlp_forward_bf16_ws_kernel(const ffn_mlp_chain ch, const uint16_t* __restrict__ 
     w.masks = reinterpret_cast<char*>(masks);
     w.num_blocks = (n + 31) / 32;
     const int64_t passes = (w.num_blocks + NB - 1) / NB;
-    bf16x8 wreg[2][2][S::TPW][2];
+    bf16x8 wreg[2][2][S::TPW][S::PARTS];
     __syncthreads();                               // tables and biases are staged
     const int fb = w.wave % NB;
     float in_next[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -618,7 +703,7 @@ struct WsBwd : WsWave {
 
 template <class S>
 __device__ __forceinline__ void ws_step_bwd(const ffn_mlp_chain& ch, const ffn_step& L, bool last_step,
-                                            WsBwd<S>& w, bf16x8 (&wreg)[2][2][S::TPW][2]) {
+                                            WsBwd<S>& w, bf16x8 (&wreg)[2][2][S::TPW][S::PARTS]) {
     constexpr int NB = S::NB, NBW = S::NBW, TPW = S::TPW;
     const int ot = L.out_tiles;
     const int kb_act = L.act_groups >> 1;
@@ -646,12 +731,12 @@ __device__ __forceinline__ void ws_step_bwd(const ffn_mlp_chain& ch, const ffn_s
         for (int b = 0; b < NBW; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][b][r] = 0.0f;
-    bf16x8 xb[NBW][2], xh[NBW];
+    WsOps<S> ops;
     bool swap_due = false;
     auto run = [&](int count) -> bool {
-        if (nt == 0) return ws_segment<S, 0>(w, acc, wreg, xb, xh, count, 0);
-        if (TPW > 1 && nt == 1) return ws_segment<S, 1>(w, acc, wreg, xb, xh, count, 0);
-        return ws_segment<S, TPW>(w, acc, wreg, xb, xh, count, 0);
+        if (nt == 0) return ws_segment<S, 0>(w, acc, wreg, ops, count, 0);
+        if (TPW > 1 && nt == 1) return ws_segment<S, 1>(w, acc, wreg, ops, count, 0);
+        return ws_segment<S, TPW>(w, acc, wreg, ops, count, 0);
     };
     if (kb_act > 0) swap_due = run(kb_act);
     if (L.aux_groups > 0) {
@@ -670,18 +755,18 @@ __device__ __forceinline__ void ws_step_bwd(const ffn_mlp_chain& ch, const ffn_s
                 v[j] = (G == 0 && w.h == 0 && j < L.lg_n && c < 4) ? d : 0.0f;
                 v[4 + j] = 0.0f;
             }
-            bf16x8 dh, dlo;
-            split8(v, dh, dlo);
+            bf16x8 dp[S::PARTS];
+            ws_split<S>(v, dp);
             f32x4* dst = w.xbuf + ws_x_index<S>(G, item % NB, 0) + w.lane;
-            dst[0] = __builtin_bit_cast(f32x4, dh);
-            dst[64] = __builtin_bit_cast(f32x4, dlo);
+#pragma unroll
+            for (int part = 0; part < S::PARTS; ++part) dst[64 * part] = __builtin_bit_cast(f32x4, dp[part]);
         }
         ws_barrier();
         swap_due = run(2);
     }
     // ---- epilogue: mask, save dZ, the next step's operands into X (arithmetic and global stores
     // before the "all consumed" barrier, the LDS stores after it: see the forward step)
-    bf16x8 res[S::TPW][NBW][2][2];
+    bf16x8 res[S::TPW][NBW][2][S::PARTS];
     int save_s = w.s, save_h = w.h, e_lane = w.lane;
     asm volatile("" : "+v"(save_s), "+v"(save_h), "+v"(e_lane));
 #pragma unroll
@@ -714,7 +799,7 @@ __device__ __forceinline__ void ws_step_bwd(const ffn_mlp_chain& ch, const ffn_s
                     __builtin_nontemporal_store(y0, &save_out[saved_index16(cq, save_s)]);
                     __builtin_nontemporal_store(y1, &save_out[saved_index16(cq + 2, save_s)]);
                 }
-                if (!last_step) split8(y, res[t][b][half][0], res[t][b][half][1]);
+                if (!last_step) ws_split<S>(y, res[t][b][half]);
             }
         }
     }
@@ -730,8 +815,9 @@ __device__ __forceinline__ void ws_step_bwd(const ffn_mlp_chain& ch, const ffn_s
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
                     f32x4* dst = w.xbuf + ws_x_index<S>(2 * o + half, w.b0 + b, 0) + e_lane;
-                    dst[0] = __builtin_bit_cast(f32x4, res[t][b][half][0]);
-                    dst[64] = __builtin_bit_cast(f32x4, res[t][b][half][1]);
+#pragma unroll
+                    for (int part = 0; part < S::PARTS; ++part)
+                        dst[64 * part] = __builtin_bit_cast(f32x4, res[t][b][half][part]);
                 }
         }
         ws_barrier();
@@ -767,7 +853,7 @@ mlp_backward_bf16_ws_kernel(const ffn_mlp_chain ch, const uint16_t* __restrict__
     w.masks = reinterpret_cast<const char*>(masks);
     w.num_blocks = (n + 31) / 32;
     const int64_t passes = (w.num_blocks + NB - 1) / NB;
-    bf16x8 wreg[2][2][S::TPW][2];
+    bf16x8 wreg[2][2][S::TPW][S::PARTS];
     const int fb = w.wave % NB;
     f32x4 dl_next = (f32x4)(0.0f);
     auto request_inputs = [&](int64_t pass) {
@@ -868,4 +954,91 @@ int launch_backward16_ws(const ffn_mlp_chain* chain, const uint16_t* packed_wt, 
     return 0;
 }
 
+// ---------------------------------------------------------------------------------- bf16x6
+typedef WsShape<1, 1, 3, 6> WsSplit6;       // three parts, six partial products: the f32-accurate mode
+typedef WsShape<1, 1, 3, 9> WsSplit9;       // all nine partial products (FFN_BF16X6_PRODUCTS=9: measurement)
+
+inline bool bf16x6_nine_products() {        // read per launch: the probe flips it inside one process
+    const char* v = getenv("FFN_BF16X6_PRODUCTS");
+    return v != nullptr && v[0] == '9';
+}
+
+// (encoding features: the f32 kernels' polynomials, bit for bit -- the hardware sin / cos of the
+// bf16x3 kernels is 2.4e-7 off, which an f32-accurate mode cannot afford)
+int launch_forward_bf16x6(const ffn_mlp_chain* chain, const uint16_t* packed_w, const float* bias,
+                          const float* positions, const float* views, int64_t n, float* logits,
+                          float* saved, uint32_t* masks, void* stream) {
+    if (bf16x6_nine_products()) {
+        if (saved != nullptr) ws_launch_fwd<WsSplit9, true, false>(chain, packed_w, bias, positions, views, n, logits, saved, masks, stream);
+        else ws_launch_fwd<WsSplit9, false, false>(chain, packed_w, bias, positions, views, n, logits, nullptr, nullptr, stream);
+    } else {
+        if (saved != nullptr) ws_launch_fwd<WsSplit6, true, false>(chain, packed_w, bias, positions, views, n, logits, saved, masks, stream);
+        else ws_launch_fwd<WsSplit6, false, false>(chain, packed_w, bias, positions, views, n, logits, nullptr, nullptr, stream);
+    }
+    return 0;
+}
+
+int launch_backward_bf16x6(const ffn_mlp_chain* chain, const uint16_t* packed_wt, const float* d_logits,
+                           int64_t n, const uint32_t* masks, float* dz, void* stream) {
+    if (bf16x6_nine_products()) ws_launch_bwd<WsSplit9>(chain, packed_wt, d_logits, n, masks, dz, stream);
+    else ws_launch_bwd<WsSplit6>(chain, packed_wt, d_logits, n, masks, dz, stream);
+    return 0;
+}
+
 }  // namespace ffn
+
+using namespace ffn;
+
+static int check_chain_bf16x6(const char* what, const ffn_mlp_chain* chain, int64_t n, bool forward) {
+    if (n < 0 || chain == nullptr || chain->num_steps < 1 || chain->num_steps > FFN_MAX_STEPS) return fail_arg(what);
+    if (chain->wide != 0 || chain->bias_floats < 0) return fail_arg(what);      // narrow chains (<= 256 channels)
+    for (int i = 0; i < chain->num_steps; ++i) {
+        const ffn_step& L = chain->step[i];
+        const int ot = L.out_tiles;
+        if (!(ot == 1 || ot == 2 || ot == 4 || ot == 8) || (L.act_groups & 3) || L.act_groups < 0 ||
+            L.act_groups > 32 || L.aux_groups < 0)
+            return fail_arg(what);
+        if (forward) {
+            if (L.dst != 0 || (L.aux_groups & 3) || L.act_groups + L.aux_groups == 0 ||
+                (L.aux_groups > 0 && (L.enc_id < 0 || L.enc_id > 1)) ||
+                (L.head_off >= 0 && L.head_off + 4 + 128 * ot > 4096))
+                return fail_arg(what);
+        } else if ((L.act_groups == 0 && L.aux_groups == 0) ||
+                   (L.aux_groups > 0 && (L.lg_col < 0 || L.lg_n < 1 || L.lg_col + L.lg_n > 4))) {
+            return fail_arg(what);
+        }
+    }
+    return 0;
+}
+
+extern "C" int ffn_mlp_forward_bf16x6(const ffn_mlp_chain* chain, const uint16_t* packed_w, const float* bias,
+                                      const float* positions, const float* views, int64_t n, float* logits,
+                                      void* stream) {
+    const char* what = "ffn_mlp_forward_bf16x6: unsupported chain or size";
+    if (n == 0) return 0;
+    if (const int rc = check_chain_bf16x6(what, chain, n, true)) return rc;
+    launch_forward_bf16x6(chain, packed_w, bias, positions, views, n, logits, nullptr, nullptr, stream);
+    return check_launch(what);
+}
+
+extern "C" int ffn_mlp_forward_bf16x6_train(const ffn_mlp_chain* chain, const uint16_t* packed_w,
+                                            const float* bias, const float* positions, const float* views,
+                                            int64_t n, float* logits, float* saved, uint32_t* masks,
+                                            void* stream) {
+    const char* what = "ffn_mlp_forward_bf16x6_train: unsupported chain or size";
+    if (saved == nullptr || masks == nullptr) return fail_arg("ffn_mlp_forward_bf16x6_train: saved and masks are required");
+    if (n == 0) return 0;
+    if (const int rc = check_chain_bf16x6(what, chain, n, true)) return rc;
+    launch_forward_bf16x6(chain, packed_w, bias, positions, views, n, logits, saved, masks, stream);
+    return check_launch(what);
+}
+
+extern "C" int ffn_mlp_backward_data_bf16x6(const ffn_mlp_chain* chain, const uint16_t* packed_wt,
+                                            const float* d_logits, int64_t n, const uint32_t* masks,
+                                            float* dz, void* stream) {
+    const char* what = "ffn_mlp_backward_data_bf16x6: unsupported chain or size";
+    if (n == 0) return 0;
+    if (const int rc = check_chain_bf16x6(what, chain, n, false)) return rc;
+    launch_backward_bf16x6(chain, packed_wt, d_logits, n, masks, dz, stream);
+    return check_launch(what);
+}

@@ -279,6 +279,7 @@ class MlpProgram:
         self._build_wgrad_jobs()
         self._build_forward16()
         self._build_backward16()
+        self._build_x6()
         self._build_pair_chains()
 
     def _dz_buffer(self, floats: int) -> torch.Tensor:
@@ -489,6 +490,7 @@ class MlpProgram:
         self.fwd16 = None
         self.packed16 = None
         self._packed16_dirty = True
+        self._packed_x6_dirty = True
         self.tiles16 = 16 if self.wide else 8
         if self.device.type != "cuda":
             return
@@ -624,6 +626,29 @@ class MlpProgram:
         self.bwd16 = chain
         self.packed16_bwd = torch.zeros((max(off, 1),), dtype=torch.int16, device=self.device)
 
+    def _build_x6(self):
+        """Chains + operand buffers of the F32-ACCURATE split mode ("bf16x6", mlp_bf16_ws.hip):
+        the split-bf16 chains with every operand as THREE bf16 parts (hi, mid, lo -- the f32 value
+        exactly) instead of two, i.e. the same K order and job tables with 1.5x the offsets
+        (``ffn_mlp_pack_bf16_parts(parts=3)``).  Narrow chains only (<= 256 channels per layer:
+        the three-part X image of a 512-wide chain does not fit the LDS)."""
+        self.fwd_x6 = self.bwd_x6 = None
+        self.packed_x6 = self.packed_x6_bwd = None
+        self._packed_x6_dirty = True
+        if self.fwd16 is None or self.wide:
+            return
+
+        def scaled(chain16, total16):
+            chain = FfnMlpChain.from_buffer_copy(bytes(chain16))
+            for k in range(chain.num_steps):
+                assert chain.step[k].w_off % 2 == 0
+                chain.step[k].w_off = chain.step[k].w_off * 3 // 2
+            return chain, torch.zeros((max(total16 * 3 // 2, 1),), dtype=torch.int16, device=self.device)
+
+        self.fwd_x6, self.packed_x6 = scaled(self.fwd16, self.packed16.numel())
+        if self.bwd16 is not None:
+            self.bwd_x6, self.packed_x6_bwd = scaled(self.bwd16, self.packed16_bwd.numel())
+
     def _build_wgrad_jobs(self):
         """Weight-gradient work list: LDS-staged units of <=256 output x <=256 input channels
         for the hidden layers, head units (<=4 output rows) for the logits heads.  Inputs are
@@ -757,21 +782,37 @@ class MlpProgram:
                     reduce_jobs=reduce_jobs, slots=slot)
 
     # ------------------------------------------------------------------ packing
-    def pack16(self):
-        """(hi, lo) bf16 operand copies of the current weights for the split-bf16 kernel."""
+    def pack16(self, parts: int = 2):
+        """bf16 operand copies of the current weights for the split kernels: ``parts`` = 2 the
+        (hi, lo) packs of the bf16x3 kernels, 3 the (hi, mid, lo) packs of the bf16x6 kernels."""
+        fwd_buf, bwd_buf = (self.packed16, self.packed16_bwd) if parts == 2 else (self.packed_x6, self.packed_x6_bwd)
+        unit = self.tiles16 * 512 * parts        # elements per K block: tiles x parts x 64 lanes x 8 bf16
         for (i, kblocks, cmap, off) in self.pack16_jobs:
             w = self.layers[i].weight.detach()
-            dst = self.packed16[off:off + kblocks * self.tiles16 * 1024]
-            _call("ffn_mlp_pack_bf16", _dev(w), c_i(w.shape[0]), c_i(w.shape[1]), c_i(w.stride(0)),
-                  _dev(cmap, torch.int32), c_i(kblocks), c_i(self.tiles16), c_i(0), _dev(dst, torch.int16))
-        for (c, kblocks, cmap, off) in (self.pack16_bwd_jobs if self.bwd16 is not None else []):
-            w = self.layers[c].weight.detach()
-            dst = self.packed16_bwd[off:off + kblocks * self.tiles16 * 1024]
-            # operand rows = the consumer's input channels (its activation part), K = its rows
-            _call("ffn_mlp_pack_bf16", _dev(w), c_i(w.shape[0]), c_i(self.layers[c].act_in),
-                  c_i(w.stride(0)), _dev(cmap, torch.int32), c_i(kblocks), c_i(self.tiles16), c_i(1),
+            off = off * parts // 2
+            dst = fwd_buf[off:off + kblocks * unit]
+            _call("ffn_mlp_pack_bf16_parts", _dev(w), c_i(w.shape[0]), c_i(w.shape[1]), c_i(w.stride(0)),
+                  _dev(cmap, torch.int32), c_i(kblocks), c_i(self.tiles16), c_i(0), c_i(parts),
                   _dev(dst, torch.int16))
-        self._packed16_dirty = False
+        for (c, kblocks, cmap, off) in (self.pack16_bwd_jobs if bwd_buf is not None else []):
+            w = self.layers[c].weight.detach()
+            off = off * parts // 2
+            dst = bwd_buf[off:off + kblocks * unit]
+            # operand rows = the consumer's input channels (its activation part), K = its rows
+            _call("ffn_mlp_pack_bf16_parts", _dev(w), c_i(w.shape[0]), c_i(self.layers[c].act_in),
+                  c_i(w.stride(0)), _dev(cmap, torch.int32), c_i(kblocks), c_i(self.tiles16), c_i(1),
+                  c_i(parts), _dev(dst, torch.int16))
+        if parts == 2:
+            self._packed16_dirty = False
+        else:
+            self._packed_x6_dirty = False
+
+    def _x6_ready(self):
+        if self.fwd_x6 is None:
+            raise NotImplementedError("the bf16x6 kernels cover chains of <= 256 channels per layer "
+                                      "whose logits heads are fused")
+        if self._packed_x6_dirty:
+            self.pack16(parts=3)
 
     def forward16(self, positions: torch.Tensor, views: Optional[torch.Tensor]) -> torch.Tensor:
         """Inference in the opt-in split-bf16 mode (3 bf16 matrix products per f32 product):
@@ -831,6 +872,7 @@ class MlpProgram:
         """Re-derives the MFMA-operand copies (and the bias / fused-head blocks) from the current
         nn.Linear weights: one launch over the job table."""
         self._packed16_dirty = True
+        self._packed_x6_dirty = True
         if getattr(self, "_pack_jobs_dev", None) is None:
             self._pack_jobs()
         _call("ffn_mlp_pack_jobs", _dev(self._pack_jobs_dev, torch.uint8), c_i(self._pack_job_count))
@@ -910,7 +952,8 @@ class MlpProgram:
                 saved: Optional[torch.Tensor] = None, precision: str = "f32") -> torch.Tensor:
         """positions (N,3) [views (N,3)] -> raw logits (N,4).  ``saved`` (a flat float
         buffer of ``saved_floats(N)`` elements) receives what the backward pass needs.
-        ``precision="bf16x3"`` (opt-in) runs the split-bf16 kernel."""
+        ``precision="bf16x3"`` (opt-in) runs the split-bf16 kernel, ``"bf16x6"`` (opt-in) the
+        f32-accurate three-part split (six bf16 matrix products per f32 product)."""
         n = positions.shape[0]
         logits = torch.empty((n, 4), dtype=torch.float32, device=self.device)
         acts, masks = (None, None) if saved is None else self._split_saved(saved, n)
@@ -932,8 +975,20 @@ class MlpProgram:
                   _dev(positions, name="positions"), _dev(views, name="views"), c_i64(n),
                   _dev(logits), _dev(acts), _dev(masks))
             return logits
+        if precision == "bf16x6":
+            self._x6_ready()
+            if saved is None:
+                _call("ffn_mlp_forward_bf16x6", ctypes.byref(self.fwd_x6), _dev(self.packed_x6, torch.int16),
+                      _dev(self.bias_buf), _dev(positions, name="positions"), _dev(views, name="views"),
+                      c_i64(n), _dev(logits))
+            else:
+                _call("ffn_mlp_forward_bf16x6_train", ctypes.byref(self.fwd_x6),
+                      _dev(self.packed_x6, torch.int16), _dev(self.bias_buf),
+                      _dev(positions, name="positions"), _dev(views, name="views"), c_i64(n),
+                      _dev(logits), _dev(acts), _dev(masks))
+            return logits
         if precision != "f32":
-            raise ValueError("precision is 'f32' or 'bf16x3'")
+            raise ValueError("precision is 'f32', 'bf16x3' or 'bf16x6'")
         plan = None if saved is None else self._tail_plan(n)
         head = None if plan is None else plan[0]
         if head is None:
@@ -1033,7 +1088,9 @@ class MlpProgram:
         launch was split (``_tail_split``) leaves the tail blocks' ReLU masks in a region only the
         f32 backward reads -- a mismatch raises instead of differentiating with stale masks.
         ``precision="bf16x3"`` (opt-in) runs the split-bf16 backward-data and weight-gradient
-        kernels."""
+        kernels; ``"bf16x6"`` (opt-in) the f32-accurate three-part backward-data kernel and the
+        EXACT-f32 weight-gradient units (twice the matrix instructions would make that kernel
+        slower than the exact one)."""
         n = positions.shape[0]
         if n == 0:                      # an empty batch contributes no gradient
             return grads.zero_()
@@ -1049,7 +1106,13 @@ class MlpProgram:
         ws.use_plan("bf16x3" if wgrad16 else "f32")
         whole = saved
         saved, masks = self._split_saved(saved, n)
-        if precision == "bf16x3" and self.bwd16 is not None:
+        if precision == "bf16x6":
+            self._x6_ready()
+            if self.bwd_x6 is not None:
+                _call("ffn_mlp_backward_data_bf16x6", ctypes.byref(self.bwd_x6),
+                      _dev(self.packed_x6_bwd, torch.int16), _dev(d_logits), c_i64(n), _dev(masks),
+                      _dev(ws.dz))
+        elif precision == "bf16x3" and self.bwd16 is not None:
             if self._packed16_dirty:
                 self.pack16()
             _call("ffn_mlp_backward_data_bf16x3", ctypes.byref(self.bwd16),

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define FFN_ABI_VERSION 2
+#define FFN_ABI_VERSION 3
 
 int ffn_abi_version(void);
 const char* ffn_last_error_string(void);
@@ -465,6 +465,37 @@ int ffn_mlp_forward_bf16x3_train(const ffn_mlp_chain* chain, const uint16_t* pac
  * 0..lg_n-1 are the head's rows) and step.out_slot = the slab slot of the step's dZ.
  * Reads the sign masks, writes every dZ slab in the f32 kernels' format. */
 int ffn_mlp_backward_data_bf16x3(const ffn_mlp_chain* chain, const uint16_t* packed_wt,
+                                 const float* d_logits, int64_t n, const uint32_t* masks,
+                                 float* dz, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * OPT-IN f32-ACCURATE split mode of K4 ("bf16x6"; separately labelled, the exact-f32 entry points
+ * stay the parity mode and the headline).  Every f32 operand is THREE bf16 parts (hi, mid, lo:
+ * 8 + 8 + 8 significand bits = the f32 value exactly) and every f32 product SIX
+ * v_mfma_f32_32x32x16_bf16 instructions -- every partial product down to 2^-16 of the leading
+ * one (h.l, l.h, m.m, h.m, m.h, h.h, smallest first; the three dropped terms are each below 2^-24
+ * of it), f32 accumulation: 12 matrix cycles per K where v_mfma_f32_32x32x2_f32 takes 32, at the
+ * error of an f32 dot product (same networks, same tolerances as the exact mode in the tests).
+ * Same organisation, chains, slab and mask formats as the bf16x3 entry points (csrc/mlp_bf16_ws.hip:
+ * eight waves, one output tile each, two blocks of 32 samples per pass); operands come from
+ * ffn_mlp_pack_bf16_parts(parts = 3): dst[(((G*tiles + o)*parts + part)*64 + lane)*8 + j], part p =
+ * bf16(v - part 0 - .. - part p-1) (parts = 2 is ffn_mlp_pack_bf16), so every w_off of the bf16x3
+ * chain scales by 3/2.  Narrow chains (<= 256 channels per layer) with fused heads; encoding
+ * features are the exact-f32 kernels' (polynomial sin / cos, bit for bit).  The weight gradients of
+ * this mode are the exact-f32 units (ffn_mlp_wgrad_units) on the slabs these kernels write.
+ * FFN_BF16X6_PRODUCTS=9 (environment, measurement only) multiplies out all nine partial products.
+ * Reference arithmetic being matched: fourier_feature_models.py:57-78, nerf_model.py:86-124. */
+int ffn_mlp_pack_bf16_parts(const float* src, int rows, int cols, int ld, const int32_t* col_map,
+                            int kblocks, int tiles, int transpose, int parts, uint16_t* dst,
+                            void* stream);
+int ffn_mlp_forward_bf16x6(const ffn_mlp_chain* chain, const uint16_t* packed_w, const float* bias,
+                           const float* positions, const float* views, int64_t n, float* logits,
+                           void* stream);
+int ffn_mlp_forward_bf16x6_train(const ffn_mlp_chain* chain, const uint16_t* packed_w,
+                                 const float* bias, const float* positions, const float* views,
+                                 int64_t n, float* logits, float* saved, uint32_t* masks,
+                                 void* stream);
+int ffn_mlp_backward_data_bf16x6(const ffn_mlp_chain* chain, const uint16_t* packed_wt,
                                  const float* d_logits, int64_t n, const uint32_t* masks,
                                  float* dz, void* stream);
 

@@ -215,6 +215,34 @@ def sample(state: Dict[str, object], idx, step: Optional[int], num_samples: int,
     return positions, dirs_rs, t, idx_t
 
 
+def voxels_forward(voxels: torch.Tensor, bias: torch.Tensor, scale: float,
+                   positions: torch.Tensor) -> torch.Tensor:
+    """Raw (N,4) logits of a dense voxel radiance field: trilinear lookup of ``voxels``
+    (1,4,S,S,S) at ``positions / scale`` (border padding, cell-centre sample grid) plus
+    ``bias`` (1,4).  Restates voxels_model.py:35-45."""
+    grid = (positions.reshape(1, -1, 1, 1, 3) / scale)
+    out = F.grid_sample(voxels, grid, padding_mode="border", align_corners=False)
+    return out.transpose(1, 2).reshape(-1, 4) + bias
+
+
+def opacity_cdfs(state: Dict[str, object], num_samples: int, opacity_fn, batch: int = 4096) -> torch.Tensor:
+    """The per-ray CDF table an opacity-guided sampler builds at construction: probe points
+    t = linspace(near, far, S_f) with S_f = S - S // 2, sigma = softplus(last output of the
+    opacity model), blend-weight CDF.  Restates ray_sampler.py:59-67,148-166,234-269
+    (``opacity_fn``: (N,3) positions -> (N,C) raw outputs)."""
+    n_focus = num_samples - num_samples // 2
+    near, far = state["near_far"]
+    t_probe = linspace_rows(near, far, n_focus)
+    rows = []
+    with torch.no_grad():
+        for lo in range(0, t_probe.shape[0], batch):
+            t = t_probe[lo:lo + batch]
+            pos = state["starts"][lo:lo + batch].unsqueeze(1) + t.unsqueeze(2) * state["directions"][lo:lo + batch].unsqueeze(1)
+            sigma = F.softplus(opacity_fn(pos.reshape(-1, 3))[:, -1]).reshape(t.shape)
+            rows.append(determine_cdf(t, sigma))
+    return torch.cat(rows)
+
+
 # --------------------------------------------------------------------------- #
 #  a8 / a9: encodings and MLPs
 # --------------------------------------------------------------------------- #

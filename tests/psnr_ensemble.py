@@ -74,20 +74,34 @@ def run_protocol(ffn, args, device, out_path, half, extra=None):
         seed = SEED + 1000 * k
         torch.manual_seed(seed)
         np.random.seed(seed % (2 ** 32))
-        model = ffn.PositionalFourierMLP(3, 4, max_log_scale=5.5, num_channels=256, embedding_size=256)
+        if getattr(args, "model", "tiny") == "nerf":       # train_nerf.py:85-88 with its defaults
+            model = ffn.NeRF(8, 256, 9.0, 10, 3.0, 4, [4], True)
+        else:
+            model = ffn.PositionalFourierMLP(3, 4, max_log_scale=5.5, num_channels=256, embedding_size=256)
         kwargs = {} if device is None else {"device": device}
+        opacity = None
+        if getattr(args, "opacity", "none") == "voxels":    # train_nerf.py:90-97: a frozen opacity model for both datasets
+            opacity = ffn.Voxels(args.voxel_side, 1.0)
+            with torch.no_grad():
+                opacity.voxels.copy_(torch.from_numpy(ball_volume(args.voxel_side)))
+            if device is not None:
+                opacity = opacity.to(device)
+                kwargs["focus_mode"] = "table"      # the reference's snapshot-at-construction CDFs
         with contextlib.redirect_stdout(io.StringIO()):
-            train = ffn.ImageDataset.load(npz, "train", args.samples, True, True, None, 4096, "RGB",
+            train = ffn.ImageDataset.load(npz, "train", args.samples, True, True, opacity, 4096, "RGB",
                                           anneal_start=0.2, num_anneal_steps=args.anneal_steps, **kwargs)
-            val = ffn.ImageDataset.load(npz, "val", args.samples, True, False, None, 4096, "RGB", **kwargs)
+            val = ffn.ImageDataset.load(npz, "val", args.samples, True, False, opacity, 4096, "RGB", **kwargs)
         if device is not None:
             model = model.to(device)
-            model.train_precision = getattr(args, "precision", "f32")
+            if hasattr(args, "precision"):      # (otherwise the model's own default / FFN_PRECISION)
+                model.train_precision = args.precision
+            if getattr(args, "host_noise", False):
+                train.sampler.noise_source = "host"
         caster = ffn.Raycaster(model)
         tee = Tee()
         t0 = time.time()
         with contextlib.redirect_stdout(tee):
-            log = caster.fit(train, val, args.rays, 5e-4, args.steps, args.crop_steps,
+            log = caster.fit(train, val, args.rays, getattr(args, "lr", 5e-4), args.steps, args.crop_steps,
                              args.report_interval, 0.1, 25000, 0.0, [], True)
         seconds = time.time() - t0
         reports = []
@@ -112,7 +126,35 @@ def run_protocol(ffn, args, device, out_path, half, extra=None):
         return json.load(f)
 
 
+def ball_volume(side, radius=0.6, seed=4242):
+    """The frozen opacity volume of the config-3 protocol: density logit of a soft ball (the
+    scene's sphere, radius 0.6 in the cube [-1, 1]^3) plus seeded noise; colour logits seeded
+    noise.  (1,4,S,S,S) float32, a pure function of its arguments."""
+    rng = np.random.RandomState(seed)
+    axis = (np.arange(side, dtype=np.float32) + 0.5) / side * 2 - 1
+    z, y, x = np.meshgrid(axis, axis, axis, indexing="ij")
+    dist = np.sqrt(x * x + y * y + z * z)
+    volume = (rng.randn(1, 4, side, side, side) * 0.3).astype(np.float32)
+    volume[0, 3] = np.clip((radius + 0.1 - dist) * 20.0, -4.0, 5.0) + (rng.randn(side, side, side) * 0.5).astype(np.float32)
+    return volume.astype(np.float32)
+
+
 def protocol_of(args):
+    doc = _protocol_of(args)
+    # keys added after round 4 appear only when they differ from the round-4 protocol, so that the
+    # round-4 fixtures keep matching
+    if getattr(args, "model", "tiny") != "tiny":
+        doc["model"] = "NeRF(8, 256, 9.0, 10, 3.0, 4, [4], True)"
+    if getattr(args, "opacity", "none") != "none":
+        doc["opacity_model"] = ("Voxels(%d, 1.0) <- tests.psnr_ensemble.ball_volume(%d): half of every ray's "
+                                "samples drawn from its CDF (ray_sampler.py:148-166,301-357)"
+                                % (args.voxel_side, args.voxel_side))
+    if getattr(args, "lr", 5e-4) != 5e-4:
+        doc["learning_rate"] = args.lr
+    return doc
+
+
+def _protocol_of(args):
     return {"model": "PositionalFourierMLP(3, 4, 5.5, num_channels=256, embedding_size=256)",
             "scene": "tests/psnr_parity.scene(%d, %d, %d): analytic shaded sphere, RGBA"
                      % (args.cameras, args.val_cameras, args.size),
@@ -232,10 +274,19 @@ def main():
     ap.add_argument("--report-interval", type=int, default=250)
     ap.add_argument("--anneal-steps", type=int, default=500)
     ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--lr", type=float, default=5e-4)
+    ap.add_argument("--model", default="tiny", choices=["tiny", "nerf"],
+                    help="nerf = train_nerf.py's default full NeRF (8 x 256, skip at 4, view branch)")
+    ap.add_argument("--opacity", default="none", choices=["none", "voxels"],
+                    help="voxels = a frozen seeded Voxels opacity model for both datasets (config 3)")
+    ap.add_argument("--voxel-side", type=int, default=32)
+    ap.add_argument("--host-noise", action="store_true",
+                    help="hip half: draw jitter / focus noise with torch.rand on the host like the reference")
     ap.add_argument("--workdir", default=os.path.join(os.environ.get("TMPDIR", "/tmp"), "ffn_psnr_ensemble"))
     ap.add_argument("--resume", action="store_true", help="continue an interrupted --out file")
-    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3"],
-                    help="hip half: training kernels (bf16x3 = the opt-in split-bf16 mode)")
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3", "bf16x6"],
+                    help="hip half: training kernels (bf16x3 = the opt-in split-bf16 mode, bf16x6 = the "
+                         "opt-in f32-accurate three-part split)")
     args = ap.parse_args()
     if args.half == "reference":
         run_reference(args)

@@ -5,6 +5,8 @@ sequence of IEEE ops (ray state, t-values, positions, indices); everything that 
 behind a GEMM or a transcendental is compared with a stated tolerance.
 """
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -346,3 +348,53 @@ def test_fit_trajectory(golden):
                                    g["fit_final/layers.%d.weight" % i], rtol=1e-4, atol=2e-6)
         np.testing.assert_allclose(model.biases[i].detach().numpy(),
                                    g["fit_final/layers.%d.bias" % i], rtol=1e-4, atol=2e-6)
+
+
+def test_config3_fit_schedule_nerf():
+    """BASELINE config 3 as a whole: the reference's own `fit` of a full NeRF with opacity-guided
+    sampling across the crop removal (tests/golden/fit_schedule_nerf.npz, written by
+    make_fit_schedule_nerf.py from /root/reference) replayed by the oracle -- the voxel opacity
+    lookup, the CDF tables (bit-equal), the t-values of every training step (bit-equal: the
+    jitter and the focus draws come from the CPU generator in the reference's order), the losses
+    and the final weights."""
+    from tests.golden.make_fit_schedule_nerf import (ANNEAL_START, ANNEAL_STEPS, NERF, SAMPLES, SIZE,
+                                                      TRAIN_CAMS, VAL_CAMS, VOXEL_SCALE)
+    from tests.psnr_parity import BOUNDS, scene
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fit_schedule_nerf.npz"))
+    intr, poses, images, train_ids, _ = scene(TRAIN_CAMS, VAL_CAMS, SIZE)
+    st = orc.sampler_state(BOUNDS, [intr] * len(train_ids), [poses[i] for i in train_ids], SIZE, SIZE)
+    voxels, bias = _t(g["opacity/voxels"]), _t(g["opacity/bias"])
+    cdfs = orc.opacity_cdfs(st, SAMPLES, lambda p: orc.voxels_forward(voxels, bias, VOXEL_SCALE, p), batch=256)
+    assert np.array_equal(cdfs[_t(g["train_cdf_ids"])].numpy(), g["train_cdf_rows"])
+    bad = np.zeros(st["num_rays"], bool)
+    bad[st["invalid"]] = True
+    valid_rows = cdfs[torch.from_numpy(np.nonzero(~bad)[0])].double()
+    np.testing.assert_allclose([float(valid_rows.sum()), float((valid_rows ** 2).sum()), len(valid_rows)],
+                               g["train_cdf_sums"], rtol=1e-12)
+    img = images[train_ids]
+    colors = _t(img[..., :3].astype(np.float32) / 255).reshape(-1, 3)
+    alphas = _t(img[..., 3].astype(np.float32) / 255).reshape(-1)
+    crop = orc.crop_points(SIZE, SIZE)
+    crop_index = np.concatenate([crop + c * SIZE * SIZE for c in range(len(train_ids))])
+    params = {k[len("init/"):]: _t(g[k]) for k in g.files if k.startswith("init/")}
+    model = orc.OracleNeRF(params, NERF["skips"], NERF["include_inputs"])
+    trainer = orc.OracleTrainer(model, 5e-4)
+    torch.manual_seed(777)
+    n_focus = SAMPLES - SAMPLES // 2
+    offsets = np.concatenate([[0], np.cumsum(g["t_rows"])])
+    losses = []
+    for step, (batch, mode) in enumerate(zip(g["batches"], g["modes"])):
+        # `batch` indexes the dataset in its mode (ray_dataset.py: Center = the crop's index map)
+        rays = crop_index[batch] if mode == 2 else batch
+        rays = rays[~bad[rays]]
+        noise = torch.rand((len(rays), SAMPLES // 2), dtype=torch.float32)
+        focus_u = torch.rand((len(rays), n_focus), dtype=torch.float32)
+        pos, view, t, ray_t = orc.sample(st, rays, step, SAMPLES, ANNEAL_START, ANNEAL_STEPS, noise, cdfs, focus_u)
+        assert np.array_equal(t.numpy(), g["t_values"][offsets[step]:offsets[step + 1]]), step
+        gc, ga = orc.ground_truth(colors, alphas, ray_t)
+        losses.append(trainer.step(pos, view, t, gc, ga, orc.lr_decay(5e-4, step, 0.1, 25000)))
+    np.testing.assert_allclose(losses, g["losses"], rtol=2e-5, atol=1e-7)
+    for key in g.files:
+        if key.startswith("final/") and not key.endswith("encoding"):
+            np.testing.assert_allclose(model.p[key[len("final/"):]].detach().numpy(), g[key], rtol=1e-4, atol=2e-6,
+                                       err_msg=key)
