@@ -1026,8 +1026,8 @@ extern "C" int ffn_mlp_forward_bf16x6_train(const ffn_mlp_chain* chain, const ui
                                             int64_t n, float* logits, float* saved, uint32_t* masks,
                                             void* stream) {
     const char* what = "ffn_mlp_forward_bf16x6_train: unsupported chain or size";
-    if (saved == nullptr || masks == nullptr) return fail_arg("ffn_mlp_forward_bf16x6_train: saved and masks are required");
     if (n == 0) return 0;
+    if (saved == nullptr || masks == nullptr) return fail_arg("ffn_mlp_forward_bf16x6_train: saved and masks are required");
     if (const int rc = check_chain_bf16x6(what, chain, n, true)) return rc;
     launch_forward_bf16x6(chain, packed_w, bias, positions, views, n, logits, saved, masks, stream);
     return check_launch(what);
