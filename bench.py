@@ -52,7 +52,12 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--rays", type=int, default=65536, help="rays per GPU per step")
+    ap.add_argument("--rays", type=int, default=65536,
+                    help="rays per GPU per step (--scaling weak) / per step of the whole job (strong)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --rays per GPU per step, the global batch grows with N (the driver's "
+                         "contract); strong: ONE global batch of --rays rays per step, sharded over "
+                         "the N ranks (BASELINE's '1 -> 8 GPU ray throughput' read on a fixed workload)")
     ap.add_argument("--samples", type=int, default=64)
     ap.add_argument("--cameras", type=int, default=100)
     ap.add_argument("--size", type=int, default=400)
@@ -137,37 +142,59 @@ def physical_cores():
 
 def cpu_baseline(args, model_state):
     """The oracle's training step (the reference's ATen op sequence restated) on the host
-    cores, on a bounded sample of the same workload: full training step and forward only."""
+    cores, on a bounded sample of the same workload: full training step and forward only.
+    `cores` = the torch thread count actually used: the FASTEST of a sweep over 8 / 16 / 32 / 64 /
+    every physical core (two steps each, shown in `thread_sweep`: torch's CPU kernels stop scaling
+    -- and then regress -- far below the core count of a GPU host); a second sample times the
+    step at 8 192 rays (closer to the GPU line's 65 536 rays per step) at that thread count."""
     from oracle import ffn_oracle as orc
-    # torch's CPU kernels stop scaling (and then regress) far below the core count of a GPU
-    # host: `cores` = the threads actually used (the fastest count for this op mix, at most one
-    # per physical core); the host's physical / logical counts are reported next to it
     phys, logical = physical_cores()
-    cores = min(phys, 32)
-    torch.set_num_threads(cores)
-    rays, S = 1024, args.samples
+    S = args.samples
     rng = torch.Generator().manual_seed(1)
     ws = [model_state["layers.%d.weight" % i].cpu() for i in range(4)]
     bs = [model_state["layers.%d.bias" % i].cpu() for i in range(4)]
     model = orc.OracleFourierMLP(model_state["a_values"].cpu(), model_state["b_values"].cpu(), ws, bs)
     trainer = orc.OracleTrainer(model, 5e-4)
-    near = torch.full((rays,), 3.0)
-    far = torch.full((rays,), 5.0)
-    starts = torch.randn(rays, 3, generator=rng)
-    starts = 4 * starts / starts.norm(dim=-1, keepdim=True)
-    dirs = -starts / 4
-    gt_c, gt_a = torch.rand(rays, 3, generator=rng), (torch.rand(rays, generator=rng) > 0.4).float()
 
-    def one_step():
-        noise = torch.rand((rays, S), generator=rng)
-        t = orc.uniform_t(near, far, S, noise)
-        pos = starts.unsqueeze(1) + t.unsqueeze(-1) * dirs.unsqueeze(1)
-        trainer.step(pos, None, t, gt_c, gt_a, 5e-4)
+    def workload(rays):
+        near = torch.full((rays,), 3.0)
+        far = torch.full((rays,), 5.0)
+        starts = torch.randn(rays, 3, generator=rng)
+        starts = 4 * starts / starts.norm(dim=-1, keepdim=True)
+        dirs = -starts / 4
+        gt_c, gt_a = torch.rand(rays, 3, generator=rng), (torch.rand(rays, generator=rng) > 0.4).float()
 
+        def sample():
+            noise = torch.rand((rays, S), generator=rng)
+            t = orc.uniform_t(near, far, S, noise)
+            return starts.unsqueeze(1) + t.unsqueeze(-1) * dirs.unsqueeze(1), t
+
+        def one_step():
+            pos, t = sample()
+            trainer.step(pos, None, t, gt_c, gt_a, 5e-4)
+
+        def one_forward():
+            pos, t = sample()
+            trainer.loss(pos, None, t, gt_c, gt_a)
+
+        return one_step, one_forward
+
+    rays = 1024
+    one_step, one_forward = workload(rays)
+    sweep = {}
+    for threads in sorted({t for t in (8, 16, 32, 64, phys) if t <= phys} or {phys}):
+        torch.set_num_threads(threads)
+        one_step()
+        t0 = time.time()
+        one_step()
+        one_step()
+        sweep[threads] = rays * 2 / (time.time() - t0)
+    cores = max(sweep, key=sweep.get)
+    torch.set_num_threads(cores)
     one_step()
     t0 = time.time()
     done = 0
-    while time.time() - t0 < 10.0 and done < 40 or done < 2:
+    while time.time() - t0 < 8.0 and done < 40 or done < 2:
         one_step()
         done += 1
     elapsed = time.time() - t0
@@ -175,50 +202,68 @@ def cpu_baseline(args, model_state):
     t1 = time.time()
     fwd_done = 0
     with torch.no_grad():
-        while time.time() - t1 < 5.0 and fwd_done < 40 or fwd_done < 2:
-            noise = torch.rand((rays, S), generator=rng)
-            t = orc.uniform_t(near, far, S, noise)
-            pos = starts.unsqueeze(1) + t.unsqueeze(-1) * dirs.unsqueeze(1)
-            trainer.loss(pos, None, t, gt_c, gt_a)
+        while time.time() - t1 < 4.0 and fwd_done < 40 or fwd_done < 2:
+            one_forward()
             fwd_done += 1
     fwd_elapsed = time.time() - t1
+    # the same step at 8 192 rays: two steps
+    big_step, _ = workload(8192)
+    big_step()
+    t2 = time.time()
+    big_step()
+    big_elapsed = time.time() - t2
     return {"value": rays * done / elapsed, "unit": "rays/s", "cores": cores,
             "physical_cores": phys, "logical_cpus": logical, "kind": "port",
+            "thread_sweep_rays_per_s": {str(k): round(v, 1) for k, v in sorted(sweep.items())},
+            "cores_chosen_because": "fastest of the sweep (two 1024-ray training steps per thread count)",
             "forward_only_rays_per_s": rays * fwd_done / fwd_elapsed,
+            "at_8192_rays_per_step_rays_per_s": round(8192 / big_elapsed, 1),
             "sample": "%d training steps (%.1f s) and %d forward passes (%.1f s) of %d rays x %d "
-                      "samples (oracle: the reference's ATen op sequence on the host CPU, "
-                      "torch.set_num_threads(%d))" % (done, elapsed, fwd_done, fwd_elapsed, rays,
-                                                      S, cores)}
+                      "samples, one more step of 8192 rays (%.1f s) (oracle: the reference's ATen op "
+                      "sequence on the host CPU, torch.set_num_threads(%d))"
+                      % (done, elapsed, fwd_done, fwd_elapsed, rays, S, big_elapsed, cores)}
 
 
 CPU_BASELINE_CACHE = os.path.join(os.environ.get("TMPDIR", "/tmp"), "ffn_bench_cpu_baseline.json")
+CPU_BASELINE_MAX_AGE_S = 6 * 3600
+
+
+def _baseline_key(args):
+    import socket
+    phys, logical = physical_cores()
+    return {"samples": args.samples, "host": socket.gethostname(), "physical_cores": phys,
+            "logical_cpus": logical, "commit": git_head(), "uid": os.getuid()}
 
 
 def cpu_baseline_for(args, model_state, world):
     """The `cpu_baseline` object of a bench line.  N = 1 measures it (and leaves the result in a
     per-box cache file); N > 1 lines carry the same object -- the cached N = 1 measurement of this
-    box when the driver ran N = 1 first, otherwise a fresh bounded measurement on rank 0 (the other
+    box when the driver ran N = 1 first (same host, core counts, commit and user, at most six hours
+    old: anything else is measured again), otherwise a fresh bounded measurement on rank 0 (the other
     ranks wait at the final barrier) -- tagged with where it came from."""
+    key = _baseline_key(args)
     if world == 1:
         out = cpu_baseline(args, model_state)
         out["source"] = "measured in this run (N = 1)"
         try:
             with open(CPU_BASELINE_CACHE, "w") as f:
-                json.dump({"samples": args.samples, "baseline": out}, f)
+                json.dump({"key": key, "time": time.time(), "baseline": out}, f)
         except OSError:
             pass
         return out
     try:
         with open(CPU_BASELINE_CACHE) as f:
             cached = json.load(f)
-        if cached.get("samples") == args.samples:
+        age = time.time() - float(cached.get("time", 0))
+        if cached.get("key") == key and 0 <= age <= CPU_BASELINE_MAX_AGE_S:
             out = cached["baseline"]
-            out["source"] = "the N = 1 run's measurement on this box (%s)" % CPU_BASELINE_CACHE
+            out["source"] = ("the N = 1 run's measurement on this box %.0f s earlier (%s; host %s, commit %s)"
+                             % (age, CPU_BASELINE_CACHE, key["host"], key["commit"]))
             return out
-    except (OSError, ValueError, KeyError):
+    except (OSError, ValueError, KeyError, TypeError):
         pass
     out = cpu_baseline(args, model_state)
-    out["source"] = "measured on rank 0 of this N = %d run (no N = 1 measurement cached on this box)" % world
+    out["source"] = "measured on rank 0 of this N = %d run (no matching N = 1 measurement cached on this box)" % world
     return out
 
 
@@ -819,47 +864,77 @@ def render_roofline(prog, render, samples, world):
             "algorithmic_flop_per_launch": flop_per_frame, "flop_per_sample": fwd}
 
 
-def default_batch_leg(device, cams, images, bounds, rays=1024, samples=128, steps=60):
+def default_batch_leg(device, cams, images, bounds, rays=1024, samples=128, steps=600, repeats=5):
     """The reference drivers' DEFAULT batch (train_nerf.py:21-27 / train_tiny_nerf.py: 1024 rays x
     128 samples per step) through TrainEngine.train_step the way `fit` drives it (epoch-level
     validity filter, no per-step host sync), for the tiny and the full NeRF, next to the same
     step at a 32 768-ray batch: the small batch leaves each of the 1024 resident wavefronts
-    ~3.1 blocks of 32 samples, which the persistent kernels can only run as 4 rounds."""
+    ~3.1 blocks of 32 samples, which the persistent kernels can only run as 4 rounds.
+
+    Protocol (round 5): `steps` (600) steps per repeat, the MEDIAN of `repeats` (5) repeats; the
+    epoch's validity filter (`epoch_ray_ids`: one pass over the epoch's ids with one host
+    synchronisation, what `fit` does once per epoch, ray_caster.py:301-305) runs OUTSIDE the timed
+    region and is reported on its own; every repeat also records how long the HOST took to enqueue
+    its steps (clock stopped before the final synchronize) next to the time the GPU took to run
+    them (events around the repeat on the launch stream): enqueue ~ total means the box is
+    host-bound and the kernels are not what the number measures."""
     import fourier_feature_nets_amd as ffn
-    out = {"workload": "%d rays x %d samples per step (the reference's defaults), 20 cameras 400x400" % (rays, samples)}
+    out = {"workload": "%d rays x %d samples per step (the reference's defaults), 20 cameras 400x400" % (rays, samples),
+           "protocol": "%d steps per repeat, median of %d repeats; validity filter of the epoch outside the "
+                       "timed region (epoch_filter_ms); host_enqueue = wall time until the last step is "
+                       "enqueued, gpu_span = HIP events around the repeat on the launch stream" % (steps, repeats)}
     with contextlib.redirect_stdout(io.StringIO()):
         ds = ffn.ImageDataset("train", images[:20], bounds, cams[:20], samples, True, True, anneal_start=0.2,
                               num_anneal_steps=2000, device=device)
-    perm = torch.randperm(len(ds), device=device, generator=torch.Generator(device=device).manual_seed(3))
+    gen = torch.Generator(device=device).manual_seed(3)
     for name in ("tiny", "nerf"):
         torch.manual_seed(20080524)
         model = (ffn.PositionalFourierMLP(3, 4, 5.5) if name == "tiny"
                  else ffn.NeRF(8, 256, 9, 10, 3, 4, [4], True)).to(device)
         engine = ffn.TrainEngine(model, 0.0, None)
 
-        def run(first, count, batch):
-            ids, cuts = ds.epoch_ray_ids(perm[first * batch:(first + count) * batch], batch)
-            for i in range(count):
-                engine.train_step(ds, perm[(first + i) * batch:(first + i + 1) * batch], first + i, 5e-4,
-                                  rays=ids[cuts[i]:cuts[i + 1]])
-            return int(ids.numel())
+        def measure(batch, count, reps):
+            rows = []
+            for rep in range(reps + 1):             # (repeat 0 warms up)
+                index = torch.randint(0, len(ds), (count * batch,), device=device, generator=gen)
+                torch.cuda.synchronize()
+                f0 = time.perf_counter()
+                ids, cuts = ds.epoch_ray_ids(index, batch)
+                torch.cuda.synchronize()
+                filter_s = time.perf_counter() - f0
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t0 = time.perf_counter()
+                e0.record()
+                for i in range(count):
+                    engine.train_step(ds, index[i * batch:(i + 1) * batch], 1000 + i, 5e-4,
+                                      rays=ids[cuts[i]:cuts[i + 1]])
+                e1.record()
+                enqueue_s = time.perf_counter() - t0
+                torch.cuda.synchronize()
+                total_s = time.perf_counter() - t0
+                if rep:
+                    rows.append({"step_ms": 1e3 * total_s / count, "host_enqueue_ms": 1e3 * enqueue_s / count,
+                                 "gpu_span_ms": e0.elapsed_time(e1) / count, "rays": int(ids.numel()) / count,
+                                 "epoch_filter_ms": 1e3 * filter_s})
+            rows.sort(key=lambda r: r["step_ms"])
+            return rows[len(rows) // 2], rows
 
-        timings = {}
-        for label, batch, count in (("default", rays, steps), ("large", 32768, 4)):
-            run(0, 3, batch)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            traced = run(3, count, batch)
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
-            timings[label] = (dt / count, dt / traced, traced / count)
+        small, small_all = measure(rays, steps, repeats)
+        large, _ = measure(32768, 8, 3)
         engine.check_finite()
-        out[name] = {"ms_per_step": round(1e3 * timings["default"][0], 4),
-                     "valid_rays_per_step": round(timings["default"][2], 1),
-                     "rays_per_s": round(1.0 / timings["default"][1], 1),
-                     "large_batch_ms_per_step": round(1e3 * timings["large"][0], 3),
-                     "large_batch_rays_per_s": round(1.0 / timings["large"][1], 1),
-                     "per_ray_rate_vs_large_batch": round(timings["large"][1] / timings["default"][1], 4)}
+        per_ray_small = small["step_ms"] / small["rays"]
+        per_ray_large = large["step_ms"] / large["rays"]
+        out[name] = {"ms_per_step": round(small["step_ms"], 4),
+                     "ms_per_step_repeats": [round(r["step_ms"], 4) for r in small_all],
+                     "host_enqueue_ms_per_step": round(small["host_enqueue_ms"], 4),
+                     "gpu_span_ms_per_step": round(small["gpu_span_ms"], 4),
+                     "host_bound": bool(small["host_enqueue_ms"] > 0.9 * small["step_ms"]),
+                     "epoch_filter_ms": round(small["epoch_filter_ms"], 3),
+                     "valid_rays_per_step": round(small["rays"], 1),
+                     "rays_per_s": round(1e3 / per_ray_small, 1),
+                     "large_batch_ms_per_step": round(large["step_ms"], 3),
+                     "large_batch_rays_per_s": round(1e3 / per_ray_large, 1),
+                     "per_ray_rate_vs_large_batch": round(per_ray_large / per_ray_small, 4)}
         del engine, model
     return out
 
@@ -949,9 +1024,12 @@ def main():
     # rays*world rays (the validity filter of get_rays then keeps all of them)
     valid_ids = torch.nonzero(dataset.sampler.valid != 0).flatten()
     gen = torch.Generator(device=device).manual_seed(1234)
-    global_batch = args.rays * world
+    if args.scaling == "strong" and args.rays % world:
+        raise SystemExit("bench.py --scaling strong: --rays %d is not a multiple of %d ranks" % (args.rays, world))
+    global_batch = args.rays * world if args.scaling == "weak" else args.rays
+    rays_per_gpu = global_batch // world
     prog = model.program()
-    n_samples = args.rays * args.samples
+    n_samples = rays_per_gpu * args.samples
     timer = KernelTimer()
 
     def run_step(step):
@@ -1031,15 +1109,17 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "antinous_400-shaped %s train step: %d cams x %dx%d, %s, "
-                                   "%d samples/ray, %d rays/GPU/step, exact-f32 MFMA"
+                                   "%d samples/ray, %d rays/GPU/step (%d rays per step over %d GPU(s), "
+                                   "%s scaling), exact-f32 MFMA"
                                    % (label[0], args.cameras, args.size, args.size, label[1],
-                                      args.samples, args.rays),
-                       "rays_per_gpu": args.rays, "samples_per_ray": args.samples,
+                                      args.samples, rays_per_gpu, global_batch, world, args.scaling),
+                       "rays_per_gpu": rays_per_gpu, "global_batch_rays": global_batch,
+                       "samples_per_ray": args.samples,
                        "parallelism": "dp%d" % world, "final_loss": float(loss),
                        "commit": git_head()},
             "roofline": {"bound": "mfma", "kernel": dominant,

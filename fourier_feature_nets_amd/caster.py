@@ -272,7 +272,10 @@ class TrainEngine:
         alphas = dataset._gt_alphas()
         aw = float(dataset.alpha_weight) if alphas is not None else 0.0
         t, pos, views = self._samples(sampler, rays, step)
-        logits = self.model.program().forward(pos, views, None)
+        # (a forward-only pass: the model's INFERENCE arithmetic, like a no-grad model call)
+        mode = getattr(self.model, "precision", "f32")
+        prog = self.model.program()
+        logits = prog.forward16(pos, views) if mode == "bf16x3" else prog.forward(pos, views, None, precision=mode)
         color, alpha, _ = ops.composite_fwd(logits, t, False, self.nan_flag)
         sums, _, _ = ops.mse_loss(color, alpha, dataset.colors, alphas, rays, 1.0, 1.0,
                                   want_grad=False)

@@ -131,6 +131,17 @@ struct WsOps<S, 2> {
 template <class S>
 struct WsOps<S, 3> {
     bf16x8 x[2][S::NBW][3];
+    // The SMALL partial products (everything but h.h: <= 2^-8 of the leading term) accumulate
+    // here, from zero, for the length of a K-loop segment (8 or 16 K blocks) and meet the main
+    // accumulator at its end in one rounded f32 add per element (ws_segment).  The matrix unit's
+    // f32 accumulation is not round-to-nearest: with all six products on one accumulator its
+    // error has a systematic part that survives sums over samples (bias gradients 4-5x the exact
+    // kernels' error against float64, with six and with nine products alike; measured:
+    // profiles/r05_bf16x6_probe.json); on an accumulator 2^-8 the size it is 2^-8 of that, and the
+    // main one sees one matrix-unit addition per K block instead of six.  (Live only inside a
+    // segment: kept across the feature generators it costs the forward kernels 500 spilled
+    // registers.)
+    f32x16 lo[S::TPW][S::NBW];
 };
 
 // one part (0 = hi, .. PARTS-1 = lo) of the B operands of X K block G, every block of this wave
@@ -203,7 +214,7 @@ template <> struct WsProducts<9> {
 // One K block of the three-part mode: K block parity HB multiplies out of operand set HB while
 // the set of K block `next` streams from LDS into the other one.
 template <class S, int NT, int HB>
-__device__ __forceinline__ void ws_kblock3(const WsWave& w, f32x16 (&acc)[S::TPW][S::NBW],
+__device__ __forceinline__ void ws_kblock3(const WsWave& w, f32x16 (&acc)[S::TPW][S::NBW], f32x16 (&lo)[S::TPW][S::NBW],
                                            const bf16x8 (&wk)[S::TPW][3], bf16x8 (&x)[2][S::NBW][3], int next) {
     constexpr int NBW = S::NBW;
     typedef WsProducts<S::PRODUCTS> P;
@@ -213,8 +224,12 @@ __device__ __forceinline__ void ws_kblock3(const WsWave& w, f32x16 (&acc)[S::TPW
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int b = 0; b < NBW; ++b)
-                acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wk[t][P::W[q]], x[HB][b][P::X[q]], acc[t][b], 0, 0, 0);
+            for (int b = 0; b < NBW; ++b) {
+                if (P::W[q] == 0 && P::X[q] == 0)
+                    acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wk[t][0], x[HB][b][0], acc[t][b], 0, 0, 0);
+                else
+                    lo[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wk[t][P::W[q]], x[HB][b][P::X[q]], lo[t][b], 0, 0, 0);
+            }
         if (q < 3) {
 #pragma unroll
             for (int b = 0; b < NBW; ++b)
@@ -227,7 +242,7 @@ template <class S, int NT, int HB>
 __device__ __forceinline__ void ws_kblock(const WsWave& w, f32x16 (&acc)[S::TPW][S::NBW],
                                           const bf16x8 (&wk)[S::TPW][S::PARTS], WsOps<S>& ops, int next) {
     if constexpr (S::PARTS == 2) ws_kblock2<S, NT, HB>(w, acc, wk, ops.xb, ops.xh, next);
-    else ws_kblock3<S, NT, HB>(w, acc, wk, ops.x, next);
+    else ws_kblock3<S, NT, HB>(w, acc, ops.lo, wk, ops.x, next);
 }
 
 template <class S, int NT, int NVM>
@@ -320,6 +335,12 @@ __device__ __forceinline__ bool ws_segment(WsWave& w, f32x16 (&acc)[S::TPW][S::N
         ws_read_x<S>(w, ops.x[0], g0, 2);
         ws_read_x<S>(w, ops.x[0], g0, 1);
         ws_read_x<S>(w, ops.x[0], g0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int b = 0; b < S::NBW; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ops.lo[t][b][r] = 0.0f;
     }
     // (pairs of chunks in ONE basic block per trip, the odd chunk outside the loop: with a
     // conditional second chunk inside it, hipcc builds a loop in which chunk<1> can follow
@@ -332,6 +353,12 @@ __device__ __forceinline__ bool ws_segment(WsWave& w, f32x16 (&acc)[S::TPW][S::N
     }
     const bool odd = g < count;
     if (odd) ws_chunk<S, NT, 0>(w, acc, wreg, ops, g0 + g, g0 + count - 1);
+    if constexpr (S::PARTS == 3) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int b = 0; b < S::NBW; ++b) acc[t][b] += ops.lo[t][b];
+    }
     return odd;
 }
 
@@ -446,7 +473,7 @@ __device__ __forceinline__ void ws_step_fwd(const ffn_mlp_chain& ch, const ffn_s
         const int g_trig = e.num_freq >> 3;       // K blocks whose eight frequencies are all real
         const int fb = w.wave % NB;               // the block this wave generates features for
         f32x4* fsave = nullptr;
-        if (TRAIN && L.save_enc_slot >= 0 && w.block0 + fb < w.num_blocks)
+        if (TRAIN && w.saved != nullptr && L.save_enc_slot >= 0 && w.block0 + fb < w.num_blocks)
             fsave = reinterpret_cast<f32x4*>(w.saved + ch.slot_offset[L.save_enc_slot] * w.num_blocks * 32) +
                     (w.block0 + fb) * (int64_t)(ch.slot_channels[L.save_enc_slot] * 8);
         // feature K blocks c0 .. c0+count-1 of this wave's block into X K blocks x0 ..
@@ -536,7 +563,7 @@ __device__ __forceinline__ void ws_step_fwd(const ffn_mlp_chain& ch, const ffn_s
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
         const int o = w.tile + 8 * t;
-        if (TRAIN && L.relu && L.mask_slot >= 0) {
+        if (TRAIN && w.masks != nullptr && L.relu && L.mask_slot >= 0) {
 #pragma unroll
             for (int b = 0; b < NBW; ++b) {
                 const int64_t at = ws_mask_idle_at<S>(L.mask_slot, w.num_blocks, blk0 + b, e_lane, t, w.tile, ot);
@@ -548,7 +575,7 @@ __device__ __forceinline__ void ws_step_fwd(const ffn_mlp_chain& ch, const ffn_s
         for (int b = 0; b < NBW; ++b) {
             const bool live = blk0 + b < w.num_blocks;
             f32x4* save_out = nullptr;
-            if (TRAIN && L.out_slot >= 0 && live)
+            if (TRAIN && w.saved != nullptr && L.out_slot >= 0 && live)
                 save_out = reinterpret_cast<f32x4*>(w.saved + ch.slot_offset[L.out_slot] * w.num_blocks * 32) +
                            (blk0 + b) * (int64_t)(ch.slot_channels[L.out_slot] * 8);
             unsigned sign_bits = 0u;
@@ -580,7 +607,7 @@ __device__ __forceinline__ void ws_step_fwd(const ffn_mlp_chain& ch, const ffn_s
                 }
                 if (!last_step) ws_split<S>(y, res[t][b][half]);
             }
-            if (TRAIN && L.relu && L.mask_slot >= 0 && live) {
+            if (TRAIN && w.masks != nullptr && L.relu && L.mask_slot >= 0 && live) {
                 *reinterpret_cast<uint16_t*>(w.masks + ws_mask_at<S>(L.mask_slot, w.num_blocks, blk0 + b, e_lane, o, ot)) =
                     (uint16_t)(sign_bits & 0xffffu);
             }
@@ -913,13 +940,15 @@ template <class S>
 static void ws_launch_fwd_modes(bool hw, const ffn_mlp_chain* chain, const uint16_t* packed_w, const float* bias,
                                 const float* positions, const float* views, int64_t n, float* logits,
                                 float* saved, uint32_t* masks, void* stream) {
-    if (saved != nullptr) {
-        if (hw) ws_launch_fwd<S, true, true>(chain, packed_w, bias, positions, views, n, logits, saved, masks, stream);
-        else ws_launch_fwd<S, true, false>(chain, packed_w, bias, positions, views, n, logits, saved, masks, stream);
-    } else {
-        if (hw) ws_launch_fwd<S, false, true>(chain, packed_w, bias, positions, views, n, logits, nullptr, nullptr, stream);
-        else ws_launch_fwd<S, false, false>(chain, packed_w, bias, positions, views, n, logits, nullptr, nullptr, stream);
-    }
+    // ONE instantiation serves training and inference launches: inference passes null slabs and
+    // the saving code tests the pointers.  The instantiation without any saving code is the
+    // SLOWER inference kernel -- hipcc spills 159 (bf16x3) / 186 (bf16x6) registers in it against
+    // 54 / 52 in this one, and every reload in front of a K loop waits, through the in-order
+    // vmcnt, for the weight requests in flight (interleaved on one box, scripts/gpu/r5_ab.sh,
+    // r5_ab2.sh: bf16x6 tiny 13.8 -> 11.9 ms, full NeRF 16.0 -> 13.1 ms per 2^21; bf16x3 full
+    // NeRF 14.5 -> 13.4 ms, tiny 6.51 -> 6.42 ms).
+    if (hw) ws_launch_fwd<S, true, true>(chain, packed_w, bias, positions, views, n, logits, saved, masks, stream);
+    else ws_launch_fwd<S, true, false>(chain, packed_w, bias, positions, views, n, logits, saved, masks, stream);
 }
 
 int launch_forward16_ws(const ffn_mlp_chain* chain, const uint16_t* packed_w, const float* bias,
@@ -929,7 +958,7 @@ int launch_forward16_ws(const ffn_mlp_chain* chain, const uint16_t* packed_w, co
     if (chain->wide) {             // 512-wide chains: two tiles per wave, two blocks per pass
         if (saved != nullptr) ws_launch_fwd<WsWide8, true, true>(chain, packed_w, bias, positions, views, n, logits, saved, masks, stream);
         else ws_launch_fwd<WsWide8, false, true>(chain, packed_w, bias, positions, views, n, logits, nullptr, nullptr, stream);
-        return 0;
+        return 0;       // (the wide shape keeps its own inference instantiation: not measured the other way)
     }
     if (ws_sixteen_waves()) ws_launch_fwd_modes<WsNarrow16>(hw, chain, packed_w, bias, positions, views, n, logits, saved, masks, stream);
     else ws_launch_fwd_modes<WsNarrow8>(hw, chain, packed_w, bias, positions, views, n, logits, saved, masks, stream);
@@ -968,13 +997,9 @@ inline bool bf16x6_nine_products() {        // read per launch: the probe flips 
 int launch_forward_bf16x6(const ffn_mlp_chain* chain, const uint16_t* packed_w, const float* bias,
                           const float* positions, const float* views, int64_t n, float* logits,
                           float* saved, uint32_t* masks, void* stream) {
-    if (bf16x6_nine_products()) {
-        if (saved != nullptr) ws_launch_fwd<WsSplit9, true, false>(chain, packed_w, bias, positions, views, n, logits, saved, masks, stream);
-        else ws_launch_fwd<WsSplit9, false, false>(chain, packed_w, bias, positions, views, n, logits, nullptr, nullptr, stream);
-    } else {
-        if (saved != nullptr) ws_launch_fwd<WsSplit6, true, false>(chain, packed_w, bias, positions, views, n, logits, saved, masks, stream);
-        else ws_launch_fwd<WsSplit6, false, false>(chain, packed_w, bias, positions, views, n, logits, nullptr, nullptr, stream);
-    }
+    // (inference launches run the saving instantiation with null slabs: see ws_launch_fwd_modes)
+    if (bf16x6_nine_products()) ws_launch_fwd<WsSplit9, true, false>(chain, packed_w, bias, positions, views, n, logits, saved, masks, stream);
+    else ws_launch_fwd<WsSplit6, true, false>(chain, packed_w, bias, positions, views, n, logits, saved, masks, stream);
     return 0;
 }
 

@@ -68,6 +68,7 @@ def error_table(dev, layers, n=8192, seed=0):
     (want * probe.double()).sum().backward()
     scale = float(want.abs().max())
     rows = {}
+    names = [n for i in range(len(model.layers)) for n in ("layers.%d.weight" % i, "layers.%d.bias" % i)]
     for mode, products in MODES:
         set_products(products)
         model.precision = model.train_precision = mode
@@ -80,14 +81,17 @@ def error_table(dev, layers, n=8192, seed=0):
         row = {"logits_max_abs_err_over_max_abs": float(err.abs().max()) / scale,
                "logits_rms_err_over_rms": float(err.pow(2).mean().sqrt() / want.detach().pow(2).mean().sqrt()),
                "inference_equals_training_forward": bool(torch.equal(y_inf, y.detach()))}
-        gmax, grms = 0.0, 0.0
-        for par, ref in zip([p for layer in model.layers for p in (layer.weight, layer.bias)], params64):
+        gmax, grms, per_tensor = 0.0, 0.0, {}
+        for key, par, ref in zip(names, [p for layer in model.layers for p in (layer.weight, layer.bias)], params64):
             g64 = ref.grad
             d = par.grad.double() - g64
-            gmax = max(gmax, float(d.abs().max()) / max(float(g64.abs().max()), 1e-300))
-            grms = max(grms, float(d.pow(2).mean().sqrt() / g64.pow(2).mean().sqrt().clamp_min(1e-300)))
+            tmax = float(d.abs().max()) / max(float(g64.abs().max()), 1e-300)
+            trms = float(d.pow(2).mean().sqrt() / g64.pow(2).mean().sqrt().clamp_min(1e-300))
+            per_tensor[key] = [tmax, trms]
+            gmax, grms = max(gmax, tmax), max(grms, trms)
         row["worst_tensor_grad_max_abs_err_over_max_abs"] = gmax
         row["worst_tensor_grad_rms_err_over_rms"] = grms
+        row["grad_err_per_tensor_max_rms"] = per_tensor
         rows[label(mode, products)] = row
     set_products(None)
     return {"model": "MLP(3, 4, num_layers=%d, num_channels=256)" % layers, "samples": n,
@@ -208,6 +212,8 @@ def main():
     ap.add_argument("--out", required=True)
     ap.add_argument("--samples", type=int, default=1 << 22)
     ap.add_argument("--skip-timing", action="store_true")
+    ap.add_argument("--error-seeds", type=int, default=0,
+                    help="repeat the error table over this many seeds and report the spread of the ratios")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     doc = {"what": __doc__.split("\n\n")[0].replace("\n", " ")}
@@ -216,6 +222,20 @@ def main():
     except OSError:
         doc["commit"] = None
     doc["errors_vs_float64"] = [error_table(dev, layers) for layers in (2, 4, 8)]
+    if args.error_seeds:
+        # seed-to-seed spread of the error ratios (split mode over exact kernels), per metric
+        spread = {}
+        for layers in (2, 8):
+            ratios = {}
+            for seed in range(1, args.error_seeds + 1):
+                rows = error_table(dev, layers, n=4096, seed=seed)["modes"]
+                for mode in ("bf16x6_6p", "bf16x6_9p"):
+                    for key in ("logits_max_abs_err_over_max_abs", "logits_rms_err_over_rms",
+                                "worst_tensor_grad_max_abs_err_over_max_abs", "worst_tensor_grad_rms_err_over_rms"):
+                        ratios.setdefault("%s/%s" % (mode, key), []).append(rows[mode][key] / max(rows["f32"][key], 1e-300))
+            spread["layers=%d" % layers] = {k: {"min": round(min(v), 3), "median": round(sorted(v)[len(v) // 2], 3),
+                                                "max": round(max(v), 3)} for k, v in ratios.items()}
+        doc["error_ratio_over_seeds"] = {"seeds": args.error_seeds, "ratios_split_over_exact": spread}
     doc["distance_from_exact_f32_kernels"] = [distance_table(dev, name) for name in ("tiny", "nerf")]
     if not args.skip_timing:
         doc["timings"] = [timing_table(dev, name, args.samples if name != "nerf" else args.samples // 2)
