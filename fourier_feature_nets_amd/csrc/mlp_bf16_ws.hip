@@ -49,6 +49,8 @@ constexpr size_t kWsLdsBytes = (size_t)kWsXBytes + kEncTableBytes + kWsBiasFloat
 // two-part kernels' four blocks.
 template <int TPW_, int SPLIT_, int PARTS_ = 2, int PRODUCTS_ = (PARTS_ == 2 ? 3 : 6)>
 struct WsShape {
+    // (sixteen waves -- two per tile, a block each -- were measured for the three-part chains too:
+    // backward data 6.45 -> 7.14 ms, and the forward does not fit 128 registers: 376 spilled)
     static_assert(PARTS_ == 2 || (PARTS_ == 3 && TPW_ == 1 && SPLIT_ == 1), "three-part chains: narrow, eight waves");
     static_assert(PARTS_ == 2 ? PRODUCTS_ == 3 : (PRODUCTS_ == 6 || PRODUCTS_ == 9), "partial products");
     static constexpr int TPW = TPW_;

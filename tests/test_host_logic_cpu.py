@@ -297,12 +297,16 @@ def _dp_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_data_parallel_step_equals_single_process_step(tmp_path):
+@pytest.mark.parametrize("world", [2, 4])
+def test_data_parallel_step_equals_single_process_step(tmp_path, world):
+    """ONE global batch of 37 rays sharded over 2 / 4 gloo ranks (ragged: 19 + 18, 10 + 10 + 10 + 7)
+    == the single-process step on the same batch: what `bench.py --scaling strong` times, and --
+    with a global batch that grows with the ranks -- what `--scaling weak` times."""
     out = str(tmp_path / "dp.pt")
-    mp.spawn(_dp_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_dp_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     blob = torch.load(out)
     ws, bs, b, pos, t, gt_c, gt_a = blob["inputs"]
-    assert blob["count"] == 19
+    assert blob["count"] == -(-37 // world)
     model = orc.OracleFourierMLP(torch.ones(b.shape[1]), b, ws, bs)
     trainer = orc.OracleTrainer(model, 5e-4)
     loss = trainer.step(pos, None, t, gt_c, gt_a, 5e-4)
@@ -424,3 +428,18 @@ def test_sample_cameras_keeps_the_reference_order():
         assert chosen == case["chosen"], (case, chosen)
         unsorted += chosen != sorted(chosen)
     assert unsorted >= 4
+
+
+def test_bench_batch_plan_weak_and_strong():
+    """`bench.py --scaling`: weak keeps the per-GPU batch and grows the global one, strong keeps
+    the global batch and shards it; a strong batch that does not divide is refused."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(os.path.dirname(os.path.dirname(
+        os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.batch_plan(65536, 1, "weak") == (65536, 65536) == bench.batch_plan(65536, 1, "strong")
+    assert bench.batch_plan(65536, 8, "weak") == (524288, 65536)
+    assert bench.batch_plan(65536, 8, "strong") == (65536, 8192)
+    with pytest.raises(SystemExit):
+        bench.batch_plan(1000, 3, "strong")

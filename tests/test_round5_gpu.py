@@ -344,3 +344,61 @@ def test_bf16x6_refuses_what_it_does_not_cover(golden):
     model.train_precision = "bf16x6"
     with pytest.raises(NotImplementedError):
         model(x)
+
+
+# ----------------------------------------------------------------------------------- look-ahead sampling
+def test_announced_next_batch_gives_the_same_steps(golden):
+    """`TrainEngine.train_step(..., lookahead=(dataset, next rays, next step))` -- the next step's
+    sampling kernels enqueued under this step's gradient all-reduce in data parallel -- takes
+    the SAME optimisation steps as the plain call: stratified + annealed sampling from the device
+    generator, bit for bit while every announcement is honoured; an announcement that is not
+    (step 3 here) falls back to fresh samples and costs one block of noise, nothing else."""
+    import fourier_feature_nets_amd as ffn
+    g = golden("training")
+    results = []
+    for announce in (False, True):
+        model = tp._small_model(g)
+        train = _quiet(ffn.ImageDataset.load, tp.SCENE, "train", 16, True, True, anneal_start=0.2,
+                       num_anneal_steps=8)
+        engine = ffn.TrainEngine(model)
+        gen = torch.Generator(device=dev()).manual_seed(7)
+        batches = [torch.randint(0, len(train), (96,), device=dev(), generator=gen) for _ in range(7)]
+        rays = [train.ray_ids(b) for b in batches]
+        torch.manual_seed(31)
+        losses = []
+        for step in range(6):
+            ahead = None
+            if announce:
+                # (step 3 announces a batch that does not come: the engine must notice)
+                nxt = rays[step + 1] if step != 3 else rays[0]
+                ahead = (train, nxt, step + 1)
+            losses.append(float(engine.train_step(train, batches[step], step, 5e-4, rays=rays[step], lookahead=ahead)))
+        engine.check_finite()
+        results.append((losses, engine.flat.clone()))
+    # steps 0..3 are identical bit for bit; from step 4 on the runs differ only through the noise
+    # block the unhonoured announcement consumed
+    assert results[0][0][:4] == results[1][0][:4]
+    assert all(abs(a - b) < 0.05 for a, b in zip(results[0][0][4:], results[1][0][4:]))
+
+
+def test_announced_next_batch_without_noise_is_bit_identical(golden):
+    """The same with a non-stratified sampler (nothing to consume): every step, honoured or not,
+    bit for bit -- losses and final weights."""
+    import fourier_feature_nets_amd as ffn
+    g = golden("training")
+    results = []
+    for announce in (False, True):
+        model = tp._small_model(g)
+        train = _quiet(ffn.ImageDataset.load, tp.SCENE, "train", 16, True, False, anneal_start=0.2,
+                       num_anneal_steps=8)
+        engine = ffn.TrainEngine(model)
+        gen = torch.Generator(device=dev()).manual_seed(7)
+        batches = [torch.randint(0, len(train), (96,), device=dev(), generator=gen) for _ in range(7)]
+        rays = [train.ray_ids(b) for b in batches]
+        losses = []
+        for step in range(6):
+            ahead = (train, rays[step + 1] if step != 3 else rays[0], step + 1) if announce else None
+            losses.append(float(engine.train_step(train, batches[step], step, 5e-4, rays=rays[step], lookahead=ahead)))
+        results.append((losses, engine.flat.clone()))
+    assert results[0][0] == results[1][0]
+    assert torch.equal(results[0][1], results[1][1])
