@@ -47,8 +47,9 @@ constexpr size_t kWsLdsBytes = (size_t)kWsXBytes + kEncTableBytes + kWsBiasFloat
 // v_mfma_f32_32x32x2_f32 takes 32.  The X image then holds three parts per value, so a pass is TWO
 // blocks (96 KiB): the same number of matrix instructions per pass and weight byte as the
 // two-part kernels' four blocks.
-template <int TPW_, int SPLIT_, int PARTS_ = 2, int PRODUCTS_ = (PARTS_ == 2 ? 3 : 6)>
+template <int TPW_, int SPLIT_, int PARTS_ = 2, int PRODUCTS_ = (PARTS_ == 2 ? 3 : 6), int ACCS_ = (PARTS_ == 2 ? 1 : 2)>
 struct WsShape {
+    static constexpr int ACCS = ACCS_;            // 2: the small partial products on their own accumulator (WsOps)
     // (sixteen waves -- two per tile, a block each -- were measured for the three-part chains too:
     // backward data 6.45 -> 7.14 ms, and the forward does not fit 128 registers: 376 spilled)
     static_assert(PARTS_ == 2 || (PARTS_ == 3 && TPW_ == 1 && SPLIT_ == 1), "three-part chains: narrow, eight waves");
@@ -227,8 +228,8 @@ __device__ __forceinline__ void ws_kblock3(const WsWave& w, f32x16 (&acc)[S::TPW
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int b = 0; b < NBW; ++b) {
-                if (P::W[q] == 0 && P::X[q] == 0)
-                    acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wk[t][0], x[HB][b][0], acc[t][b], 0, 0, 0);
+                if (S::ACCS == 1 || (P::W[q] == 0 && P::X[q] == 0))
+                    acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wk[t][P::W[q]], x[HB][b][P::X[q]], acc[t][b], 0, 0, 0);
                 else
                     lo[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wk[t][P::W[q]], x[HB][b][P::X[q]], lo[t][b], 0, 0, 0);
             }
@@ -337,12 +338,14 @@ __device__ __forceinline__ bool ws_segment(WsWave& w, f32x16 (&acc)[S::TPW][S::N
         ws_read_x<S>(w, ops.x[0], g0, 2);
         ws_read_x<S>(w, ops.x[0], g0, 1);
         ws_read_x<S>(w, ops.x[0], g0, 0);
+        if constexpr (S::ACCS == 2) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int b = 0; b < S::NBW; ++b)
+                for (int b = 0; b < S::NBW; ++b)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) ops.lo[t][b][r] = 0.0f;
+                    for (int r = 0; r < 16; ++r) ops.lo[t][b][r] = 0.0f;
+        }
     }
     // (pairs of chunks in ONE basic block per trip, the odd chunk outside the loop: with a
     // conditional second chunk inside it, hipcc builds a loop in which chunk<1> can follow
@@ -355,7 +358,7 @@ __device__ __forceinline__ bool ws_segment(WsWave& w, f32x16 (&acc)[S::TPW][S::N
     }
     const bool odd = g < count;
     if (odd) ws_chunk<S, NT, 0>(w, acc, wreg, ops, g0 + g, g0 + count - 1);
-    if constexpr (S::PARTS == 3) {
+    if constexpr (S::PARTS == 3 && S::ACCS == 2) {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -988,6 +991,14 @@ int launch_backward16_ws(const ffn_mlp_chain* chain, const uint16_t* packed_wt, 
 // ---------------------------------------------------------------------------------- bf16x6
 typedef WsShape<1, 1, 3, 6> WsSplit6;       // three parts, six partial products: the f32-accurate mode
 typedef WsShape<1, 1, 3, 9> WsSplit9;       // all nine partial products (FFN_BF16X6_PRODUCTS=9: measurement)
+// The FORWARD kernels keep one accumulator: there the systematic part of the matrix unit's
+// rounding stays inside the exact kernels' own error (logits 0.8-0.9x theirs against float64, 0.4x
+// with two accumulators) and no sum over samples amplifies it, while the second accumulator costs
+// the forward 40 more spilled registers and 8 % (training forward 12.8 -> 14.0 ms, interleaved on one
+// box, profiles/r05_bf16x6_forward_accumulators_ab.txt).  BACKWARD DATA keeps two: its dZ feed the
+// bias and weight gradients -- sums over every sample of the batch (and it is 2 % FASTER with
+// them: shorter dependent chains, no spills).  FFN_BF16X6_FWD_ACCS=2 selects two in the forward too.
+typedef WsShape<1, 1, 3, 6, 1> WsSplit6one;
 
 inline bool bf16x6_nine_products() {        // read per launch: the probe flips it inside one process
     const char* v = getenv("FFN_BF16X6_PRODUCTS");
@@ -1000,7 +1011,9 @@ int launch_forward_bf16x6(const ffn_mlp_chain* chain, const uint16_t* packed_w, 
                           const float* positions, const float* views, int64_t n, float* logits,
                           float* saved, uint32_t* masks, void* stream) {
     // (inference launches run the saving instantiation with null slabs: see ws_launch_fwd_modes)
+    const char* two = getenv("FFN_BF16X6_FWD_ACCS");
     if (bf16x6_nine_products()) ws_launch_fwd<WsSplit9, true, false>(chain, packed_w, bias, positions, views, n, logits, saved, masks, stream);
+    else if (two == nullptr || two[0] != '2') ws_launch_fwd<WsSplit6one, true, false>(chain, packed_w, bias, positions, views, n, logits, saved, masks, stream);
     else ws_launch_fwd<WsSplit6, true, false>(chain, packed_w, bias, positions, views, n, logits, saved, masks, stream);
     return 0;
 }

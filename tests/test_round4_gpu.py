@@ -521,10 +521,10 @@ def test_fit_schedule_across_the_crop_removal(tmp_path):
         orig_init(self, *a, **k)
         self.loss_history = []
 
-    def recording_step(self, dataset, batch, step, lr, rays=None):
+    def recording_step(self, dataset, batch, step, lr, rays=None, **kw):
         batches.append(torch.as_tensor(batch).cpu().numpy().astype(np.int64))
         modes.append(int(dataset.mode.value))
-        return orig_step(self, dataset, batch, step, lr, rays=rays)
+        return orig_step(self, dataset, batch, step, lr, rays=rays, **kw)
 
     ffn.TrainEngine.__init__, ffn.TrainEngine.train_step = recording_init, recording_step
     buf = io.StringIO()
