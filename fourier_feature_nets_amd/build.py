@@ -35,6 +35,7 @@ SOURCES = {
     "mlp_bf16_ws.hip": ["-fno-slp-vectorize"],
     "wgrad.hip": [],
     "wgrad_bf16.hip": [],
+    "wgrad_bf16x6.hip": [],
     "occupancy.hip": [],
 }
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC,

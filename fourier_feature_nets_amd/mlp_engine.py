@@ -44,6 +44,14 @@ HEAD_COST16 = 13
 if os.environ.get("FFN_UNIT_COST16"):
     _c = [int(v) for v in os.environ["FFN_UNIT_COST16"].split(",")]
     UNIT_COST16, HEAD_COST16 = {4: _c[0], 2: _c[1], 1: _c[2]}, _c[3]
+# the f32-accurate split kernel (wgrad_bf16x6.hip): six matrix instructions per product and a
+# three-way split -- a full unit's block ~3.5 us; narrower units run unpipelined; the f32 head
+# unit as above (FFN_UNIT_COST_X6 = "full,half,quarter,head" for calibration)
+UNIT_COST_X6 = {4: 24, 2: 17, 1: 17}
+HEAD_COST_X6 = 10
+if os.environ.get("FFN_UNIT_COST_X6"):
+    _c = [int(v) for v in os.environ["FFN_UNIT_COST_X6"].split(",")]
+    UNIT_COST_X6, HEAD_COST_X6 = {4: _c[0], 2: _c[1], 1: _c[2]}, _c[3]
 if os.environ.get("FFN_UNIT_COST"):       # "full,half,quarter,head" -- calibration experiments
     _c = [int(v) for v in os.environ["FFN_UNIT_COST"].split(",")]
     UNIT_COST, HEAD_COST = {4: _c[0], 2: _c[1], 1: _c[2]}, _c[3]
@@ -239,14 +247,16 @@ class Workspace:
         if plan is None:
             dev = self._prog.device
             raw = self._prog._plan_wgrad(self._blocks, precision)
-            plan = dict(unit_segments=_struct_array_to_device(raw["unit_segments"], dev),
-                        unit_seg_start=torch.tensor(raw["unit_starts"], dtype=torch.int32, device=dev),
+            launches = [(kind, _struct_array_to_device(segs, dev), torch.tensor(starts, dtype=torch.int32, device=dev))
+                        for kind, segs, starts in raw["launches"]]
+            plan = dict(unit_segments=launches[0][1], unit_seg_start=launches[0][2], launches=launches,
                         reduce_jobs=_struct_array_to_device(raw["reduce_jobs"], dev),
                         num_reduce_jobs=len(raw["reduce_jobs"]),
                         partial_floats=raw["slots"] * self._prog.partial_floats)
             self._plans[precision] = plan
         self.unit_segments = plan["unit_segments"]
         self.unit_seg_start = plan["unit_seg_start"]
+        self.launches = plan["launches"]      # (kernel precision, segments, starts) per launch
         self.reduce_jobs = plan["reduce_jobs"]
         self.num_reduce_jobs = plan["num_reduce_jobs"]
         if self.partials is None or self.partials.numel() < plan["partial_floats"]:
@@ -732,25 +742,46 @@ class MlpProgram:
 
     def _plan_wgrad(self, blocks: int, precision: str = "f32"):
         """Segments of the weight-gradient kernel + the reducer's job table.  One
-        workgroup-segment = 4 consecutive partial slots (one per wave)."""
+        workgroup-segment = 4 consecutive partial slots (one per wave).
+
+        "bf16x6" is planned as TWO launches over one partial buffer and one reducer table: the
+        three-part kernel takes the units with all four 128x128 quadrants (and the logits-head
+        units), the exact-f32 kernel -- which FOLDS narrow input windows -- the units with fewer
+        (NeRF's 63- / 27-channel encodings, its 128-channel view layer): in the three-part kernel
+        those run unpipelined and cost as much as 0.7 of a full unit each (full NeRF weight
+        gradients: 30.9 ms per 2^21 samples with every unit on it, 18.3 exact).  ``launches`` lists
+        (kernel precision, segments, starts); every unit's reducer jobs carry the fold of the kernel
+        that wrote its partials."""
         slot = 0
         reduce_jobs = []
+        kernel_of = []              # per unit: the precision of the kernel that computes it
         unit_costs = []
-        unit_cost, head_cost = (UNIT_COST16, HEAD_COST16) if precision == "bf16x3" else (UNIT_COST, HEAD_COST)
         for u, meta in zip(self.wgrad_units, self.unit_meta):
+            kind = precision
+            if precision == "bf16x6" and u.kind != 1:
+                mh, nh = self._quadrants(meta["m_quads"], meta["n_quads"])
+                kind = "bf16x6" if mh * nh == 4 else "f32"
+            kernel_of.append(kind)
+            unit_cost, head_cost = {"bf16x3": (UNIT_COST16, HEAD_COST16),
+                                    "bf16x6": (UNIT_COST_X6, HEAD_COST_X6)}.get(kind, (UNIT_COST, HEAD_COST))
             if u.kind == 1:
                 unit_costs.append(head_cost)
             else:
                 mh, nh = self._quadrants(meta["m_quads"], meta["n_quads"])
-                fold = self._fold(meta["n_quads"], precision)
+                fold = self._fold(meta["n_quads"], kind)
                 unit_costs.append(unit_cost[mh * nh] if fold == 1 else FOLD_COST[(mh * nh, fold)])
-        raw, unit_starts = self._split(unit_costs, blocks, WGRAD_GROUPS)
-        unit_segments = []
         unit_slots = [[] for _ in self.wgrad_units]
-        for (u, b0, b1) in raw:
-            unit_segments.append(FfnWgradSegment(u, slot, b0, b1))
-            unit_slots[u].append(slot)
-            slot += 4
+        launches = []
+        for kind in sorted(set(kernel_of), key=lambda k: k != precision):      # the mode's own kernel first
+            ids = [u for u, k in enumerate(kernel_of) if k == kind]
+            raw, starts = self._split([unit_costs[u] for u in ids], blocks, WGRAD_GROUPS)
+            segments = []
+            for (j, b0, b1) in raw:
+                segments.append(FfnWgradSegment(ids[j], slot, b0, b1))
+                unit_slots[ids[j]].append(slot)
+                slot += 4
+            launches.append((kind, segments, starts))
+        unit_segments, unit_starts = launches[0][1], launches[0][2]
         for u, meta in enumerate(self.unit_meta):
             spec = self.layers[meta["layer"]]
             sl = unit_slots[u]
@@ -775,11 +806,11 @@ class MlpProgram:
                         0, sl[0] + qd, sl[-1] + 4, 4 * (meta["m0"] + 32 * mp), spec.out,
                         meta["n_quad0"] + 32 * np_, min(32, meta["n_quads"] - 32 * np_),
                         meta["k_base"], spec.ld, int(meta["first"] and np_ == 0), 0, mh * nh,
-                        self._fold(meta["n_quads"], precision), 0,
+                        self._fold(meta["n_quads"], kernel_of[u]), 0,
                         self.grad_w_off[meta["layer"]], self.grad_b_off[meta["layer"]],
                         self.col_maps[meta["layer"]].data_ptr()))
         return dict(unit_segments=unit_segments, unit_starts=unit_starts,
-                    reduce_jobs=reduce_jobs, slots=slot)
+                    reduce_jobs=reduce_jobs, slots=slot, launches=launches)
 
     # ------------------------------------------------------------------ packing
     def pack16(self, parts: int = 2):
@@ -1102,8 +1133,12 @@ class MlpProgram:
                                    "split %s) but the backward was asked for %s (tail split %s)"
                                    % (record[2], record[3], precision, split))
         ws = self.workspace(n)
-        wgrad16 = precision == "bf16x3"     # (units are <= 256 x 256 windows at any layer width)
-        ws.use_plan("bf16x3" if wgrad16 else "f32")
+        # (units are <= 256 x 256 windows at any layer width)  bf16x6: the three-part units, or --
+        # FFN_BF16X6_WGRAD=f32 -- the exact-f32 units on the slabs the bf16x6 chain kernels wrote
+        wgrad_mode = precision if precision == "bf16x3" else "f32"
+        if precision == "bf16x6" and os.environ.get("FFN_BF16X6_WGRAD", "bf16x6") != "f32":
+            wgrad_mode = "bf16x6"
+        ws.use_plan(wgrad_mode)
         whole = saved
         saved, masks = self._split_saved(saved, n)
         if precision == "bf16x6":
@@ -1133,10 +1168,12 @@ class MlpProgram:
                 _call("ffn_mlp_backward_data", ctypes.byref(tail_chain), _dev(self.packed_bwd),
                       _dev(d_logits[cut:]), c_i64(n - cut), _dev(self._tail_masks(whole, n)),
                       _dev(ws.dz), c_i64(head), c_i64(blocks))
-        _call("ffn_mlp_wgrad_units_bf16x3" if wgrad16 else "ffn_mlp_wgrad_units",
-              ctypes.byref(self.fwd),
-                  _dev(self.wgrad_units_dev, torch.uint8), _dev(ws.unit_segments, torch.uint8),
-                  _dev(ws.unit_seg_start, torch.int32), c_i(WGRAD_GROUPS), _dev(saved),
+        for kind, segments, starts in ws.launches:
+            _call({"bf16x3": "ffn_mlp_wgrad_units_bf16x3", "bf16x6": "ffn_mlp_wgrad_units_bf16x6"}.get(
+                      kind, "ffn_mlp_wgrad_units"),
+                  ctypes.byref(self.fwd),
+                  _dev(self.wgrad_units_dev, torch.uint8), _dev(segments, torch.uint8),
+                  _dev(starts, torch.int32), c_i(WGRAD_GROUPS), _dev(saved),
                   _dev(ws.dz), _dev(d_logits), c_i64(n), _dev(ws.partials))
         _call("ffn_mlp_wgrad_reduce", _dev(ws.reduce_jobs, torch.uint8),
                   c_i(ws.num_reduce_jobs), _dev(ws.partials), _dev(grads))

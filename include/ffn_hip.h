@@ -550,6 +550,15 @@ int ffn_mlp_wgrad_units_bf16x3(const ffn_mlp_chain* chain, const ffn_wgrad_unit*
                                const ffn_wgrad_segment* segments, const int32_t* seg_start,
                                int num_groups, const float* saved, const float* dz,
                                const float* d_logits, int64_t n, float* partials, void* stream);
+/* Weight-gradient units of the f32-accurate "bf16x6" mode (csrc/wgrad_bf16x6.hip): ffn_mlp_wgrad_units with every f32
+ * product as six bf16 matrix products on three-part operands; units, segments, partial format and
+ * the reducer are shared with the exact-f32 and the bf16x3 kernels (the logits-head unit stays
+ * exact f32).  The dZ window is double buffered; the input window is split just in time, hi parts
+ * first, and the products are ordered by the part of it they need. */
+int ffn_mlp_wgrad_units_bf16x6(const ffn_mlp_chain* chain, const ffn_wgrad_unit* units,
+                               const ffn_wgrad_segment* segments, const int32_t* seg_start,
+                               int num_groups, const float* saved, const float* dz,
+                               const float* d_logits, int64_t n, float* partials, void* stream);
 
 /* Fixed-order reduction of the partials of each job into the flat natural-layout
  * gradient buffer (nn.Linear weight (out,in) row-major, then bias). */

@@ -237,7 +237,28 @@ def compare(doc, reference_path, out_path):
         if deltas:
             paired_reports.append({"step": s, "seeds": len(deltas), "mean_delta_db": float(np.mean(deltas)),
                                    "max_abs_delta_db": float(np.max(np.abs(deltas)))})
+    # what the comparison can and cannot resolve: the minimum detectable difference of the
+    # UNPAIRED means (2 standard errors of their difference) next to the 0.05 dB bar, and how long
+    # the seed-PAIRED trajectories stay inside it
+    mdd = 2.0 * se
+    held = [r["step"] for r in paired_reports if r["max_abs_delta_db"] < 0.05]
+    first_out = next((r["step"] for r in paired_reports if r["max_abs_delta_db"] >= 0.05), None)
+    if abs(delta) >= 0.05 and abs(delta) >= mdd:
+        verdict3 = "fail"
+    elif mdd <= 0.05:
+        verdict3 = "pass-resolved"
+    else:
+        verdict3 = "pass-unresolved"
     doc["against_reference"] = {
+        "resolution": {
+            "bar_db": 0.05, "minimum_detectable_difference_db (2 s.e. of the difference of the means)": mdd,
+            "seeds_per_side_for_mdd_0p05": int(np.ceil((2.0 * np.sqrt(2.0) * max(a["std"] or 0.0, b["std"] or 0.0) / 0.05) ** 2)),
+            "verdict": verdict3,
+            "verdicts": "fail: |delta| >= 0.05 dB and >= 2 s.e.; pass-resolved: not failed and the ensemble COULD "
+                        "have detected 0.05 dB (2 s.e. <= 0.05); pass-unresolved: not failed, but a 0.05 dB gap "
+                        "would not have been detected by the means -- see the paired reports",
+            "paired_reports_all_seeds_within_0p05_db_at_steps": held,
+            "first_report_step_with_a_seed_outside_0p05_db": first_out},
         "paired_val_psnr_by_report": paired_reports,
         "file": os.path.relpath(reference_path, ROOT), "reference_final": b, "hip_final": a,
         "per_seed_delta_db": paired,

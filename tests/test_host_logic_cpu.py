@@ -94,11 +94,22 @@ def test_chain_and_wgrad_plans(make):
     assert last.save_out_slot == 0
     # every (row, col) of every weight gradient is produced by exactly one reduce job
     for blocks, precision in ((1, "f32"), (7, "f32"), (4096, "f32"), (5, "bf16x3"), (4096, "bf16x3"),
-                              (131072, "bf16x3"), (4099, "bf16x3")):
-        # (the split-bf16 plan has its own unit costs)
+                              (131072, "bf16x3"), (4099, "bf16x3"), (3, "bf16x6"), (4099, "bf16x6"),
+                              (131072, "bf16x6")):
+        # (the split-bf16 plan has its own unit costs; the bf16x6 plan is TWO launches: units with
+        # four quadrants and the heads on the three-part kernel, narrower ones on the exact-f32 one)
         plan = prog._plan_wgrad(blocks, precision)
+        segments = [seg for _, segs, _ in plan["launches"] for seg in segs]
+        if precision != "bf16x6":
+            assert len(plan["launches"]) == 1 and plan["launches"][0][0] == precision
+            assert segments == plan["unit_segments"]
+        kernel_of = {}
+        for kind, segs, starts in plan["launches"]:
+            assert len(starts) == 257 and starts[-1] == len(segs) and starts[0] == 0
+            for seg in segs:
+                assert kernel_of.setdefault(seg.job, kind) == kind
         cover = {}
-        for seg in plan["unit_segments"]:
+        for seg in segments:
             cover.setdefault(("u", seg.job), []).append((seg.blk_begin, seg.blk_end))
         assert len(cover) == len(prog.wgrad_units)
         for spans in cover.values():
@@ -133,8 +144,13 @@ def test_chain_and_wgrad_plans(make):
             else:
                 mh, nh = prog._quadrants(meta["m_quads"], meta["n_quads"])
                 rule = 4 if meta["n_quads"] <= 8 else (2 if meta["n_quads"] <= 16 else 1)
-                expected += [rule if precision == "f32" else 1] * (mh * nh)
+                folds = precision == "f32" or (precision == "bf16x6" and mh * nh < 4)
+                expected += [rule if folds else 1] * (mh * nh)
         assert [rj.n_fold for rj in plan["reduce_jobs"]] == expected
+        if precision == "bf16x6":
+            for u, meta in enumerate(prog.unit_meta):
+                full = not meta.get("head") and prog._quadrants(meta["m_quads"], meta["n_quads"]) == (2, 2)
+                assert kernel_of[u] == ("bf16x6" if (full or meta.get("head")) else "f32"), u
         slots = set()
         for rj in plan["reduce_jobs"]:
             mine = set(range(rj.slot_begin, rj.slot_end, rj.slot_stride))
@@ -143,8 +159,9 @@ def test_chain_and_wgrad_plans(make):
         assert max(slots) < plan["slots"]
         # every partial slot a unit's segments write is read by exactly that unit's reduce jobs
         written = {}
-        for seg in plan["unit_segments"]:
+        for seg in segments:
             for wave in range(4):
+                assert seg.slot + wave not in written
                 written[seg.slot + wave] = seg.job
         assert slots <= set(written)       # (a narrow head leaves the partials of its idle waves unread)
         assert len(plan["unit_starts"]) == 257 and plan["unit_starts"][-1] == len(plan["unit_segments"])
