@@ -1,0 +1,6 @@
+# timing-only (WRONG results): the three-way split replaced by one packed convert per stage
+SUBS = {"wgrad_bf16x6.hip": [("""        if (!LAST) {
+            x[2 * t] = pair[0] - __builtin_bit_cast(float, h << 16);
+            x[2 * t + 1] = pair[1] - __builtin_bit_cast(float, h & 0xffff0000u);
+        }""", """        if (false) {
+        }""")]}
