@@ -523,6 +523,27 @@ def config3_leg(device, cams, images, bounds, rays_per_step=65536, steps=3):
     finally:
         fine.train_precision = "f32"
         coarse.precision = "f32"
+    # ... and in the OPT-IN f32-accurate split mode (labelled): forward / backward data / weight
+    # gradients of the fine model on the three-part kernels (its two 63-channel input windows, the
+    # 128-channel view layer and the heads on the exact-f32 units); the coarse pass stays the fused
+    # exact-f32 kernel
+    fine.train_precision = "bf16x6"
+    try:
+        run_step(2 * steps + 2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for step in range(2 * steps + 3, 3 * steps + 3):
+            run_step(step)
+        torch.cuda.synchronize()
+        acc_ms = 1e3 * (time.perf_counter() - t0) / steps
+        engine.check_finite()
+        out["f32_accurate_split"] = {
+            "label": "opt-in f32-accurate split kernels (three bf16 parts per operand, six products) for "
+                     "the fine model's training kernels; fused exact-f32 coarse pass; reported separately",
+            "step_ms": round(acc_ms, 2), "rays_per_s": round(rays_per_step / (acc_ms * 1e-3), 1),
+            "speedup_vs_exact_f32_step": round(step_ms / acc_ms, 3)}
+    finally:
+        fine.train_precision = "f32"
     del engine
     prog.release_workspaces()
     torch.cuda.empty_cache()
@@ -810,6 +831,55 @@ SPLIT_MODES = {
                  "(matrix pipe ~0.55 busy); weight gradients 192 matrix instructions per block and unit "
                  "under a four-stage LDS-DMA ring, conversions pinned between them (DESIGN: bf16x6 section)"},
 }
+
+
+def split_render(device, bounds, cams, samples, mode):
+    """Frames/sec of the 400x400 render with the model's inference calls in an opt-in split mode
+    (three passes: sampling, MLP, compositing -- the fused render kernel is exact-f32 only), its
+    MLP forward next to the exact-f32 one, and the frames' PSNR against the exact-f32 frames."""
+    import fourier_feature_nets_amd as ffn
+    torch.manual_seed(20080524)
+    model = ffn.PositionalFourierMLP(3, 4, 5.5).to(device)
+    caster = ffn.Raycaster(model)
+    with contextlib.redirect_stdout(io.StringIO()):
+        sampler = ffn.RaySampler(bounds, cams[:8], samples, False, device=device)
+    exact = [caster.render_image_device(sampler, f, 1 << 20).clone() for f in range(2)]
+    prog = model.program()
+    n = 65536 * samples
+    x = torch.rand((n, 3), device=device) * 2 - 1
+    flops = 2 * sum(sp.out * sp.ld for sp in prog.layers) * n
+    timings, outs = {}, {}
+    for which in ("f32", mode):
+        fn = (lambda: prog.forward16(x, None)) if which == "bf16x3" else (lambda: prog.forward(x, None, None, precision=which))
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            outs[which] = fn()
+        e1.record()
+        torch.cuda.synchronize()
+        timings[which] = e0.elapsed_time(e1) / 3
+    err = float((outs["f32"] - outs[mode]).abs().max())
+    scale = float(outs["f32"].abs().max())
+    del x, outs
+    model.precision = mode
+    fast = [caster.render_image_device(sampler, f, 1 << 20).clone() for f in range(2)]
+    torch.cuda.synchronize()
+    r0 = time.perf_counter()
+    for f in range(8):
+        caster.render_image_device(sampler, f, 1 << 20)
+    torch.cuda.synchronize()
+    fps = 8 / (time.perf_counter() - r0)
+    caster.check_finite()
+    mse = float(torch.stack([(a.float() - b.float()).square().mean() for a, b in zip(exact, fast)]).mean())
+    psnr = 10 * np.log10(255.0 ** 2 / max(mse, 1e-12))
+    return {"mlp_forward_ms": {k: round(v, 3) for k, v in timings.items()},
+            "mlp_speedup_vs_exact_f32": round(timings["f32"] / timings[mode], 3),
+            "algorithmic_tflops": round(flops / (timings[mode] * 1e-3) / 1e12, 1),
+            "max_abs_logit_difference_vs_exact_f32_kernels": err, "max_abs_logit": scale,
+            "render_fps_400x400_%d_samples_kernels_only" % samples: round(fps, 2),
+            "render_psnr_db_vs_exact_f32_frames": round(float(psnr), 2)}
 
 
 def bf16_train_leg(device, dataset, rays_per_step, samples, steps=6, mode="bf16x3"):
@@ -1269,6 +1339,8 @@ def main():
                                          if solo and not args.no_bf16_leg else None)
         result["f32_accurate_split"] = (bf16_train_leg(device, dataset, args.rays, args.samples, mode="bf16x6")
                                         if solo and not args.no_bf16_leg else None)
+        if result["f32_accurate_split"] is not None:
+            result["f32_accurate_split"]["inference"] = split_render(device, bounds, cams, args.samples, "bf16x6")
         del dataset
         torch.cuda.empty_cache()
         result["config5_step"] = (config5_leg(device, bounds)

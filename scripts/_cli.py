@@ -38,7 +38,7 @@ TRAIN_COMMON = [
     ("--anneal-start", dict(type=float, default=0.2)),
     ("--num-anneal-steps", dict(type=int, default=2000)),
     # not a flag of the reference: the opt-in split-bf16 kernels, training and renders
-    ("--precision", dict(choices=["f32", "bf16x3"], default="f32")),
+    ("--precision", dict(choices=["f32", "bf16x3", "bf16x6"], default="f32")),
     # not flags of the reference either: opt-in empty-space skipping during training (DESIGN K9):
     # exact steps for --skip-warmup steps, then an occupancy grid derived from the model and
     # rebuilt every --skip-refresh steps
@@ -79,7 +79,7 @@ ORBIT = [
     ("--alpha-thresh", dict(type=float, default=0.3)),
     ("--batch_size", dict(type=int, default=4096)),
     ("--device", dict(default="cuda")),
-    ("--precision", dict(choices=["f32", "bf16x3"], default="f32")),   # not a flag of the reference
+    ("--precision", dict(choices=["f32", "bf16x3", "bf16x6"], default="f32")),   # not a flag of the reference
     FOCUS_MODE,
 ]
 
@@ -126,8 +126,10 @@ def setup_device(requested: str, want_group: bool):
 
 
 def apply_precision(model, precision: str):
-    """--precision bf16x3: the opt-in split-bf16 kernels for training and inference calls of a
-    fused-MLP model (models without that switch, e.g. voxel grids, are left alone)."""
+    """--precision bf16x3 / bf16x6: the opt-in split kernels for training and inference calls of a
+    fused model (bf16x3: three bf16 products per f32 product, ~2^-16 per product; bf16x6: three-part
+    operands, six products, the error of an f32 dot product -- chains of <= 256 channels); the
+    default is the exact-f32 kernels.  Not a flag of the reference."""
     if precision != "f32" and hasattr(model, "train_precision"):
         model.precision = precision
         model.train_precision = precision
