@@ -417,6 +417,8 @@ class Raycaster(nn.Module):
         # with one (14.3 vs 18.6: per-ray blocks of 32 and two pairs in step), so that case
         # keeps the three passes
         # (``fused_render = "always"`` overrides, for measurements)
+        if model.program().big:         # layers wider than 512 channels: no fused render kernel
+            return False
         return self.fused_render == "always" or not (model.program().wide and self.occupancy is not None)
 
     def render_rays(self, sampler: RaySampler, rays, include_depth=False,

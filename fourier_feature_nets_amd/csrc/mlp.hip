@@ -240,7 +240,13 @@ __device__ __forceinline__ void team_barrier() {
 //   1 slab destination, no fused head, no output save   (hidden layers; dgrad steps)
 //   2 slab destination, output saved                    (forward: fused head + save; dgrad: last step)
 //   3 slab destination, fused head, no save             (forward inference)
-template <int OT, int MODE, int TWP, int FLAV>
+//
+// BIG (chains with a layer wider than 512 channels, up to 1024; ffn_mlp_chain.wide == 3): the team
+// of FOUR waves with up to eight output tiles per wave and the whole 128 KiB slab area as its one
+// slab (128 K groups: 1024 channels x 32 samples).  The fused-head weights of such a chain (4 per
+// channel: 4100 floats for ONE 1024-channel head) outgrow the LDS copy of the bias buffer, so BIG
+// steps read head blocks from the bias buffer itself (L2) -- like biases past the LDS copy.
+template <int OT, int MODE, int TWP, int FLAV, bool BIG = false>
 __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step& L,
                                          const ffn_step* next, WaveCtx& w,
                                          const float* __restrict__ packed_w,
@@ -248,7 +254,7 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
                                          float* __restrict__ slab_out) { // fwd: saved; bwd: dZ
     constexpr bool WIDE = TWP > 1;
     constexpr int TW = TWP;                       // waves sharing a step's output tiles (1, 2 or 4)
-    constexpr int kChunk = WIDE ? 64 : 32;        // K groups the slab holds
+    constexpr int kChunk = BIG ? 128 : (WIDE ? 64 : 32);        // K groups the slab holds
     const int half = WIDE ? w.half : 0;
     // accumulators start at the bias (forward) or zero (backward): the 32 LDS reads go out
     // back to back here instead of sitting, each with its own wait, in the epilogue
@@ -457,9 +463,10 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
                                       : (MODE != kBackward && FLAV >= 2);
     const bool to_slab = FLAV == 0 ? L.dst == 0 : true;
     const bool save_y = FLAV == 0 ? save_out != nullptr : FLAV == 2;
-    const float* hw = w.bias_lds + (fused_head ? L.head_off : 0) + 4 + 16 * w.h;
+    const float* head_base = BIG ? w.bias_glb : w.bias_lds;
+    const float* hw = head_base + (fused_head ? L.head_off : 0) + 4 + 16 * w.h;
     if (fused_head && w.h == 0 && half == 0) {
-        const f32x4 hb = *reinterpret_cast<const f32x4*>(w.bias_lds + L.head_off);
+        const f32x4 hb = *reinterpret_cast<const f32x4*>(head_base + L.head_off);
 #pragma unroll
         for (int c = 0; c < 4; ++c) w.logit[c] += hb[c];
     }
@@ -550,7 +557,7 @@ __device__ __forceinline__ void run_step(const ffn_mlp_chain& ch, const ffn_step
     if (WIDE) team_barrier();        // the step's output is in the slab
 }
 
-template <int MODE, int TWP>
+template <int MODE, int TWP, bool BIG = false>
 __device__ __forceinline__ void run_chain(const ffn_mlp_chain& ch, WaveCtx& w,
                                           const float* __restrict__ packed_w,
                                           float* __restrict__ slab_out) {
@@ -572,7 +579,7 @@ __device__ __forceinline__ void run_chain(const ffn_mlp_chain& ch, WaveCtx& w,
         const ffn_step& L = ch.step[li];
         const ffn_step* next = li + 1 < ch.num_steps ? &ch.step[li + 1] : nullptr;
         const int ot = L.out_tiles / TW;
-        if (TWP < 4 && ot == 8) {
+        if ((TWP < 4 || BIG) && ot == 8) {
             // the 256-channel steps (all the time of every supported model) get a specialised
             // epilogue; the flavour is a property of the step, known before its K loops start.
             // (Only as many specialisations as the register allocator digests: every inlined
@@ -580,13 +587,13 @@ __device__ __forceinline__ void run_chain(const ffn_mlp_chain& ch, WaveCtx& w,
             const bool saves = MODE != kInfer && L.save_out_slot >= 0 && w.active;
             const bool head = MODE != kBackward && L.head_off >= 0;
             if (MODE == kBackward) {
-                if (saves) run_step<8, MODE, TWP, 2>(ch, L, next, w, packed_w, pre, slab_out);
-                else run_step<8, MODE, TWP, 1>(ch, L, next, w, packed_w, pre, slab_out);
-            } else if (!head && L.dst == 0) run_step<8, MODE, TWP, 1>(ch, L, next, w, packed_w, pre, slab_out);
-            else run_step<8, MODE, TWP, 0>(ch, L, next, w, packed_w, pre, slab_out);
-        } else if (TWP < 4 && ot == 4) run_step<4, MODE, TWP, 0>(ch, L, next, w, packed_w, pre, slab_out);
-        else if (ot == 2) run_step<2, MODE, TWP, 0>(ch, L, next, w, packed_w, pre, slab_out);
-        else run_step<1, MODE, TWP, 0>(ch, L, next, w, packed_w, pre, slab_out);
+                if (saves) run_step<8, MODE, TWP, 2, BIG>(ch, L, next, w, packed_w, pre, slab_out);
+                else run_step<8, MODE, TWP, 1, BIG>(ch, L, next, w, packed_w, pre, slab_out);
+            } else if (!head && L.dst == 0) run_step<8, MODE, TWP, 1, BIG>(ch, L, next, w, packed_w, pre, slab_out);
+            else run_step<8, MODE, TWP, 0, BIG>(ch, L, next, w, packed_w, pre, slab_out);
+        } else if ((TWP < 4 || BIG) && ot == 4) run_step<4, MODE, TWP, 0, BIG>(ch, L, next, w, packed_w, pre, slab_out);
+        else if (ot == 2) run_step<2, MODE, TWP, 0, BIG>(ch, L, next, w, packed_w, pre, slab_out);
+        else run_step<1, MODE, TWP, 0, BIG>(ch, L, next, w, packed_w, pre, slab_out);
     }
 }
 
@@ -618,7 +625,7 @@ __device__ __forceinline__ void wave_setup(WaveCtx& w, char* smem, int64_t n, in
     w.active = true;
 }
 
-template <int MODE, int TWP>
+template <int MODE, int TWP, bool BIG = false>
 __global__ void __launch_bounds__(256, 1)
 mlp_forward_kernel(const ffn_mlp_chain ch, const float* __restrict__ packed_w,
                    const float* __restrict__ bias, const float* __restrict__ positions,
@@ -670,7 +677,7 @@ mlp_forward_kernel(const ffn_mlp_chain ch, const float* __restrict__ packed_w,
         w.v0 = in_next[3]; w.v1 = in_next[4]; w.v2 = in_next[5];
         request_inputs(first + (pass + 1) * stride);
         w.logit[0] = w.logit[1] = w.logit[2] = w.logit[3] = 0.0f;
-        run_chain<MODE, TWP>(ch, w, packed_w, saved);
+        run_chain<MODE, TWP, BIG>(ch, w, packed_w, saved);
         f32x4 out;
 #pragma unroll
         for (int c = 0; c < 4; ++c)   // MFMA heads leave their rows on h == 0, fused heads on both halves
@@ -943,7 +950,7 @@ focus_fused_kernel(const ffn_mlp_chain ch, const float* __restrict__ packed_w,
 
 // Backward-data chain: consumes d_logits (N,4) and the saved forward activations, writes
 // dZ of every hidden layer (block layout) for the weight-gradient kernel.
-template <int TWP>
+template <int TWP, bool BIG = false>
 __global__ void __launch_bounds__(256, 1)
 mlp_backward_data_kernel(const ffn_mlp_chain ch, const float* __restrict__ packed_wt,
                          const float* __restrict__ d_logits, int64_t n,
@@ -978,7 +985,7 @@ mlp_backward_data_kernel(const ffn_mlp_chain ch, const float* __restrict__ packe
         }
         w.dl = dl_next;
         request_dl(first + (pass + 1) * stride);
-        run_chain<kBackward, TWP>(ch, w, packed_wt, dz);
+        run_chain<kBackward, TWP, BIG>(ch, w, packed_wt, dz);
         if (!WIDE) w.block += stride;
     }
 }
@@ -1011,16 +1018,20 @@ static int validate_chain(const ffn_mlp_chain* ch, bool backward, bool train = f
     if (ch->bias_floats < 0) return 1;
     const bool wide = ch->wide != 0;
     const bool quad = ch->wide == 2;       // four waves per block: narrow chains of >= 128 channels
+    const bool big = ch->wide == 3;        // four waves per block, up to 1024 channels per layer
+    if (ch->wide < 0 || ch->wide > 3) return 1;
     for (int i = 0; i < ch->num_steps; ++i) {
         const ffn_step& L = ch->step[i];
         const int ot = L.out_tiles;
         if (quad && (!(ot == 4 || ot == 8) || L.act_groups > 32 || L.dst != 0)) return 1;
-        if (wide ? !(ot == 2 || ot == 4 || ot == 8 || ot == 16) : !(ot == 1 || ot == 2 || ot == 4 || ot == 8)) return 1;
-        if (L.act_groups < 0 || L.aux_groups < 0 || L.act_groups > (wide ? 64 : 32)) return 1;
+        if (big ? !(ot == 4 || ot == 8 || ot == 16 || ot == 32)
+                : (wide ? !(ot == 2 || ot == 4 || ot == 8 || ot == 16) : !(ot == 1 || ot == 2 || ot == 4 || ot == 8))) return 1;
+        if (L.act_groups < 0 || L.aux_groups < 0 || L.act_groups > (big ? 128 : (wide ? 64 : 32))) return 1;
         if ((L.act_groups & 3) || (L.aux_groups & 3) || L.act_groups + L.aux_groups == 0) return 1;
         if (!backward && L.aux_groups > 0 && (L.enc_id < 0 || L.enc_id > 1)) return 1;
         // fused-head blocks (4 bias floats + 4 per channel) are read from the LDS copy only
-        if (!backward && L.head_off >= 0 && L.head_off + 4 + 128 * ot > kBiasLdsFloats) return 1;
+        if (!backward && L.head_off >= 0 &&
+            L.head_off + 4 + 128 * ot > (big ? ch->bias_floats : kBiasLdsFloats)) return 1;    // (big: from L2)
         if (!backward && (L.b_off < 0 || L.b_off + 32 * ot > ch->bias_floats)) return 1;
         if (!backward && (ch->enc[0].num_freq > 256 || ch->enc[1].num_freq > 256)) return 1;
         if (backward && L.aux_groups != 0 && L.aux_groups != 4) return 1;
@@ -1061,15 +1072,15 @@ static void allow_big_lds(K kernel, size_t bytes = kLdsBytes) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-template <int MODE, int TWP>
+template <int MODE, int TWP, bool BIG = false>
 static void launch_forward(const ffn_mlp_chain* chain, const float* packed_w, const float* bias,
                            const float* positions, const float* views, int64_t n, float* logits,
                            float* saved, uint32_t* masks, int64_t slab_block0, int64_t slab_blocks,
                            void* stream) {
     const int64_t blocks32 = (n + kSamplesPerWave - 1) / kSamplesPerWave;
     const int64_t grid = persistent_grid(blocks32, kWavesPerBlock / TWP);
-    allow_big_lds(&mlp_forward_kernel<MODE, TWP>);
-    hipLaunchKernelGGL((mlp_forward_kernel<MODE, TWP>), dim3((unsigned)grid), dim3(256), kLdsBytes,
+    allow_big_lds(&mlp_forward_kernel<MODE, TWP, BIG>);
+    hipLaunchKernelGGL((mlp_forward_kernel<MODE, TWP, BIG>), dim3((unsigned)grid), dim3(256), kLdsBytes,
                        (hipStream_t)stream, *chain, packed_w, bias, positions, views, n, logits, saved,
                        masks, slab_block0, slab_blocks);
 }
@@ -1086,7 +1097,10 @@ extern "C" int ffn_mlp_forward(const ffn_mlp_chain* chain, const float* packed_w
     if (slab_blocks != 0 && (slab_block0 < 0 || slab_block0 + (n + 31) / 32 > slab_blocks))
         return fail_arg("ffn_mlp_forward: the launch's blocks must lie inside [0, slab_blocks)");
     const bool train = saved != nullptr;
-    if (chain->wide == 2) {            // four waves per block: training launches (a batch's short last round)
+    if (chain->wide == 3) {            // layers of up to 1024 channels: a team of four waves per block
+        if (train) launch_forward<kTrainFwd, 4, true>(chain, packed_w, bias, positions, views, n, logits, saved, masks, slab_block0, slab_blocks, stream);
+        else launch_forward<kInfer, 4, true>(chain, packed_w, bias, positions, views, n, logits, saved, masks, slab_block0, slab_blocks, stream);
+    } else if (chain->wide == 2) {     // four waves per block: training launches (a batch's short last round)
         if (!train) return fail_arg("ffn_mlp_forward: four-waves-per-block chains (wide == 2) are training-only");
         launch_forward<kTrainFwd, 4>(chain, packed_w, bias, positions, views, n, logits, saved, masks, slab_block0, slab_blocks, stream);
     } else if (chain->wide) {
@@ -1107,7 +1121,8 @@ extern "C" int ffn_render_fused_fwd(const ffn_mlp_chain* chain, const float* pac
     if (rays->num_rays == 0) return 0;
     if (rays->num_rays < 0 || rays->num_samples < 1 || rays->num_samples > 256)
         return fail_arg("ffn_render_fused_fwd: need 1 <= num_samples <= 256");
-    if (validate_chain(chain, false)) return fail_arg("ffn_render_fused_fwd: bad chain");
+    if (validate_chain(chain, false) || chain->wide > 1)
+        return fail_arg("ffn_render_fused_fwd: bad chain (narrow and 512-wide forward chains only)");
     if (rays->t_values == nullptr && rays->unit == nullptr)
         return fail_arg("ffn_render_fused_fwd: unit or t_values is required");
     RenderParams p;
@@ -1163,14 +1178,14 @@ extern "C" int ffn_focus_fused(const ffn_mlp_chain* chain, const float* packed_w
     return check_launch("ffn_focus_fused");
 }
 
-template <int TWP>
+template <int TWP, bool BIG = false>
 static void launch_backward(const ffn_mlp_chain* chain, const float* packed_wt, const float* d_logits,
                             int64_t n, uint32_t* masks, float* dz, int64_t slab_block0,
                             int64_t slab_blocks, void* stream) {
     const int64_t blocks32 = (n + kSamplesPerWave - 1) / kSamplesPerWave;
     const int64_t grid = persistent_grid(blocks32, kWavesPerBlock / TWP);
-    allow_big_lds(&mlp_backward_data_kernel<TWP>);
-    hipLaunchKernelGGL((mlp_backward_data_kernel<TWP>), dim3((unsigned)grid), dim3(256), kLdsBytes,
+    allow_big_lds(&mlp_backward_data_kernel<TWP, BIG>);
+    hipLaunchKernelGGL((mlp_backward_data_kernel<TWP, BIG>), dim3((unsigned)grid), dim3(256), kLdsBytes,
                        (hipStream_t)stream, *chain, packed_wt, d_logits, n, masks, dz, slab_block0, slab_blocks);
 }
 
@@ -1182,7 +1197,8 @@ extern "C" int ffn_mlp_backward_data(const ffn_mlp_chain* chain, const float* pa
     if (n < 0 || validate_chain(chain, true)) return fail_arg("ffn_mlp_backward_data: bad chain or size");
     if (slab_blocks != 0 && (slab_block0 < 0 || slab_block0 + (n + 31) / 32 > slab_blocks))
         return fail_arg("ffn_mlp_backward_data: the launch's blocks must lie inside [0, slab_blocks)");
-    if (chain->wide == 2) launch_backward<4>(chain, packed_wt, d_logits, n, masks, dz, slab_block0, slab_blocks, stream);
+    if (chain->wide == 3) launch_backward<4, true>(chain, packed_wt, d_logits, n, masks, dz, slab_block0, slab_blocks, stream);
+    else if (chain->wide == 2) launch_backward<4>(chain, packed_wt, d_logits, n, masks, dz, slab_block0, slab_blocks, stream);
     else if (chain->wide) launch_backward<2>(chain, packed_wt, d_logits, n, masks, dz, slab_block0, slab_blocks, stream);
     else launch_backward<1>(chain, packed_wt, d_logits, n, masks, dz, slab_block0, slab_blocks, stream);
     return check_launch("ffn_mlp_backward_data");

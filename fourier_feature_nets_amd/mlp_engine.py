@@ -205,20 +205,25 @@ class DenseSpec:
         self.act_in_p = self.act_in
 
 
-def _padded_width(channels: int, wide: bool = False) -> int:
+MAX_HIDDEN_CHANNELS = 1024
+
+
+def _padded_width(channels: int, wide=False) -> int:
     """Width a hidden layer of ``channels`` outputs runs at: the kernels' tile counts are 1/2/4/8
-    tiles of 32 channels (2/4/8/16 in a chain with a layer wider than 256), so any other width is
+    tiles of 32 channels (2/4/8/16 in a chain with a layer wider than 256: ``wide`` = 1 / True;
+    4/8/16/32 in a chain with a layer wider than 512: ``wide`` = 3), so any other width is
     zero-padded to the next one -- zero rows / columns in the operand packs, zero bias, zero
     fused-head weights; the padding's activations, dZ and gradients are exactly 0 in f32 and the
     reducer drops them (reference: nn.Linear accepts any width, ``train_nerf.py:28-31``)."""
-    for width in ((64, 128, 256, 512) if wide else (32, 64, 128, 256)):
+    widths = {0: (32, 64, 128, 256), 1: (64, 128, 256, 512), 3: (128, 256, 512, 1024)}[int(wide)]
+    for width in widths:
         if channels <= width:
             return width
-    raise NotImplementedError("fused MLP kernels support hidden layers of up to 512 channels "
-                              "(got %d)" % channels)
+    raise NotImplementedError("fused MLP kernels support hidden layers of up to %d channels "
+                              "(got %d)" % (MAX_HIDDEN_CHANNELS, channels))
 
 
-def _tiles(channels: int, wide: bool = False) -> int:
+def _tiles(channels: int, wide=False) -> int:
     return _padded_width(channels, wide) // 32
 
 
@@ -331,14 +336,19 @@ class MlpProgram:
         self._fill_encodings(fwd)
         # a layer wider than 256 channels switches the whole chain to the two-waves-per-block
         # kernels (64 KiB slab per pair)
-        self.wide = any(sp.to_logits is None and sp.out > 256 for sp in self.layers)
-        fwd.wide = 1 if self.wide else 0
+        # ... and a layer wider than 512 (up to 1024) to a team of FOUR waves per block on the whole
+        # 128 KiB slab area (ffn_mlp_chain.wide == 3; exact-f32 kernels only, three-pass renders)
+        widest = max([sp.out for sp in self.layers if sp.to_logits is None] or [0])
+        self.wide = widest > 256
+        self.big = widest > 512
+        self.wide_level = 3 if self.big else (1 if self.wide else 0)
+        fwd.wide = self.wide_level
         # any nn.Linear width is accepted: hidden layers run zero-padded to a supported tile count
         producer = -1
         for i, sp in enumerate(self.layers):
             sp.act_in_p = self.layers[producer].out_p if (sp.act_in > 0 and producer >= 0) else sp.act_in
             if sp.to_logits is None:
-                sp.out_p = _padded_width(sp.out, self.wide)
+                sp.out_p = _padded_width(sp.out, self.wide_level)
                 producer = i
         # bias buffer = [fused-head blocks | per-step padded biases]: the kernels keep its first
         # BIAS_LDS_FLOATS floats in LDS (every head block must be there: the epilogues read them
@@ -433,7 +443,7 @@ class MlpProgram:
             self.fwd_shapes[i] = (groups, L.out_tiles)
             w_off += groups * L.out_tiles * 256
             b_off += 32 * L.out_tiles
-        if h_off > BIAS_LDS_FLOATS:
+        if h_off > BIAS_LDS_FLOATS and not self.big:      # (big chains read head blocks from L2)
             raise NotImplementedError("fused logits heads need %d floats of LDS (limit %d)"
                                       % (h_off, BIAS_LDS_FLOATS))
         for k in range(num_steps):
@@ -463,7 +473,8 @@ class MlpProgram:
             slot_off += self.encodings[spec.enc_id].width
         self.fwd = fwd
         self.saved_channels = slot_off
-        self.mask_words = 512 if self.wide else 256     # uint32 of ReLU sign bits per slot and block
+        # uint32 of ReLU sign bits per slot and block: 64 lanes x 128 bit per wave of a block's team
+        self.mask_words = 1024 if self.big else (512 if self.wide else 256)
         self.num_grad_floats = g_off
         self.packed_fwd = torch.zeros((max(w_off, 1),), dtype=torch.float32, device=self.device)
         self.bias_buf = torch.zeros((b_off,), dtype=torch.float32, device=self.device)
@@ -502,7 +513,7 @@ class MlpProgram:
         self._packed16_dirty = True
         self._packed_x6_dirty = True
         self.tiles16 = 16 if self.wide else 8
-        if self.device.type != "cuda":
+        if self.device.type != "cuda" or self.big:      # (no split-bf16 kernels beyond 512 channels)
             return
         steps = [(i, self.fwd.step[self.step_of[i]]) for i in range(len(self.layers))
                  if self.step_of[i] is not None]

@@ -196,10 +196,23 @@ def test_tail_plan_of_a_training_launch():
 
 
 def test_unsupported_shapes_raise_not_fall_back():
+    # round 5: layers of up to 1024 channels plan (a team of four waves per block, wide == 3):
+    # 513..1024 pad to the next of 128 / 256 / 512 / 1024; beyond 1024 raises
     with pytest.raises(NotImplementedError):
-        _plan(ffn.GaussianFourierMLP(3, 4, 10.0, num_channels=1024))
+        _plan(ffn.GaussianFourierMLP(3, 4, 10.0, num_channels=1025))
     with pytest.raises(NotImplementedError):
-        _plan(ffn.NeRF(8, 513, 9, 10, 3, 4, [4], True))
+        _plan(ffn.NeRF(8, 2048, 9, 10, 3, 4, [4], True))
+    big = _plan(ffn.NeRF(8, 1024, 9, 10, 3, 4, [4], True))
+    assert big.big and big.fwd.wide == 3 and big.bwd.wide == 3 and big.mask_words == 1024
+    assert max(big.fwd.step[k].out_tiles for k in range(big.fwd.num_steps)) == 32
+    assert max(big.fwd.step[k].act_groups for k in range(big.fwd.num_steps)) == 128
+    assert big.fwd16 is None and big.fwd_x6 is None and not big.pair_chain_ok
+    # (its two head blocks -- 4100 + 2052 floats -- lie beyond the kernels' LDS copy: read from L2)
+    assert sum(4 + 4 * ch for _, _, ch in big.fused_heads) > 4096
+    odd = _plan(ffn.MLP(3, 4, num_channels=768))
+    assert odd.big and [sp.out_p for sp in odd.layers] == [1024, 1024, 1024, 4]
+    mid = _plan(ffn.NeRF(8, 513, 9, 10, 3, 4, [4], True))
+    assert mid.big and mid.layers[0].out_p == 1024
     # everything up to 512 channels plans: padded widths, biases beyond the kernels' LDS copy
     wide = _plan(ffn.NeRF(8, 512, 9, 10, 3, 4, [4], True))
     assert wide.fwd.bias_floats > 4096 and all(off + 4 + 4 * ch <= 4096 for _, off, ch in wide.fused_heads)

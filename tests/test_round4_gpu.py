@@ -50,6 +50,12 @@ def _make(kind):
         return ffn.NeRF(8, 512, 9, 10, 3, 4, [4], True)
     if kind == "nerf100":
         return ffn.NeRF(4, 100, 5, 6, 2, 3, [2], False)
+    if kind == "mlp768":            # round 5: layers wider than 512 (a team of four waves per block)
+        return ffn.MLP(3, 4, num_channels=768)
+    if kind == "nerf1024":
+        return ffn.NeRF(8, 1024, 9, 10, 3, 4, [4], True)
+    if kind == "positional640":
+        return ffn.PositionalFourierMLP(3, 4, 5.5, num_channels=640)
     raise KeyError(kind)
 
 
@@ -71,7 +77,8 @@ def _oracle_of(model):
     return ref, pairs
 
 
-KINDS = ["mlp96", "mlp7", "positional384", "gaussian200", "nerf192", "nerf32", "nerf512", "nerf100"]
+KINDS = ["mlp96", "mlp7", "positional384", "gaussian200", "nerf192", "nerf32", "nerf512", "nerf100",
+         "mlp768", "nerf1024", "positional640"]
 
 
 @pytest.mark.parametrize("kind", KINDS)
@@ -85,9 +92,11 @@ def test_any_layer_width_forward_and_gradients_against_the_oracle(kind):
     ref, pairs = _oracle_of(model)
     model = model.to(dev())
     prog = model.program()
-    assert any(sp.out_p != sp.out for sp in prog.layers if sp.to_logits is None) or kind == "nerf512"
+    assert any(sp.out_p != sp.out for sp in prog.layers if sp.to_logits is None) or kind in ("nerf512", "nerf1024")
     if kind == "nerf512":
         assert prog.wide and prog.fwd.bias_floats > 4096
+    if kind in ("mlp768", "nerf1024", "positional640"):
+        assert prog.big and prog.fwd.wide == 3
     named = dict(model.named_parameters())
     for n in (45, 9000 + 7):
         torch.manual_seed(n)
@@ -121,7 +130,7 @@ def test_any_layer_width_forward_and_gradients_against_the_oracle(kind):
             assert rel < 5e-3, (kind, key, n, rel)
 
 
-@pytest.mark.parametrize("kind", ["mlp96", "nerf192", "nerf32", "nerf512", "positional384"])
+@pytest.mark.parametrize("kind", ["mlp96", "nerf192", "nerf32", "nerf512", "positional384", "mlp768", "nerf1024"])
 def test_any_layer_width_optimisation_step_against_the_oracle(kind):
     """One complete `TrainEngine.train_step` (sample -> model -> composite -> loss -> backward ->
     clip -> Adam, ray_caster.py:319-329) of a padded-width model == the oracle's step: loss and
