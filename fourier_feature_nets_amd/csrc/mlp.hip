@@ -889,6 +889,13 @@ struct FocusParams {
     const float* unit_focus; const float* u; float* t_io;
 };
 
+// 512-wide opacity models (WIDE): a PAIR of waves owns a ray, like the fused render -- each wave
+// computes half of every step's output channels, the even wave adds the odd wave's partial logits
+// and does the CDF / sampling / merge in the pair's slab.  The chain's barriers are workgroup-wide:
+// the two pairs run in step (every ray takes the same number of passes here), a pair without a
+// ray walks ray 0's probe points with its stores switched off, and one more barrier per ray keeps
+// the odd wave's next feature burst out of the slab the even wave is still merging in.
+template <bool WIDE>
 __global__ void __launch_bounds__(256, 1)
 focus_fused_kernel(const ffn_mlp_chain ch, const float* __restrict__ packed_w,
                    const float* __restrict__ bias, const FocusParams p) {
@@ -903,15 +910,24 @@ focus_fused_kernel(const ffn_mlp_chain ch, const float* __restrict__ packed_w,
     __syncthreads();
     WaveCtx w;
     int64_t stride;
-    wave_setup<1>(w, smem, kSamplesPerWave, stride);
+    wave_setup<(WIDE ? 2 : 1)>(w, smem, kSamplesPerWave, stride);
     w.bias_glb = bias;
     w.block = 0;
     w.masks = nullptr;
     const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int waves = gridDim.x * kWavesPerBlock;
+    constexpr int kTeams = WIDE ? 2 : kWavesPerBlock;
+    const int team = WIDE ? wave_in_block >> 1 : wave_in_block;
+    f32x4* partial = reinterpret_cast<f32x4*>(smem + kWavesPerBlock * kActBytesPerWave + kEncTableBytes +
+                                              kBiasLdsFloats * 4) + team * 64;
+    const int teams = gridDim.x * kTeams;
     const int n = p.n_focus;
     const int nblk = (n + 31) >> 5;
-    for (int r = blockIdx.x * kWavesPerBlock + wave_in_block; r < p.num_rays; r += waves) {
+    const int rounds = (p.num_rays + teams - 1) / teams;
+    for (int round = 0; round < rounds; ++round) {
+        const int r0 = round * teams + (int)blockIdx.x * kTeams + team;
+        const bool have = r0 < p.num_rays;
+        if (!WIDE && !have) continue;
+        const int r = have ? r0 : 0;          // (a pair without a ray keeps the barriers company)
         const int64_t ray = p.ray_index[r];
         const float sx = p.starts[ray * 3 + 0], sy = p.starts[ray * 3 + 1], sz = p.starts[ray * 3 + 2];
         const float dx = p.dirs[ray * 3 + 0], dy = p.dirs[ray * 3 + 1], dz = p.dirs[ray * 3 + 2];
@@ -929,9 +945,21 @@ focus_fused_kernel(const ffn_mlp_chain ch, const float* __restrict__ packed_w,
             w.x2 = mul_add_rn(t, dz, sz);
             w.v0 = dx; w.v1 = dy; w.v2 = dz;
             w.logit[0] = w.logit[1] = w.logit[2] = w.logit[3] = 0.0f;
-            run_chain<kInfer, 1>(ch, w, packed_w, nullptr);
-            const float out = w.logit[3] + __shfl_xor(w.logit[3], 32);
+            run_chain<kInfer, (WIDE ? 2 : 1)>(ch, w, packed_w, nullptr);
+            float out = w.logit[3] + __shfl_xor(w.logit[3], 32);
+            if (WIDE) {                   // the two waves of a pair hold partial sums
+                f32x4 mine;
+                mine[0] = mine[1] = mine[2] = 0.0f;
+                mine[3] = out;
+                if (w.half == 1) partial[w.lane] = mine;
+                team_barrier();
+                if (w.half == 0) out += partial[w.lane][3];
+            }
             if (w.h == hb) sigma_logit = out;
+        }
+        if (WIDE && (w.half != 0 || !have)) {
+            team_barrier();               // (matches the barrier behind the even wave's merge)
+            continue;
         }
         // probe sample s sits on lane s
         float sigma[1], delta[1];
@@ -945,6 +973,7 @@ focus_fused_kernel(const ffn_mlp_chain ch, const float* __restrict__ packed_w,
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
         focus_merge_ray(near, span, c, tv, p.u + (int64_t)r * n, p.unit_focus, p.S, n, w.lane, row);
+        if (WIDE) team_barrier();         // the slab is free for the next ray's features
     }
 }
 
@@ -1164,16 +1193,23 @@ extern "C" int ffn_focus_fused(const ffn_mlp_chain* chain, const float* packed_w
     if (num_rays == 0) return 0;
     if (num_rays < 0 || num_samples > 256 || n_focus < 3 || n_focus > 64 || n_focus > num_samples)
         return fail_arg("ffn_focus_fused: need 3 <= n_focus <= 64, n_focus <= S <= 256");
-    if (validate_chain(chain, false) || chain->wide)
-        return fail_arg("ffn_focus_fused: bad chain (narrow forward chains only)");
+    if (validate_chain(chain, false) || chain->wide > 1)
+        return fail_arg("ffn_focus_fused: bad chain (narrow and 512-wide forward chains only)");
     FocusParams p;
     p.starts = starts; p.dirs = directions; p.near_far = near_far; p.total_rays = num_rays_total;
     p.ray_index = ray_index; p.num_rays = num_rays; p.S = num_samples; p.n_focus = n_focus;
     p.unit_focus = unit_focus; p.u = u; p.t_io = t_io;
+    if (chain->wide) {                 // a pair of waves per ray, two pairs per workgroup
+        const int64_t grid = persistent_grid(num_rays, 2);
+        allow_big_lds(&focus_fused_kernel<true>);
+        hipLaunchKernelGGL(focus_fused_kernel<true>, dim3((unsigned)grid), dim3(256), kLdsBytes,
+                           (hipStream_t)stream, *chain, packed_w, bias, p);
+        return check_launch("ffn_focus_fused");
+    }
     const int64_t wgs = ((int64_t)num_rays + kWavesPerBlock - 1) / kWavesPerBlock;
     const int64_t grid = persistent_grid(wgs * kWavesPerBlock, kWavesPerBlock);
-    allow_big_lds(&focus_fused_kernel);
-    hipLaunchKernelGGL(focus_fused_kernel, dim3((unsigned)grid), dim3(256), kLdsBytes,
+    allow_big_lds(&focus_fused_kernel<false>);
+    hipLaunchKernelGGL(focus_fused_kernel<false>, dim3((unsigned)grid), dim3(256), kLdsBytes,
                        (hipStream_t)stream, *chain, packed_w, bias, p);
     return check_launch("ffn_focus_fused");
 }

@@ -1113,8 +1113,8 @@ class MlpProgram:
                      unit_focus, u, t_io):
         """Fused live focus sampling with THIS chain as the opacity model (see
         ``ffn_focus_fused``): fills ``t_io`` (R,S) in place."""
-        if self.wide or n_focus > 64:
-            raise NotImplementedError("fused focus sampling: narrow chains, at most 64 probe points")
+        if self.big or n_focus > 64:
+            raise NotImplementedError("fused focus sampling: chains of up to 512 channels, at most 64 probe points")
         _call("ffn_focus_fused", ctypes.byref(self.fwd), _dev(self.packed_fwd), _dev(self.bias_buf),
               _dev(starts), _dev(directions), _dev(near_far), c_i64(near_far.shape[1]),
               _dev(ray_index, torch.int64), c_i(ray_index.shape[0]), c_i(num_samples), c_i(n_focus),

@@ -21,14 +21,17 @@ def main():
     ap.add_argument("--model", default="tiny")
     ap.add_argument("--iters", type=int, default=4)
     ap.add_argument("--modes", default="f32,bf16x3")
+    ap.add_argument("--channels", type=int, default=256, help="hidden width (nerf / mlp models)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(1)
     n = args.rays * args.samples
     if args.model == "tiny":
         model, views = ffn.PositionalFourierMLP(3, 4, 5.5).to(dev), None
+    elif args.model == "mlp":
+        model, views = ffn.PositionalFourierMLP(3, 4, 5.5, num_channels=args.channels).to(dev), None
     else:
-        model = ffn.NeRF(8, 256, 9, 10, 3, 4, [4], True).to(dev)
+        model = ffn.NeRF(8, args.channels, 9, 10, 3, 4, [4], True).to(dev)
         views = torch.nn.functional.normalize(torch.randn(n, 3, device=dev), dim=1)
     prog = model.program()
     x = torch.rand(n, 3, device=dev) * 2 - 1
@@ -49,7 +52,10 @@ def main():
         spans.setdefault(name, []).append((e0, e1))
 
     _lib.call = hooked
-    out = {"library": os.environ.get("FFN_HIP_LIBRARY", "in-tree"), "samples": n}
+    out = {"library": os.environ.get("FFN_HIP_LIBRARY", "in-tree"), "samples": n, "model": args.model,
+           "channels": args.channels,
+           "flop_per_sample": {"forward": 2 * sum(sp.out * sp.ld for sp in prog.layers),
+                               "backward_data": 2 * sum(sp.out * sp.act_in for sp in prog.layers)}}
     for mode in args.modes.split(","):
         spans.clear()
         for it in range(args.iters + 1):

@@ -707,10 +707,27 @@ def test_fused_focus_kernel_equals_the_five_launch_live_path(golden):
             plain = smp.sample_t(idx, None)
             assert torch.equal(fused, plain)
             assert bool((fused[:, 1:] >= fused[:, :-1]).all())
-    # a 512-wide opacity model or a voxel grid takes the five-launch path
+    # round 5: a 512-wide opacity model runs the kernel's pair-of-waves variant (a pair per ray,
+    # two pairs per workgroup: odd ray counts and a single ray leave a pair without a ray) --
+    # == the five-launch path bit for bit; a model wider than 512 takes the five-launch path
     from tests.test_kernels_gpu import _load_fourier
     wide, _ = _load_fourier(golden("models"), "gaussian512")
-    smp = _quiet(ffn.RaySampler, data["bounds"], cams, 16, False, wide, 64, device=dev(), focus_mode="live")
+    for S, stratified in ((128, True), (16, False), (7, True)):
+        smp = _quiet(ffn.RaySampler, data["bounds"], cams, S, stratified, wide, 64, device=dev(), focus_mode="live")
+        n_focus = S - S // 2
+        assert smp._can_fuse_focus(n_focus) and wide.program().wide
+        for rays in (idx, idx[:1], idx[:777]):
+            smp.fused_focus = True
+            torch.manual_seed(S)
+            fused = smp.sample_t(rays, None)
+            smp.fused_focus = False
+            torch.manual_seed(S)
+            plain = smp.sample_t(rays, None)
+            assert torch.equal(fused, plain), (S, rays.numel())
+            assert bool((fused[:, 1:] >= fused[:, :-1]).all())
+    torch.manual_seed(3)
+    big = ffn.MLP(3, 4, num_layers=2, num_channels=768).to(dev())
+    smp = _quiet(ffn.RaySampler, data["bounds"], cams, 16, False, big, 64, device=dev(), focus_mode="live")
     assert not smp._can_fuse_focus(8)
     assert smp.sample_t(idx, None).shape == (idx.numel(), 16)
 

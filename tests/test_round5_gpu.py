@@ -414,3 +414,37 @@ def test_announced_next_batch_without_noise_is_bit_identical(golden):
         results.append((losses, engine.flat.clone()))
     assert results[0][0] == results[1][0]
     assert torch.equal(results[0][1], results[1][1])
+
+
+# ----------------------------------------------------------------------------------- 512-wide model as its own opacity model
+def test_wide_model_as_its_own_opacity_model_renders_on_the_one_launch_paths(golden):
+    """orbit_video.py's configuration (orbit_video.py:66-78: without --opacity-model the radiance
+    field itself guides the sampler) for BASELINE config 5's 512-wide Gaussian-feature model: the
+    coarse pass runs in ONE launch (the pair-of-waves variant of the fused focus kernel) and the
+    frame in one launch of the fused render kernel; the frame equals, byte for byte, the one
+    rendered through a sampler with the reference's precomputed CDF table."""
+    import fourier_feature_nets_amd as ffn
+    from tests.test_round2_gpu import SCENE, _scene_sampler
+    model, _ = tk._load_fourier(golden("models"), "gaussian512")
+    data = np.load(SCENE)
+    cams = _scene_sampler(8).cameras
+    frames = {}
+    for mode in ("table", "live"):
+        smp = _quiet(ffn.RaySampler, data["bounds"], cams, 32, False, model, 64, device=dev(), focus_mode=mode)
+        if mode == "live":
+            assert smp.cdfs is None and smp._can_fuse_focus(16) and model.program().wide
+            seen = []
+            from fourier_feature_nets_amd import _lib
+            real = _lib.call
+            _lib.call = lambda name, *a: (seen.append(name), real(name, *a))[1]
+            try:
+                frames[mode] = ffn.Raycaster(model).render_image(smp, 1, 64)
+            finally:
+                _lib.call = real
+            assert "ffn_focus_fused" in seen and "ffn_render_fused_fwd" in seen, sorted(set(seen))
+            assert "ffn_mlp_forward" not in seen
+        else:
+            frames[mode] = ffn.Raycaster(model).render_image(smp, 1, 64)
+    assert frames["live"].shape == frames["table"].shape and frames["live"].dtype == np.uint8
+    assert np.array_equal(frames["live"], frames["table"])
+    assert int(frames["live"].max()) > 0
