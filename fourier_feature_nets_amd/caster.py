@@ -228,7 +228,10 @@ class TrainEngine:
             # reference takes the mean of empty tensors here (ray_caster.py:321-326): a NaN loss
             # whose backward poisons every weight.  The loss is reported the same way (0 / 0), but
             # the optimiser step is skipped: no moment decay, no weight decay, weights intact.
-            return ops.loss_value(sums, 0, aw)
+            loss = ops.loss_value(sums, 0, aw)
+            if self.loss_history is not None:       # (one entry per call, skipped step or not)
+                self.loss_history.append(loss)
+            return loss
         self.count += 1
         ops.clip_adam(self.flat, self.grads, self.exp_avg, self.exp_avg_sq, self.count, lr,
                       weight_decay=self.weight_decay, scratch=self.scratch,

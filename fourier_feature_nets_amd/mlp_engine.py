@@ -1004,7 +1004,15 @@ class MlpProgram:
             # their own region when the launch is split (`_tail_split`), the split-bf16 kernels
             # know one mask region only
             split = self._tail_plan(n) if precision == "f32" else None
-            self._fwd_record = (saved.data_ptr(), n, precision, split)
+            # (per buffer: the last few forwards are remembered, so that a backward on an older
+            # buffer is checked against ITS forward)
+            records = getattr(self, "_fwd_records", None)
+            if records is None:
+                records = self._fwd_records = {}
+            records.pop(saved.data_ptr(), None)
+            records[saved.data_ptr()] = (saved.data_ptr(), n, precision, split)
+            while len(records) > 8:
+                records.pop(next(iter(records)))
         if precision == "bf16x3":
             if saved is None:
                 return self.forward16(positions, views)
@@ -1136,10 +1144,13 @@ class MlpProgram:
         n = positions.shape[0]
         if n == 0:                      # an empty batch contributes no gradient
             return grads.zero_()
-        record = getattr(self, "_fwd_record", None)
-        if record is not None and record[0] == saved.data_ptr() and record[1] == n:
+        record = (getattr(self, "_fwd_records", None) or {}).get(saved.data_ptr())
+        if record is not None and record[1] == n:
+            # the slab and dZ formats are shared by the modes; what must match is WHERE the ReLU
+            # masks of the launch's tail blocks were written (an f32 forward with a tail split keeps
+            # them in a region of their own that only the f32 backward with the same split reads)
             split = self._tail_plan(n) if precision == "f32" else None
-            if record[2] != precision or record[3] != split:
+            if record[3] != split:
                 raise RuntimeError("MlpProgram.backward: `saved` was filled by a %s forward (tail "
                                    "split %s) but the backward was asked for %s (tail split %s)"
                                    % (record[2], record[3], precision, split))

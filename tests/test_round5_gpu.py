@@ -448,3 +448,34 @@ def test_wide_model_as_its_own_opacity_model_renders_on_the_one_launch_paths(gol
     assert frames["live"].shape == frames["table"].shape and frames["live"].dtype == np.uint8
     assert np.array_equal(frames["live"], frames["table"])
     assert int(frames["live"].max()) > 0
+
+
+# ----------------------------------------------------------------------------------- forward / backward pairing
+def test_backward_checks_the_mask_region_of_its_own_forward(golden):
+    """A training forward in exact f32 whose launch was split (full rounds + a short last round on
+    the team kernels) keeps the tail blocks' ReLU masks in a region only the f32 backward with the
+    same split reads: a backward in another mode on THAT buffer raises; the same buffer filled
+    without a split, and an older buffer with its own record, differentiate in either mode."""
+    model, _ = tk._load_fourier(golden("models"), "positional")
+    prog = model.program()
+    n_split = 32 * (prog._resident_waves() + 10)
+    if prog._tail_plan(n_split) is None:
+        pytest.skip("no tail split at this size on this device")
+    n_plain = 1000
+    assert prog._tail_plan(n_plain) is None
+    grads = torch.empty((prog.num_grad_floats,), dtype=torch.float32, device=dev())
+    bufs = {}
+    for n in (n_plain, n_split):
+        x = torch.rand(n, 3, device=dev()) * 2 - 1
+        buf = torch.zeros((prog.saved_floats(n),), dtype=torch.float32, device=dev())
+        prog.forward(x, None, buf, precision="f32")
+        bufs[n] = (x, buf, torch.randn(n, 4, device=dev()) / n)
+    x, buf, dl = bufs[n_plain]            # the OLDER buffer: checked against its own forward
+    prog.backward(dl, x, None, buf, grads, precision="bf16x3")
+    prog.backward(dl, x, None, buf, grads, precision="f32")
+    x, buf, dl = bufs[n_split]
+    prog.backward(dl, x, None, buf, grads, precision="f32")
+    with pytest.raises(RuntimeError, match="tail split"):
+        prog.backward(dl, x, None, buf, grads, precision="bf16x3")
+    with pytest.raises(RuntimeError, match="tail split"):
+        prog.backward(dl, x, None, buf, grads, precision="bf16x6")
