@@ -60,12 +60,25 @@ class Tee(io.StringIO):
         return super().write(text)
 
 
-def run_protocol(ffn, args, device, out_path, half, extra=None):
-    """K seeds of Raycaster.fit through the package `ffn` (the reference or the HIP one)."""
-    npz = os.path.join(args.workdir, "psnr_ensemble_%dx%d_%d.npz" % (args.size, args.size, args.cameras))
+def scene_path(args):
+    """The protocol's scene file in the work directory, written if absent.  The name carries every
+    argument the contents depend on, and a file found there is checked against them (a stale file
+    from a run with another camera count must not be picked up silently)."""
+    npz = os.path.join(args.workdir, "psnr_ensemble_%dx%d_%d_%d.npz" % (args.size, args.size, args.cameras,
+                                                                       args.val_cameras))
     os.makedirs(args.workdir, exist_ok=True)
     if not os.path.exists(npz):
         write_npz(npz, args.cameras, args.val_cameras, args.size)
+    counts = np.load(npz)["split_counts"].tolist()
+    if counts[:2] != [args.cameras, args.val_cameras]:
+        raise RuntimeError("%s holds %s cameras, the protocol asks for %d + %d" %
+                           (npz, counts, args.cameras, args.val_cameras))
+    return npz
+
+
+def run_protocol(ffn, args, device, out_path, half, extra=None):
+    """K seeds of Raycaster.fit through the package `ffn` (the reference or the HIP one)."""
+    npz = scene_path(args)
     runs = []
     if os.path.exists(out_path) and args.resume:
         with open(out_path) as f:
@@ -267,9 +280,11 @@ def compare(doc, reference_path, out_path):
         "delta_mean_db": delta, "stderr_of_delta_db": se,
         "within_0p05_db": abs(delta) < 0.05, "within_2_stderr": abs(delta) < 2 * se,
         # (the HIP half may run MORE seeds than the reference half: the reference's are a prefix)
+        # (and a reference fixture may hold fewer runs than its protocol planned: the seeds that
+        # count are the ones its runs carry)
         "protocol_matches": ({k: v for k, v in ref["protocol"].items() if k != "seeds"} ==
                              {k: v for k, v in doc["protocol"].items() if k != "seeds"} and
-                             set(ref["protocol"]["seeds"]) <= set(doc["protocol"]["seeds"])),
+                             {r["seed"] for r in ref["runs"]} <= set(doc["protocol"]["seeds"])),
         "mean_curves": curve,
         "verdict": "pass" if (abs(delta) < 0.05 or abs(delta) < 2 * se) else "fail"}
     with open(out_path, "w") as f:
