@@ -473,3 +473,54 @@ def test_bench_batch_plan_weak_and_strong():
     assert bench.batch_plan(65536, 8, "strong") == (65536, 8192)
     with pytest.raises(SystemExit):
         bench.batch_plan(1000, 3, "strong")
+
+
+def test_psnr_ensemble_verdicts_and_stale_scene_files(tmp_path):
+    """tests/psnr_ensemble.py, the statistics the PSNR clause rests on: the three-valued verdict
+    (fail / pass-resolved / pass-unresolved) with the minimum detectable difference, the
+    seed-paired window, `protocol_matches` against a fixture that holds fewer runs than planned --
+    and a cached scene file with another camera count is refused, not picked up."""
+    import argparse
+    import json
+    from tests import psnr_ensemble as pe
+
+    def doc(finals, seeds_planned, drift):
+        runs = [{"seed": 100 + i, "reports": [{"step": s, "train_psnr": v, "val_psnr": v + drift * s * (1 if i % 2 else -1)}
+                                              for s in (0, 10, 20)], "final_val_psnr": v}
+                for i, v in enumerate(finals)]
+        out = {"protocol": {"seeds": [100 + i for i in range(seeds_planned)], "rays": 1024}, "runs": runs}
+        out.update(pe.stats_of(runs))
+        return out
+
+    ref_path = str(tmp_path / "ref.json")
+    out_path = str(tmp_path / "out.json")
+
+    def verdict(mine, theirs, drift=0.0, planned=None):
+        with open(ref_path, "w") as f:
+            json.dump(doc(theirs, planned or len(theirs), 0.0), f)
+        import contextlib, io
+        with contextlib.redirect_stdout(io.StringIO()):
+            got = pe.compare(doc(mine, len(mine), drift), ref_path, out_path)["against_reference"]
+        return got
+
+    tight = [30.00, 30.01, 29.99, 30.00, 30.01, 29.99]
+    a = verdict(tight, tight)
+    assert a["resolution"]["verdict"] == "pass-resolved" and a["protocol_matches"]
+    assert a["resolution"]["first_report_step_with_a_seed_outside_0p05_db"] is None
+    wide = [30.0, 30.6, 29.4, 30.3, 29.7, 30.0]
+    b = verdict(wide, wide, drift=0.004)
+    assert b["resolution"]["verdict"] == "pass-unresolved"          # 2 s.e. of the means is far above 0.05 dB
+    assert b["resolution"]["first_report_step_with_a_seed_outside_0p05_db"] == 20   # 0.004 dB/step leaves at 0.08
+    assert b["resolution"]["paired_reports_all_seeds_within_0p05_db_at_steps"] == [0, 10]
+    c = verdict([v + 0.2 for v in tight], tight)
+    assert c["resolution"]["verdict"] == "fail" and c["verdict"] == "fail"
+    # a fixture with fewer runs than its protocol planned still matches on the seeds it carries
+    d = verdict(tight, tight[:3], planned=6)
+    assert d["protocol_matches"] and len(d["per_seed_delta_db"]) == 3
+
+    args = argparse.Namespace(workdir=str(tmp_path), size=8, cameras=3, val_cameras=2)
+    first = pe.scene_path(args)
+    assert pe.scene_path(args) == first
+    os.replace(first, first.replace("_3_2.npz", "_3_1.npz"))         # a file written for 3 + 2 cameras under the 3 + 1 name
+    with pytest.raises(RuntimeError, match="cameras"):
+        pe.scene_path(argparse.Namespace(workdir=str(tmp_path), size=8, cameras=3, val_cameras=1))
