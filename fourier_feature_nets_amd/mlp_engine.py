@@ -652,7 +652,10 @@ class MlpProgram:
         the split-bf16 chains with every operand as THREE bf16 parts (hi, mid, lo -- the f32 value
         exactly) instead of two, i.e. the same K order and job tables with 1.5x the offsets
         (``ffn_mlp_pack_bf16_parts(parts=3)``).  Narrow chains only (<= 256 channels per layer:
-        the three-part X image of a 512-wide chain does not fit the LDS)."""
+        the three-part X image of a 512-wide chain leaves room for ONE 32-sample block per pass
+        (96 KiB), i.e. every weight would stream from L2 once per 32 samples -- 4.7 MB per pass of
+        a three-layer 512-wide chain, ~620 GB per 2^22 samples, ~40 ms at the L2's rate where the
+        exact-f32 kernel takes 50: not built)."""
         self.fwd_x6 = self.bwd_x6 = None
         self.packed_x6 = self.packed_x6_bwd = None
         self._packed_x6_dirty = True
