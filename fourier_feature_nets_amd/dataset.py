@@ -16,7 +16,7 @@ import torch.nn as nn
 from . import ops
 from .cameras import CameraInfo, Resolution
 from .sampler import RaySampler, RaySamples
-from .utils import ETABar, RenderResult, check_color_space, rgb_to_ycrcb_u8
+from .utils import RenderResult, check_color_space, rgb_to_ycrcb_u8
 
 
 class _MseLoss(torch.autograd.Function):

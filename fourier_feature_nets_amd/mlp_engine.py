@@ -12,11 +12,10 @@ import ctypes
 import os
 from typing import Dict, List, Optional, Sequence
 
-import numpy as np
 import torch
 
 from . import _lib
-from ._lib import c_i, c_i64, c_p
+from ._lib import c_i, c_i64
 from .ops import _call, _dev
 
 MAX_STEPS = 16

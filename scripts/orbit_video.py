@@ -7,7 +7,6 @@ import os
 import sys
 
 import numpy as np
-import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import fourier_feature_nets_amd as ffn  # noqa: E402
