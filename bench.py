@@ -41,9 +41,12 @@ KERNEL_OF = {"ffn_mlp_forward": "mlp_forward_kernel<train>",
              "ffn_mlp_backward_data": "mlp_backward_data_kernel",
              "ffn_mlp_wgrad_units": "wgrad_unit_kernel"}
 # (kernel symbols as rocprofv3 prints them; the second template argument of the chain kernels is
-# the number of waves per block: round 3's profiles call the same kernels <1, false> / <false>)
-SYMBOL_OF = {"mlp_forward_kernel<train>": ("ffn::mlp_forward_kernel<1, 1>", "ffn::mlp_forward_kernel<1, false>"),
-             "mlp_backward_data_kernel": ("ffn::mlp_backward_data_kernel<1>", "ffn::mlp_backward_data_kernel<false>"),
+# the number of waves per block, the third -- round 5 -- the team-of-four variant of the 1024-wide
+# chains: round 4's profiles call the same kernels <1, 1> / <1>, round 3's <1, false> / <false>)
+SYMBOL_OF = {"mlp_forward_kernel<train>": ("ffn::mlp_forward_kernel<1, 1, false>", "ffn::mlp_forward_kernel<1, 1>",
+                                           "ffn::mlp_forward_kernel<1, false>"),
+             "mlp_backward_data_kernel": ("ffn::mlp_backward_data_kernel<1, false>", "ffn::mlp_backward_data_kernel<1>",
+                                          "ffn::mlp_backward_data_kernel<false>"),
              "wgrad_unit_kernel": ("ffn::wgrad_unit_kernel",)}
 
 

@@ -524,3 +524,16 @@ def test_psnr_ensemble_verdicts_and_stale_scene_files(tmp_path):
     os.replace(first, first.replace("_3_2.npz", "_3_1.npz"))         # a file written for 3 + 2 cameras under the 3 + 1 name
     with pytest.raises(RuntimeError, match="cameras"):
         pe.scene_path(argparse.Namespace(workdir=str(tmp_path), size=8, cameras=3, val_cameras=1))
+
+
+def test_bench_finds_its_kernels_in_the_committed_traffic_profile():
+    """bench.py's `roofline.traffic` comes from the committed PMC passes, looked up by the kernel
+    symbol rocprofv3 printed: a template argument added to a kernel must not turn it into null."""
+    import argparse
+    import bench
+    args = argparse.Namespace(rays=65536, samples=64, model="tiny")
+    for name in bench.SYMBOL_OF:
+        value, source = bench.traffic_of(name, args)
+        assert value is not None and value > 1e9, (name, source)
+    # another shape than the profiled one has no traffic figure (null, never a wrong one)
+    assert bench.traffic_of("wgrad_unit_kernel", argparse.Namespace(rays=1024, samples=64, model="tiny"))[0] is None
