@@ -253,7 +253,8 @@ def compare(doc, reference_path, out_path):
     # what the comparison can and cannot resolve: the minimum detectable difference of the
     # UNPAIRED means (2 standard errors of their difference) next to the 0.05 dB bar, and how long
     # the seed-PAIRED trajectories stay inside it
-    mdd = 2.0 * se
+    # (a side with a single seed has no standard error: nothing is resolved by the means then)
+    mdd = 2.0 * se if (a["stderr"] is not None and b["stderr"] is not None) else float("inf")
     held = [r["step"] for r in paired_reports if r["max_abs_delta_db"] < 0.05]
     first_out = next((r["step"] for r in paired_reports if r["max_abs_delta_db"] >= 0.05), None)
     if abs(delta) >= 0.05 and abs(delta) >= mdd:
@@ -264,7 +265,7 @@ def compare(doc, reference_path, out_path):
         verdict3 = "pass-unresolved"
     doc["against_reference"] = {
         "resolution": {
-            "bar_db": 0.05, "minimum_detectable_difference_db (2 s.e. of the difference of the means)": mdd,
+            "bar_db": 0.05, "minimum_detectable_difference_db (2 s.e. of the difference of the means)": mdd if np.isfinite(mdd) else None,
             "seeds_per_side_for_mdd_0p05": int(np.ceil((2.0 * np.sqrt(2.0) * max(a["std"] or 0.0, b["std"] or 0.0) / 0.05) ** 2)),
             "verdict": verdict3,
             "verdicts": "fail: |delta| >= 0.05 dB and >= 2 s.e.; pass-resolved: not failed and the ensemble COULD "
@@ -286,7 +287,7 @@ def compare(doc, reference_path, out_path):
                              {k: v for k, v in doc["protocol"].items() if k != "seeds"} and
                              {r["seed"] for r in ref["runs"]} <= set(doc["protocol"]["seeds"])),
         "mean_curves": curve,
-        "verdict": "pass" if (abs(delta) < 0.05 or abs(delta) < 2 * se) else "fail"}
+        "verdict": "pass" if (abs(delta) < 0.05 or abs(delta) < mdd) else "fail"}
     with open(out_path, "w") as f:
         json.dump(doc, f, indent=1)
     print(json.dumps({k: v for k, v in doc["against_reference"].items() if k != "mean_curves"}, indent=1))

@@ -537,3 +537,22 @@ def test_bench_finds_its_kernels_in_the_committed_traffic_profile():
         assert value is not None and value > 1e9, (name, source)
     # another shape than the profiled one has no traffic figure (null, never a wrong one)
     assert bench.traffic_of("wgrad_unit_kernel", argparse.Namespace(rays=1024, samples=64, model="tiny"))[0] is None
+
+
+def test_psnr_ensemble_single_seed_resolves_nothing(tmp_path):
+    """One seed a side has no standard error: the means resolve nothing (never a `fail`)."""
+    import contextlib, io, json
+    from tests import psnr_ensemble as pe
+
+    def doc(v):
+        runs = [{"seed": 1, "reports": [{"step": 0, "train_psnr": v, "val_psnr": v}], "final_val_psnr": v}]
+        out = {"protocol": {"seeds": [1]}, "runs": runs}
+        out.update(pe.stats_of(runs))
+        return out
+    ref = str(tmp_path / "ref.json")
+    with open(ref, "w") as f:
+        json.dump(doc(20.0), f)
+    with contextlib.redirect_stdout(io.StringIO()):
+        got = pe.compare(doc(20.4), ref, str(tmp_path / "out.json"))["against_reference"]
+    assert got["resolution"]["verdict"] == "pass-unresolved" and got["verdict"] == "pass"
+    json.dumps(got)      # (no infinity in the document)
