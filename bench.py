@@ -295,13 +295,18 @@ def check_one_device_per_rank(group, world, device, backend, shared_gpu):
     if world > visible:
         raise SystemExit("bench.py: %d ranks but only %d GPU(s) visible to rank %d"
                          % (world, visible, dist.get_rank(group)))
-    # the device's PCI bus id identifies the physical GPU whatever the visibility masks are
+    # the device's PCI address (domain : bus : device) and uuid identify the physical GPU whatever
+    # the visibility masks are; the index inside this process's view separates unmasked ranks
     props = torch.cuda.get_device_properties(device)
-    ident = "%s/%d" % (getattr(props, "pci_bus_id", None) or getattr(props, "uuid", ""), device.index)
+    hardware = tuple(str(getattr(props, key, "")) for key in ("pci_domain_id", "pci_bus_id", "pci_device_id", "uuid"))
+    known = any(v not in ("", "None") for v in hardware)
+    ident = ":".join(hardware) + "/%d/%d" % (visible, device.index)
     idents = [None] * world
-    dist.all_gather_object(idents, ident, group=group)
-    if len(set(idents)) != world:
-        raise SystemExit("bench.py: ranks share a GPU under the nccl backend: %s" % (idents,))
+    dist.all_gather_object(idents, (ident, known), group=group)
+    if not all(k for _, k in idents):       # (no hardware identity on this build of torch: cannot tell)
+        return {"visible_devices": visible, "distinct_devices": None}
+    if len({i for i, _ in idents}) != world:
+        raise SystemExit("bench.py: ranks share a GPU under the nccl backend: %s" % ([i for i, _ in idents],))
     return {"visible_devices": visible, "distinct_devices": world}
 
 
