@@ -1,11 +1,14 @@
-# HIP halves of round 5's two extra PSNR protocols against their reference fixtures (as many seeds
-# as the fixtures hold), exact-f32 kernels and the bf16x6 mode, jitter from the CPU generator like
-# the reference (seed-paired trajectories)
+# HIP halves of round 5's two extra PSNR protocols against their reference fixtures: HIP_SEEDS seeds
+# (default 24; the fixtures' seeds are a prefix: those are the seed-paired ones), exact-f32 kernels
+# and the bf16x6 mode, jitter from the CPU generator like the reference (seed-paired trajectories)
 OUT=gpurun_out/r5ens
 mkdir -p $OUT
 K_NERF=$(python -c "import json;print(len(json.load(open('tests/golden/psnr_ensemble_reference_nerf.json'))['runs']))")
 K_SLOW=$(python -c "import json;print(len(json.load(open('tests/golden/psnr_ensemble_reference_slow.json'))['runs']))")
-echo "reference seeds: nerf $K_NERF, slow $K_SLOW"
+HIP_SEEDS=${HIP_SEEDS:-24}
+if [ $K_NERF -lt $HIP_SEEDS ]; then K_NERF=$HIP_SEEDS; fi
+if [ $K_SLOW -lt $HIP_SEEDS ]; then K_SLOW=$HIP_SEEDS; fi
+echo "hip seeds: nerf $K_NERF, slow $K_SLOW"
 for mode in f32 bf16x6; do
   suffix=""; if [ $mode != f32 ]; then suffix="_$mode"; fi
   FFN_PRECISION=$mode timeout 1500 python -m tests.psnr_ensemble hip --model nerf --opacity voxels --size 128 --cameras 20 --val-cameras 4 \
