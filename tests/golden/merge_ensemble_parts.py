@@ -1,7 +1,9 @@
 """Joins the `runs` of several `python -m tests.psnr_ensemble reference ... --resume` processes that
 computed disjoint ranges of ONE protocol's seeds in parallel (seed k re-seeds torch and numpy at its
 start and shares nothing with the other seeds, so a seed's curve does not depend on the process it
-ran in).  Build container only; the output is the fixture a single process would have written.
+ran in -- checked from the other side: the HIP halves run all 24 seeds in ONE process and stay
+within 0.0011 dB of every reference seed at every report, the first seeds of the parts included).
+Build container only; the output is the fixture a single process would have written.
 
     python tests/golden/merge_ensemble_parts.py OUT.json BASE.json PART.json:FIRST [PART.json:FIRST ...]
 
