@@ -123,9 +123,7 @@ class TrainEngine:
         return buf
 
     def _samples(self, sampler: RaySampler, rays: torch.Tensor, step: Optional[int]):
-        t = sampler.sample_t(rays, step)
-        pos, views = ops.materialise_samples(sampler.starts, sampler.directions, rays, t,
-                                             want_views=self.model.use_view)
+        t, pos, views = sampler.sample_points(rays, step, want_views=self.model.use_view)
         return t, pos.view(-1, 3), None if views is None else views.view(-1, 3)
 
     def shard(self, rays: torch.Tensor) -> torch.Tensor:

@@ -111,6 +111,47 @@ materialise_kernel(const float* __restrict__ starts, const float* __restrict__ d
     }
 }
 
+// ---------------------------------------------------------------------------------- K2a + K2b
+// sample_t_kernel and materialise_kernel in ONE launch (samplers without an opacity model, where
+// nothing merges into t between the two): a thread per (ray, sample) computes t with the K2a
+// operations, then the sample's position and view direction with the K2b operations -- the same
+// bits as the two launches (this file is compiled without FMA contraction).
+__global__ void __launch_bounds__(256)
+sample_materialise_kernel(const float* __restrict__ near_far, int64_t total_rays,
+                          const float* __restrict__ starts, const float* __restrict__ dirs,
+                          const int64_t* __restrict__ ray_index, int num_rays, int count,
+                          const float* __restrict__ unit, const float* __restrict__ noise, float anneal,
+                          float* __restrict__ t_out, float* __restrict__ positions,
+                          float* __restrict__ views) {
+    const int64_t n = (int64_t)num_rays * count;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(e / count);
+        const int s = (int)(e - (int64_t)r * count);
+        const int64_t ray = ray_index[r];
+        float near = near_far[ray];
+        float far = near_far[total_rays + ray];
+        if (anneal >= 0.0f) {
+            const float mid = (near + far) * 0.5f;
+            near = mid + (near - mid) * anneal;
+            far = mid + (far - mid) * anneal;
+        }
+        const float span = far - near;
+        float t = near + unit[s] * span;
+        if (noise != nullptr) {
+            const float scale = span / (float)count;
+            t = t + noise[e] * scale;
+        }
+        t_out[e] = t;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float dir = dirs[ray * 3 + d];
+            positions[e * 3 + d] = starts[ray * 3 + d] + t * dir;
+            if (views != nullptr) views[e * 3 + d] = dir;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------- K8
 __global__ void __launch_bounds__(256)
 to_image_kernel(const float* __restrict__ colors, const int64_t* __restrict__ pixel_index,
@@ -184,6 +225,18 @@ extern "C" int ffn_sample_t(const float* near_far, int64_t num_rays_total,
                        (hipStream_t)stream, near_far, num_rays_total, ray_index, num_rays, count,
                        unit, noise, anneal, t_out, t_stride);
     return check_launch("ffn_sample_t");
+}
+
+extern "C" int ffn_sample_materialise(const float* near_far, int64_t num_rays_total, const float* starts,
+                                      const float* directions, const int64_t* ray_index, int num_rays,
+                                      int count, const float* unit, const float* noise, float anneal,
+                                      float* t_out, float* positions, float* views, void* stream) {
+    if (num_rays == 0) return 0;
+    if (num_rays < 0 || count <= 0) return fail_arg("ffn_sample_materialise: shape");
+    hipLaunchKernelGGL(sample_materialise_kernel, dim3(grid_for((int64_t)num_rays * count)), dim3(256), 0,
+                       (hipStream_t)stream, near_far, num_rays_total, starts, directions, ray_index,
+                       num_rays, count, unit, noise, anneal, t_out, positions, views);
+    return check_launch("ffn_sample_materialise");
 }
 
 extern "C" int ffn_materialise_samples(const float* starts, const float* directions,

@@ -105,6 +105,18 @@ def materialise_samples(starts, directions, ray_index, t_values, want_views=True
     return pos, views
 
 
+def sample_materialise(near_far, starts, directions, ray_index, count, unit, noise, anneal, want_views=True):
+    """K2a + K2b in one launch: t (R,count), positions (R,count,3) [, view_directions]."""
+    rays = ray_index.shape[0]
+    t = torch.empty((rays, count), dtype=torch.float32, device=near_far.device)
+    pos = torch.empty((rays, count, 3), dtype=torch.float32, device=near_far.device)
+    views = torch.empty_like(pos) if want_views else None
+    _call("ffn_sample_materialise", _dev(near_far), c_i64(near_far.shape[1]), _dev(starts), _dev(directions),
+          _dev(ray_index, torch.int64, "ray_index"), c_i(rays), c_i(count), _dev(unit), _dev(noise),
+          c_f(-1.0 if anneal is None else float(anneal)), _dev(t), _dev(pos), _dev(views))
+    return t, pos, views
+
+
 def cdf_build(t_probe: torch.Tensor, opacity: torch.Tensor) -> torch.Tensor:
     """K2c.  (P,n),(P,n) -> (P,n-1)."""
     rays, n = t_probe.shape

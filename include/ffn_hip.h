@@ -75,6 +75,15 @@ int ffn_materialise_samples(const float* starts, const float* directions,
                             const int64_t* ray_index, const float* t_values, int num_rays,
                             int num_samples, float* positions, float* views, void* stream);
 
+/* K2a + K2b in one launch (ray_sampler.py:372-397 for a sampler WITHOUT an opacity model, where
+ * nothing merges into t between the two): the arguments of ffn_sample_t with t_stride == count,
+ * plus the ray starts / directions; t_out (R,count), positions / views (R,count,3), views may be
+ * NULL.  Bit-identical to ffn_sample_t followed by ffn_materialise_samples. */
+int ffn_sample_materialise(const float* near_far, int64_t num_rays_total, const float* starts,
+                           const float* directions, const int64_t* ray_index, int num_rays,
+                           int count, const float* unit, const float* noise, float anneal,
+                           float* t_out, float* positions, float* views, void* stream);
+
 /* K2c  per-ray CDF from probe opacities (ray_sampler.py:59-67, _determine_cdf).
  *   t_probe (P,n), opacity (P,n) -> cdf (P,n-1) */
 int ffn_cdf_build(const float* t_probe, const float* opacity, int64_t num_rays, int n,

@@ -111,6 +111,14 @@ def test_sampling_bit_exact(ops, golden, step, stratified):
     assert np.array_equal(pos.cpu().numpy(), g["%s_pos_%s" % (tag, key)])
     if not stratified:
         assert np.array_equal(views.cpu().numpy(), g["u_view_" + key])
+    # the one-launch form (what samplers without an opacity model run): the same bits, hence the
+    # reference's own values too
+    t1, pos1, views1 = ops.sample_materialise(near_far, starts, dirs, idx, S, unit, noise, anneal)
+    assert torch.equal(t1, t) and torch.equal(pos1, pos) and torch.equal(views1, views)
+    t2, pos2, none = ops.sample_materialise(near_far, starts, dirs, idx, S, unit, noise, anneal, want_views=False)
+    assert none is None and torch.equal(t2, t) and torch.equal(pos2, pos)
+    empty = idx[:0]
+    assert ops.sample_materialise(near_far, starts, dirs, empty, S, unit, None, None)[1].shape == (0, S, 3)
 
 
 def test_sampling_empty_and_ragged(ops, golden):
