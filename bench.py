@@ -1311,16 +1311,28 @@ def main():
                             "next one starts (what Raycaster.render_image returns)"},
         }
         if engine.collective_events:
-            us = [1e3 * a.elapsed_time(b) for a, b in engine.collective_events]
+            staged = backend != "nccl"
+            us = [1e3 * a.elapsed_time(b) for a, _, b in engine.collective_events]
+            # (host-staged groups: the middle stamp sits behind the collective, nothing overlaps)
+            under = [0.0 if staged else 1e3 * a.elapsed_time(m) for a, m, _ in engine.collective_events]
+            waited = ([1e3 * a.elapsed_time(m) for a, m, _ in engine.collective_events] if staged
+                      else [1e3 * m.elapsed_time(b) for _, m, b in engine.collective_events])
+            step_us = 1e6 * elapsed / args.steps
             result["collective"] = {
                 "op": "all_reduce(sum) of [flat gradients | 2 loss sums], one per step",
                 "overlap": "issued asynchronously on the communicator's stream; the next step's sampling "
-                           "kernels are enqueued under it, the launch stream waits in front of clip+Adam "
-                           "(avg_us spans issue -> wait, i.e. includes those kernels)",
+                           "kernels are enqueued under it, the launch stream waits in front of clip+Adam",
                 "backend": "rccl" if backend == "nccl" else backend + " (host-staged)",
                 "ranks": world, "bytes": int(engine.reduce_buf.numel()) * 4,
-                "avg_us": round(sum(us) / len(us), 1), "max_us": round(max(us), 1),
-                "frac_of_step": round(sum(us) / len(us) * 1e-3 / (1e3 * elapsed / args.steps), 4),
+                # three stamps on the launch stream per step: issue | look-ahead sampling enqueued |
+                # behind the wait.  The span is max(collective, sampling) -- NOT the collective alone
+                "span_issue_to_wait_avg_us": round(sum(us) / len(us), 1),
+                "span_issue_to_wait_max_us": round(max(us), 1),
+                "sampling_under_the_collective_avg_us": round(sum(under) / len(under), 1),
+                "launch_stream_waited_avg_us": round(sum(waited) / len(waited), 1),
+                "launch_stream_waited_max_us": round(max(waited), 1),
+                "waited_frac_of_step": round(sum(waited) / len(waited) / step_us, 4),
+                "span_frac_of_step": round(sum(us) / len(us) / step_us, 4),
                 "shared_gpu": shared_gpu,
                 # rank 0's view of the collective; the ranks' own step times sit next to it
                 "rank_step_ms": rank_ms, "placement": placement}

@@ -95,7 +95,7 @@ class TrainEngine:
             import torch.distributed as dist
             # a gloo group (CPU tests, several ranks sharing one GPU) reduces through the host
             self._host_staged = dist.get_backend(process_group) == "gloo"
-        self.collective_events = None     # set to [] to record (start, end) events per all-reduce
+        self.collective_events = None     # set to [] to record (issue, sampling enqueued, behind the wait) events per all-reduce
         # OPT-IN empty-space skipping during training (BASELINE config 5; no counterpart in the
         # reference): with an OccupancyGrid here, the MLP forward / backward run only on the
         # samples in occupied cells; the others are treated as sigma = 0 constants (no colour, no
@@ -154,7 +154,12 @@ class TrainEngine:
         mine = self.shard(next_rays)
         per_launch = max(1, self.max_samples // sampler.num_samples)
         chunk = mine[:per_launch]
-        self._prefetched = {"key": (next_rays.data_ptr(), int(next_rays.numel()), next_step, id(sampler)),
+        if mine.numel() == 0:      # (a rank whose shard of the next batch is empty has nothing to sample)
+            return
+        # the announced tensor itself is kept: `train_step` accepts the look-ahead only for the very
+        # same object (an address + count identity would also match a NEW batch allocated where a
+        # freed one lay)
+        self._prefetched = {"rays": next_rays, "step": next_step, "sampler": sampler,
                             "shard": mine, "samples": self._samples(sampler, chunk, next_step)}
 
     def train_step(self, dataset, batch, step: int, lr: float,
@@ -168,7 +173,8 @@ class TrainEngine:
         all_rays = dataset.ray_ids(batch) if rays is None else rays
         global_count = int(all_rays.numel())
         ahead, self._prefetched = getattr(self, "_prefetched", None), None
-        if ahead is not None and ahead["key"] != (all_rays.data_ptr(), global_count, step, id(sampler)):
+        if ahead is not None and not (ahead["rays"] is all_rays and ahead["step"] == step and
+                                      ahead["sampler"] is sampler):
             ahead = None          # (not the batch that was announced: sample afresh)
         rays = self.shard(all_rays) if ahead is None else ahead["shard"]
         count = int(rays.numel())
@@ -255,22 +261,30 @@ class TrainEngine:
         import torch.distributed as dist
         events = self.collective_events
         if events is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            # three stamps on the LAUNCH stream: issue | the look-ahead sampling kernels enqueued |
+            # behind the wait.  (e0, e1) spans max(collective, sampling), NOT the collective alone;
+            # (e0, em) is the sampling that ran under it, and what the step really pays for the
+            # collective is the rest, (em, e1): the time the launch stream stood waiting.
+            e0, em, e1 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
             e0.record()
         if self._host_staged:
             host = self.reduce_buf.cpu()
             dist.all_reduce(host, group=self.group)
             self.reduce_buf.copy_(host)
+            if events is not None:
+                em.record()          # (host-staged: nothing overlaps, the sampling comes behind)
             if lookahead is not None:
                 self._prefetch(lookahead)
         else:
             work = dist.all_reduce(self.reduce_buf, group=self.group, async_op=True)
             if lookahead is not None:
                 self._prefetch(lookahead)
+            if events is not None:
+                em.record()
             work.wait()              # (the launch stream waits; the host does not)
         if events is not None:
             e1.record()
-            events.append((e0, e1))
+            events.append((e0, em, e1))
 
     def reduce_small(self, values: torch.Tensor) -> torch.Tensor:
         """Sum of a few device floats over the ranks (sharded validation): in place."""
@@ -583,6 +597,7 @@ class Raycaster(nn.Module):
             order = self._epoch_order(num_rays, engine)
             # valid-ray filter of the whole epoch in one go (one sync per epoch, not per step)
             epoch_rays, bounds = train_dataset.epoch_ray_ids(order, batch_size)
+            announced = None
             for bi, start in enumerate(range(0, num_rays, batch_size)):
                 if step > num_steps:
                     break
@@ -599,12 +614,14 @@ class Raycaster(nn.Module):
                 # this step's gradient all-reduce (data parallel only; never with host-side noise,
                 # whose draws a discarded look-ahead -- crop removal, last step -- would shift
                 # against the reference's generator)
-                ahead = None
+                # (the engine honours an announcement only for the very tensor it was given)
+                mine = announced if announced is not None else epoch_rays[bounds[bi]:bounds[bi + 1]]
+                ahead = announced = None
                 if (engine.group is not None and bi + 2 < len(bounds) and step < num_steps
                         and train_dataset.sampler.noise_source != "host"):
-                    ahead = (train_dataset, epoch_rays[bounds[bi + 1]:bounds[bi + 2]], step + 1)
-                engine.train_step(train_dataset, batch, step, lr,
-                                  rays=epoch_rays[bounds[bi]:bounds[bi + 1]], lookahead=ahead)
+                    announced = epoch_rays[bounds[bi + 1]:bounds[bi + 2]]
+                    ahead = (train_dataset, announced, step + 1)
+                engine.train_step(train_dataset, batch, step, lr, rays=mine, lookahead=ahead)
 
                 if step < 10 or step % report_interval == 0:
                     engine.check_finite()

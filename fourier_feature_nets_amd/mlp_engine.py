@@ -957,6 +957,24 @@ class MlpProgram:
         acts = self.saved_channels * 32 * blocks
         return saved[:acts], saved[acts:acts + self.fwd.num_slots * self.mask_words * blocks]
 
+    def slab_rows(self, saved: torch.Tensor, n: int, layer: int) -> torch.Tensor:
+        """The output of hidden layer ``layer`` (an index into ``self.layers``) as an ``(n, out)``
+        tensor, read back from the activation slab a training forward left in ``saved`` -- a copy
+        for `FourierFeatureMLP.keep_activations` (fourier_feature_models.py:74-75), off the hot
+        path.  Slab layout (section 3 of DESIGN.md): per 32-sample block ``C * 32`` floats as
+        float4 ``[cq][pos]``, ``cq = channel / 4``, ``pos = sample ^ (cq & 15)``."""
+        slot = self.slot_of.get(layer) if isinstance(self.slot_of, dict) else None
+        if slot is None:
+            raise ValueError("layer %d leaves no activation slab" % layer)
+        blocks = (n + 31) // 32
+        acts, _ = self._split_saved(saved, n)
+        ch, off = int(self.fwd.slot_channels[slot]), int(self.fwd.slot_offset[slot])
+        region = acts[off * blocks * 32:(off + ch) * blocks * 32].view(blocks, ch // 4, 32, 4)
+        cq = torch.arange(ch // 4, device=saved.device)
+        pos = torch.arange(32, device=saved.device)[None, :] ^ (cq[:, None] & 15)      # where sample s sits
+        rows = region[:, cq[:, None], pos, :]                                          # (blocks, cq, s, 4)
+        return rows.permute(0, 2, 1, 3).reshape(blocks * 32, ch)[:n, :self.layers[layer].out].contiguous()
+
     # ------------------------------------------------------------------ tail on wave pairs
     def _resident_waves(self) -> int:
         if getattr(self, "_waves", None) is None:
@@ -1140,14 +1158,26 @@ class MlpProgram:
         launch was split (``_tail_split``) leaves the tail blocks' ReLU masks in a region only the
         f32 backward reads -- a mismatch raises instead of differentiating with stale masks.
         ``precision="bf16x3"`` (opt-in) runs the split-bf16 backward-data and weight-gradient
-        kernels; ``"bf16x6"`` (opt-in) the f32-accurate three-part backward-data kernel and the
-        EXACT-f32 weight-gradient units (twice the matrix instructions would make that kernel
-        slower than the exact one)."""
+        kernels; ``"bf16x6"`` (opt-in) the f32-accurate three-part backward-data kernel and a
+        TWO-LAUNCH weight-gradient plan over one partial buffer: every full unit (four 128 x 128
+        quadrants) and the logits-head units on the three-part kernel
+        (``ffn_mlp_wgrad_units_bf16x6``), units with fewer quadrants -- NeRF's 63- / 27-channel
+        encodings, its 128-channel view layer -- on the exact-f32 kernel, which folds narrow
+        windows (``_plan_wgrad``).  ``FFN_BF16X6_WGRAD=f32`` puts every unit on the exact-f32 kernel.
+        Forward / backward pairs: the same mode on both sides, or an exact-f32 forward under any
+        backward (the slab, mask and save-on-consume layouts are shared and both directions are
+        tested against each other); any other mix raises."""
         n = positions.shape[0]
         if n == 0:                      # an empty batch contributes no gradient
             return grads.zero_()
         record = (getattr(self, "_fwd_records", None) or {}).get(saved.data_ptr())
         if record is not None and record[1] == n:
+            if record[2] != precision and record[2] != "f32":
+                # the layouts of the three kernel families are the same TODAY; only the pairs the
+                # tests differentiate through (same mode, or an exact-f32 forward) are let through
+                raise RuntimeError("MlpProgram.backward: `saved` was filled by a %s forward; a %s backward "
+                                   "on it is not a tested pair (same mode, or an f32 forward)"
+                                   % (record[2], precision))
             # the slab and dZ formats are shared by the modes; what must match is WHERE the ReLU
             # masks of the launch's tail blocks were written (an f32 forward with a tail split keeps
             # them in a region of their own that only the f32 backward with the same split reads)

@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 
 from .mlp_engine import DenseSpec, EncodingSpec, MlpProgram
+from .sampler import _notice_once
 
 
 class _FusedChainFunction(torch.autograd.Function):
@@ -33,16 +34,26 @@ class _FusedChainFunction(torch.autograd.Function):
         # needs_input_grad stays true for parameters even under torch.no_grad()
         track = grad_mode and any(ctx.needs_input_grad[4:])
         saved = None
-        if track:
+        # (keep_activations: the slabs are written even without gradient tracking, and handed to
+        # FourierFeatureMLP.forward, which copies the last hidden layer out of them)
+        keep = bool(getattr(module, "keep_activations", False)) and positions.shape[0] > 0
+        if track or keep:
             saved = torch.empty((prog.saved_floats(positions.shape[0]),), dtype=torch.float32,
                                 device=positions.device)
         precision = module.train_precision if track else "f32"
-        if not track and module.precision == "bf16x3":
+        if keep and not track:
+            precision = module.precision
+            logits = prog.forward(positions, views, saved, precision=precision)
+            module._kept_slabs = saved
+            saved = None
+        elif not track and module.precision == "bf16x3":
             logits = prog.forward16(positions, views)       # opt-in fast inference mode
         elif not track and module.precision == "bf16x6":
             logits = prog.forward(positions, views, None, precision="bf16x6")   # opt-in, f32-accurate
         else:
             logits = prog.forward(positions, views, saved, precision=precision)
+        if keep and track:
+            module._kept_slabs = saved
         ctx.module = module
         ctx.precision = precision     # backward runs in the mode its forward ran in
         ctx.saved_acts = saved
@@ -82,7 +93,8 @@ class _FusedModel(nn.Module):
         # f32-accurate three-part split (six bf16 products per f32 product, mlp_bf16_ws.hip).
         self.precision = "f32"
         # "bf16x3" / "bf16x6": the OPT-IN split kernels for the TRAINING pass as well (forward with
-        # saved activations, backward data; bf16x6 keeps the exact-f32 weight-gradient units).
+        # saved activations, backward data, weight gradients -- bf16x6: full units on the three-part
+        # kernel, narrow units on the exact-f32 one; FFN_BF16X6_WGRAD=f32 opts out).
         # Separately labelled wherever it is reported.
         self.train_precision = "f32"
         # FFN_PRECISION=bf16x6|bf16x3 (environment, read at construction): the arithmetic mode of
@@ -91,6 +103,9 @@ class _FusedModel(nn.Module):
         mode = os.environ.get("FFN_PRECISION", "f32")
         if mode not in ("f32", "bf16x3", "bf16x6"):
             raise ValueError("FFN_PRECISION must be f32, bf16x3 or bf16x6, not %r" % mode)
+        if mode != "f32":
+            _notice_once("FFN_PRECISION=%s: every model built in this process (opacity / coarse models "
+                         "included) computes in the opt-in %s mode, not in exact f32" % (mode, mode))
         self.precision = self.train_precision = mode
 
     def _chain(self, device):   # -> (encodings, dense specs)
@@ -202,12 +217,24 @@ class FourierFeatureMLP(_FusedModel):
 
     def forward(self, inputs: torch.Tensor) -> torch.Tensor:
         """(N,3) positions -> (N,num_outputs) raw outputs."""
-        if self.keep_activations:
-            raise NotImplementedError("keep_activations is a lecture visualisation hook; it is "
-                                      "outside the HIP hot path")
         self.activations.clear()
+        self._kept_slabs = None
         out = _FusedChainFunction.apply(self, torch.is_grad_enabled(), inputs, None,
                                         *self._dense_params())
+        if self.keep_activations:
+            # fourier_feature_models.py:70-75: the output of the last hidden layer, as a numpy
+            # array on the host.  The forward pass left that layer's activation slab in HBM; this
+            # is a copy of it (MlpProgram.slab_rows), not a second evaluation.
+            hidden = len(self.layers) - 2
+            if hidden < 0:
+                raise NotImplementedError("keep_activations needs at least one hidden layer")
+            n = inputs.shape[0]
+            if n == 0:
+                rows = torch.zeros((0, self.layers[hidden].out_features))
+            else:
+                rows = self.program().slab_rows(self._kept_slabs, n, hidden)
+            self._kept_slabs = None
+            self.activations.append(rows.detach().cpu().numpy())
         return out if self.num_outputs == 4 else out[:, :self.num_outputs]
 
     def save(self, path: str):

@@ -491,7 +491,11 @@ int ffn_mlp_backward_data_bf16x3(const ffn_mlp_chain* chain, const uint16_t* pac
  * bf16(v - part 0 - .. - part p-1) (parts = 2 is ffn_mlp_pack_bf16), so every w_off of the bf16x3
  * chain scales by 3/2.  Narrow chains (<= 256 channels per layer) with fused heads; encoding
  * features are the exact-f32 kernels' (polynomial sin / cos, bit for bit).  The weight gradients of
- * this mode are the exact-f32 units (ffn_mlp_wgrad_units) on the slabs these kernels write.
+ * this mode are TWO launches over one partial buffer and one reducer table: full units (four
+ * 128 x 128 quadrants) and the logits-head units on ffn_mlp_wgrad_units_bf16x6 (three-part operands,
+ * below), units with fewer quadrants on the exact-f32 ffn_mlp_wgrad_units, which folds narrow input
+ * windows -- both read the slabs these kernels write (host: MlpProgram._plan_wgrad;
+ * FFN_BF16X6_WGRAD=f32 keeps every unit on the exact-f32 kernel).
  * FFN_BF16X6_PRODUCTS=9 (environment, measurement only) multiplies out all nine partial products.
  * Reference arithmetic being matched: fourier_feature_models.py:57-78, nerf_model.py:86-124. */
 int ffn_mlp_pack_bf16_parts(const float* src, int rows, int cols, int ld, const int32_t* col_map,

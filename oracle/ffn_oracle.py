@@ -287,6 +287,17 @@ def fourier_mlp_forward(x: torch.Tensor, a_values, b_values,
     return F.linear(h, weights[-1], biases[-1])
 
 
+def fourier_mlp_last_hidden(x: torch.Tensor, a_values, b_values,
+                            weights: Sequence[torch.Tensor],
+                            biases: Sequence[torch.Tensor]) -> torch.Tensor:
+    """What `FourierFeatureMLP.keep_activations` records: the output of the last hidden layer.
+    Restates fourier_feature_models.py:70-75."""
+    h = fourier_features(x, a_values, b_values)
+    for w, b in zip(weights[:-1], biases[:-1]):
+        h = torch.relu(F.linear(h, w, b))
+    return h
+
+
 def nerf_encode(x: torch.Tensor, enc: torch.Tensor, include_inputs: bool) -> torch.Tensor:
     """[cos(xB), sin(xB), x] with no pi factor.  Restates nerf_model.py:97-102."""
     e = x @ enc

@@ -46,8 +46,11 @@ for mode in ("weak", "strong"):
         "speedup_vs_1": None if base is None else b["value"] / base["value"],
         "efficiency_vs_1": None if base is None else b["value"] / base["value"] / n,
         "scaling": b["scaling"], "backend": col.get("backend"), "shared_gpu": col.get("shared_gpu"),
-        "all_reduce_avg_us": col.get("avg_us"), "all_reduce_max_us": col.get("max_us"),
-        "all_reduce_frac_of_step": col.get("frac_of_step"), "rank_step_ms": col.get("rank_step_ms"),
+        "all_reduce_span_incl_overlapped_sampling_avg_us": col.get("span_issue_to_wait_avg_us"),
+        "sampling_under_the_collective_avg_us": col.get("sampling_under_the_collective_avg_us"),
+        "launch_stream_waited_for_all_reduce_avg_us": col.get("launch_stream_waited_avg_us"),
+        "launch_stream_waited_for_all_reduce_max_us": col.get("launch_stream_waited_max_us"),
+        "waited_frac_of_step": col.get("waited_frac_of_step"), "rank_step_ms": col.get("rank_step_ms"),
         "placement": col.get("placement"),
         "cpu_baseline_source": (b.get("cpu_baseline") or {}).get("source"),
         "commit": b["config"].get("commit")})
@@ -58,6 +61,6 @@ out = {"what": "scaling of the headline training step: weak = RAYS (65 536) rays
 json.dump(out, open("gpurun_out/scale/scale_curve.json", "w"), indent=1)
 for mode, curve in curves.items():
   for c in curve:
-    print(mode, c["n_gpus"], "GPUs: %.0f rays/s  %.2f ms/step  efficiency %s  all-reduce %s us"
-          % (c["rays_per_s"], c["ms_per_step"], c["efficiency_vs_1"], c["all_reduce_avg_us"]))
+    print(mode, c["n_gpus"], "GPUs: %.0f rays/s  %.2f ms/step  efficiency %s  waited for the all-reduce %s us"
+          % (c["rays_per_s"], c["ms_per_step"], c["efficiency_vs_1"], c["launch_stream_waited_for_all_reduce_avg_us"]))
 PY

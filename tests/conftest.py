@@ -12,8 +12,27 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def pytest_addoption(parser):
+    # `pytest -m gpu --precision bf16x6` (or FFN_TEST_PRECISION=bf16x6): EVERY test runs with every
+    # model it builds in the opt-in arithmetic mode -- the exact mode's bodies and tolerances
+    # unchanged (FFN_PRECISION is read by the model constructors); tests marked `exact_only` state
+    # why they need the exact-f32 kernels and are skipped with that reason
+    parser.addoption("--precision", default=os.environ.get("FFN_TEST_PRECISION", "f32"),
+                     choices=["f32", "bf16x3", "bf16x6"],
+                     help="arithmetic mode of every model the tests build (default: exact f32)")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu)")
+    config.addinivalue_line("markers", "exact_only(reason): the test pins something of the exact-f32 kernels "
+                                       "themselves; skipped under --precision bf16x6 / bf16x3")
+    mode = config.getoption("--precision")
+    if mode != "f32":
+        os.environ["FFN_PRECISION"] = mode
+
+
+def pytest_report_header(config):
+    return "arithmetic mode of the models under test: %s" % config.getoption("--precision")
 
 
 def pytest_collection_modifyitems(config, items):
@@ -22,6 +41,13 @@ def pytest_collection_modifyitems(config, items):
         have_gpu = torch.cuda.is_available()
     except Exception:  # pragma: no cover
         have_gpu = False
+    mode = config.getoption("--precision")
+    if mode != "f32":
+        for item in items:
+            marker = item.get_closest_marker("exact_only")
+            if marker is not None:
+                why = marker.kwargs.get("reason") or (marker.args[0] if marker.args else "pins the exact-f32 kernels")
+                item.add_marker(pytest.mark.skip(reason="--precision %s: %s" % (mode, why)))
     if have_gpu:
         return
     skip = pytest.mark.skip(reason="no GPU visible")
