@@ -186,6 +186,8 @@ class TrainEngine:
         if count == 0:
             self.reduce_buf.zero_()
         precision = getattr(self.model, "train_precision", "f32")
+        if hasattr(self.model, "effective_precision"):
+            precision = self.model.effective_precision(precision)
         for lo in range(0, count, per_launch):
             chunk = rays[lo:lo + per_launch]
             first = lo == 0
@@ -326,6 +328,8 @@ class TrainEngine:
         t, pos, views = self._samples(sampler, rays, step)
         # (a forward-only pass: the model's INFERENCE arithmetic, like a no-grad model call)
         mode = getattr(self.model, "precision", "f32")
+        if hasattr(self.model, "effective_precision"):
+            mode = self.model.effective_precision(mode)
         prog = self.model.program()
         logits = prog.forward16(pos, views) if mode == "bf16x3" else prog.forward(pos, views, None, precision=mode)
         color, alpha, _ = ops.composite_fwd(logits, t, False, self.nan_flag)
@@ -422,10 +426,15 @@ class Raycaster(nn.Module):
         self.check_finite()
         return out
 
+    @staticmethod
+    def _inference_mode(model) -> str:
+        mode = getattr(model, "precision", "f32")
+        return model.effective_precision(mode) if hasattr(model, "effective_precision") else mode
+
     def _can_fuse(self, sampler: RaySampler) -> bool:
         model = self.model
         if not (self.fused_render and hasattr(model, "program") and sampler.num_samples <= 256
-                and getattr(model, "precision", "f32") == "f32"):
+                and self._inference_mode(model) == "f32"):
             return False
         # 512-wide chains: the pair-of-waves variant equals the three-pass rate without a grid
         # (1.33 vs 1.35 frames/s at 800x800x128) but loses to the globally compacted K9 path

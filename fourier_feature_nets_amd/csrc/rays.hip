@@ -113,9 +113,18 @@ materialise_kernel(const float* __restrict__ starts, const float* __restrict__ d
 
 // ---------------------------------------------------------------------------------- K2a + K2b
 // sample_t_kernel and materialise_kernel in ONE launch (samplers without an opacity model, where
-// nothing merges into t between the two): a thread per (ray, sample) computes t with the K2a
-// operations, then the sample's position and view direction with the K2b operations -- the same
-// bits as the two launches (this file is compiled without FMA contraction).
+// nothing merges into t between the two): t with the K2a operations, then the sample's position
+// and view direction with the K2b operations -- the same bits as the two launches (this file is
+// compiled without FMA contraction).
+// A pure 28 S B / ray output stream, so the kernel is shaped by its STORES (round 6; one thread per
+// (ray, sample) with three 4-byte stores at a 12-byte lane stride per array moved 2.6 TB/s): a
+// workgroup owns 1024 consecutive samples = 4 KiB of t, 12 KiB of positions, 12 KiB of views, all
+// three 16-byte aligned; a thread computes the t-values of ITS four samples (one float4 store) and
+// leaves them with their ray ids in LDS; then every thread writes three float4 of positions and
+// three of views -- lane i the bytes 16 i .. 16 i + 15 of a 4 KiB run, whole cache lines per wave --
+// from the LDS copy and the (L1-resident) ray state.
+constexpr int kSmChunk = 1024;
+
 __global__ void __launch_bounds__(256)
 sample_materialise_kernel(const float* __restrict__ near_far, int64_t total_rays,
                           const float* __restrict__ starts, const float* __restrict__ dirs,
@@ -123,31 +132,79 @@ sample_materialise_kernel(const float* __restrict__ near_far, int64_t total_rays
                           const float* __restrict__ unit, const float* __restrict__ noise, float anneal,
                           float* __restrict__ t_out, float* __restrict__ positions,
                           float* __restrict__ views) {
+    __shared__ float t_s[kSmChunk];
+    __shared__ int64_t ray_s[kSmChunk];
     const int64_t n = (int64_t)num_rays * count;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n;
-         e += (int64_t)gridDim.x * blockDim.x) {
-        const int r = (int)(e / count);
-        const int s = (int)(e - (int64_t)r * count);
-        const int64_t ray = ray_index[r];
-        float near = near_far[ray];
-        float far = near_far[total_rays + ray];
-        if (anneal >= 0.0f) {
-            const float mid = (near + far) * 0.5f;
-            near = mid + (near - mid) * anneal;
-            far = mid + (far - mid) * anneal;
-        }
-        const float span = far - near;
-        float t = near + unit[s] * span;
-        if (noise != nullptr) {
-            const float scale = span / (float)count;
-            t = t + noise[e] * scale;
-        }
-        t_out[e] = t;
+    const int64_t e0 = (int64_t)blockIdx.x * kSmChunk;
+    const int live = (int)(n - e0 < kSmChunk ? n - e0 : kSmChunk);       // samples of this chunk
+    const int64_t r0 = e0 / count;                                       // (uniform)
+    const unsigned rem0 = (unsigned)(e0 - r0 * count);
+    float4 tq;
+    float* tv = reinterpret_cast<float*>(&tq);
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
+    for (int j = 0; j < 4; ++j) {
+        const int li = 4 * (int)threadIdx.x + j;
+        float t = 0.0f;
+        int64_t ray = 0;
+        if (li < live) {
+            const unsigned q = (rem0 + (unsigned)li) / (unsigned)count;
+            const int s = (int)(rem0 + (unsigned)li - q * (unsigned)count);
+            ray = ray_index[r0 + q];
+            float near = near_far[ray];
+            float far = near_far[total_rays + ray];
+            if (anneal >= 0.0f) {
+                const float mid = (near + far) * 0.5f;
+                near = mid + (near - mid) * anneal;
+                far = mid + (far - mid) * anneal;
+            }
+            const float span = far - near;
+            t = near + unit[s] * span;
+            if (noise != nullptr) {
+                const float scale = span / (float)count;
+                t = t + noise[e0 + li] * scale;
+            }
+        }
+        tv[j] = t;
+        t_s[li] = t;
+        ray_s[li] = ray;
+    }
+    if (4 * (int)threadIdx.x + 3 < live) {
+        reinterpret_cast<float4*>(t_out + e0)[threadIdx.x] = tq;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (4 * (int)threadIdx.x + j < live) t_out[e0 + 4 * threadIdx.x + j] = tv[j];
+    }
+    __syncthreads();
+    float* pos_chunk = positions + e0 * 3;
+    float* view_chunk = views == nullptr ? nullptr : views + e0 * 3;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int j0 = 4 * (q * 256 + (int)threadIdx.x);         // first float of this thread's float4
+        if (j0 >= 3 * live) continue;
+        float4 pq, vq;
+        float* pv = reinterpret_cast<float*>(&pq);
+        float* vv = reinterpret_cast<float*>(&vq);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int el = j0 + i;
+            const int smp = el < 3 * live ? el / 3 : live - 1;
+            const int d = el - 3 * (el / 3);
+            const int64_t ray = ray_s[smp];
             const float dir = dirs[ray * 3 + d];
-            positions[e * 3 + d] = starts[ray * 3 + d] + t * dir;
-            if (views != nullptr) views[e * 3 + d] = dir;
+            pv[i] = starts[ray * 3 + d] + t_s[smp] * dir;
+            vv[i] = dir;
+        }
+        if (j0 + 3 < 3 * live) {
+            reinterpret_cast<float4*>(pos_chunk)[q * 256 + threadIdx.x] = pq;
+            if (view_chunk != nullptr) reinterpret_cast<float4*>(view_chunk)[q * 256 + threadIdx.x] = vq;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (j0 + i < 3 * live) {
+                    pos_chunk[j0 + i] = pv[i];
+                    if (view_chunk != nullptr) view_chunk[j0 + i] = vv[i];
+                }
         }
     }
 }
@@ -233,7 +290,8 @@ extern "C" int ffn_sample_materialise(const float* near_far, int64_t num_rays_to
                                       float* t_out, float* positions, float* views, void* stream) {
     if (num_rays == 0) return 0;
     if (num_rays < 0 || count <= 0) return fail_arg("ffn_sample_materialise: shape");
-    hipLaunchKernelGGL(sample_materialise_kernel, dim3(grid_for((int64_t)num_rays * count)), dim3(256), 0,
+    const int64_t chunks = ((int64_t)num_rays * count + kSmChunk - 1) / kSmChunk;
+    hipLaunchKernelGGL(sample_materialise_kernel, dim3((unsigned)chunks), dim3(256), 0,
                        (hipStream_t)stream, near_far, num_rays_total, starts, directions, ray_index,
                        num_rays, count, unit, noise, anneal, t_out, positions, views);
     return check_launch("ffn_sample_materialise");

@@ -851,6 +851,15 @@ class MlpProgram:
         else:
             self._packed_x6_dirty = False
 
+    def covers(self, precision: str) -> bool:
+        """Whether the opt-in arithmetic mode has kernels for this chain ("f32": always).  bf16x6:
+        chains of <= 256 channels per layer whose logits heads are fused; bf16x3: fused heads."""
+        if precision == "bf16x6":
+            return self.fwd_x6 is not None
+        if precision == "bf16x3":
+            return self.fwd16 is not None
+        return precision == "f32"
+
     def _x6_ready(self):
         if self.fwd_x6 is None:
             raise NotImplementedError("the bf16x6 kernels cover chains of <= 256 channels per layer "

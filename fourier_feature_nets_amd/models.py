@@ -40,15 +40,16 @@ class _FusedChainFunction(torch.autograd.Function):
         if track or keep:
             saved = torch.empty((prog.saved_floats(positions.shape[0]),), dtype=torch.float32,
                                 device=positions.device)
-        precision = module.train_precision if track else "f32"
+        precision = module.effective_precision(module.train_precision) if track else "f32"
+        infer_mode = module.effective_precision(module.precision)
         if keep and not track:
-            precision = module.precision
+            precision = infer_mode
             logits = prog.forward(positions, views, saved, precision=precision)
             module._kept_slabs = saved
             saved = None
-        elif not track and module.precision == "bf16x3":
+        elif not track and infer_mode == "bf16x3":
             logits = prog.forward16(positions, views)       # opt-in fast inference mode
-        elif not track and module.precision == "bf16x6":
+        elif not track and infer_mode == "bf16x6":
             logits = prog.forward(positions, views, None, precision="bf16x6")   # opt-in, f32-accurate
         else:
             logits = prog.forward(positions, views, saved, precision=precision)
@@ -105,8 +106,22 @@ class _FusedModel(nn.Module):
             raise ValueError("FFN_PRECISION must be f32, bf16x3 or bf16x6, not %r" % mode)
         if mode != "f32":
             _notice_once("FFN_PRECISION=%s: every model built in this process (opacity / coarse models "
-                         "included) computes in the opt-in %s mode, not in exact f32" % (mode, mode))
+                         "included) computes in the opt-in %s mode wherever that mode has kernels for its "
+                         "chain, in exact f32 elsewhere" % (mode, mode))
         self.precision = self.train_precision = mode
+        # A mode that came from the ENVIRONMENT is a process-wide default: a chain it does not cover
+        # (bf16x6: layers wider than 256 channels) runs the exact-f32 kernels, with a notice.  A mode
+        # assigned to the attributes by hand is a request: a chain it does not cover raises.
+        self._precision_is_default = mode != "f32"
+
+    def effective_precision(self, mode: str) -> str:
+        """The arithmetic a call in ``mode`` runs in (see ``_precision_is_default``)."""
+        if mode == "f32" or not self._precision_is_default or self.program().covers(mode):
+            return mode
+        _notice_once("%s: no %s kernels for this chain (%s) -- it runs in exact f32"
+                     % (type(self).__name__, mode,
+                        "layers wider than 256 channels" if mode == "bf16x6" else "unfused logits heads"))
+        return "f32"
 
     def _chain(self, device):   # -> (encodings, dense specs)
         raise NotImplementedError

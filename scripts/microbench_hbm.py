@@ -49,6 +49,26 @@ def main():
     index = torch.randint(0, 4 * R, (R,), device=dev)
     sec = timed(lambda: ops.composite_train(logits, t, gt_colors, gt_alphas, index, 1.0 / (3 * R), 0.1 / R))
     out["composite_train (K5 + K6 + K5b in one launch)"] = (R * (20 * S + 16 * S + 8 + 16), sec)
+    # K2a + K2b in one launch (samplers without an opacity model): t, positions, view directions of a
+    # batch -- 28 S B / ray written; read: ray id 8 B + near / far 8 B + start and direction 24 B per
+    # ray (+ 4 S B of jitter when stratified)
+    from fourier_feature_nets_amd._lib import c_f, c_i, c_i64
+    from fourier_feature_nets_amd.ops import _call, _dev
+    total = 4 * R
+    near_far = torch.stack([torch.full((total,), 3.0, device=dev), torch.full((total,), 5.0, device=dev)]).contiguous()
+    starts = torch.randn(total, 3, device=dev)
+    dirs = torch.nn.functional.normalize(torch.randn(total, 3, device=dev), dim=1)
+    ray_index = torch.randint(0, total, (R,), device=dev)
+    unit = torch.linspace(0, 1, S, device=dev)
+    noise = torch.rand(R, S, device=dev)
+    t_out = torch.empty(R, S, device=dev)
+    pos_out = torch.empty(R, S, 3, device=dev)
+    view_out = torch.empty(R, S, 3, device=dev)
+    for label, jitter in (("uniform", None), ("stratified", noise)):
+        sec = timed(lambda: _call("ffn_sample_materialise", _dev(near_far), c_i64(total), _dev(starts), _dev(dirs),
+                                  _dev(ray_index, torch.int64, "ray_index"), c_i(R), c_i(S), _dev(unit),
+                                  _dev(jitter), c_f(-1.0), _dev(t_out), _dev(pos_out), _dev(view_out)))
+        out["sample_materialise (K2a + K2b, %s)" % label] = (R * (28 * S + 40 + (4 * S if jitter is not None else 0)), sec)
     n = R * S
     x = torch.rand(n, 3, device=dev) * 2 - 1
     b = ffn.PositionalFourierMLP(3, 4, 5.5).b_values.data.clone().contiguous().to(dev)

@@ -205,12 +205,19 @@ EXACT_MODE_TESTS = (
      _case(test_config3_fit_against_the_references_own_fit)])
 
 
+# cases whose model has a hidden layer of 256 channels reading 256 channels: a FULL weight-gradient
+# unit (four 128 x 128 quadrants), the kind the three-part weight-gradient kernel takes
+WGRAD_X6_EXPECTED = {(tk.test_fused_mlp_backward_against_golden, "positional"),
+                     (tk.test_fused_nerf_forward_backward_against_golden, "nerf")}
+
+
 @pytest.mark.parametrize("fn,kwargs", EXACT_MODE_TESTS)
 def test_exact_mode_tests_in_the_f32_accurate_split_mode(fn, kwargs, golden, tmp_path, monkeypatch):
     """The reference-golden / oracle tests of the EXACT mode, unchanged -- same bodies, same
     tolerances -- with every model they build in the opt-in bf16x6 mode (FFN_PRECISION is read by
-    the model constructors: inference calls, the training forward and backward data run the
-    three-part split kernels; weight gradients the exact-f32 units)."""
+    the model constructors: inference calls, the training forward, backward data AND the weight
+    gradients of every full unit run the three-part split kernels; units with fewer than four
+    quadrants the exact-f32 kernel that folds them)."""
     import fourier_feature_nets_amd as ffn
     monkeypatch.setenv("FFN_PRECISION", "bf16x6")
     probe = ffn.MLP(3, 4)
@@ -234,6 +241,9 @@ def test_exact_mode_tests_in_the_f32_accurate_split_mode(fn, kwargs, golden, tmp
     used = {n for n in seen if n.startswith("ffn_mlp_")}
     if fn is not tk.test_fused_mlp_empty_batch:
         assert used & {"ffn_mlp_forward_bf16x6", "ffn_mlp_forward_bf16x6_train"}, sorted(used)
+    # a backward pass through a chain with a full 256 x 256 unit ran the three-part weight gradients
+    if (fn, kwargs.get("name")) in WGRAD_X6_EXPECTED:
+        assert "ffn_mlp_wgrad_units_bf16x6" in used, sorted(used)
     # no exact-f32 (or bf16x3) chain kernel ran behind the test's back
     assert not used & {"ffn_mlp_forward", "ffn_mlp_backward_data", "ffn_mlp_forward_bf16x3",
                        "ffn_mlp_forward_bf16x3_train", "ffn_mlp_backward_data_bf16x3",
@@ -343,10 +353,12 @@ def test_bf16x6_batch_independence_and_ragged_sizes(golden):
             assert torch.equal(model(x[lo:lo + 777]), whole[lo:lo + 777]), lo
 
 
-def test_bf16x6_refuses_what_it_does_not_cover(golden):
-    """512-wide chains have no three-part kernels (their X image does not fit the LDS): the mode
-    raises for them, it does not fall back to another arithmetic."""
+def test_bf16x6_refuses_what_it_does_not_cover(golden, monkeypatch):
+    """512-wide chains have no three-part kernels (their X image does not fit the LDS): a mode
+    REQUESTED for such a model (assigned to its attributes) raises, it does not fall back to another
+    arithmetic.  (Only the environment-wide default does: next test.)"""
     from tests.test_kernels_gpu import _load_fourier
+    monkeypatch.delenv("FFN_PRECISION", raising=False)
     model, _ = _load_fourier(golden("models"), "gaussian512")
     x = torch.rand(100, 3, device=dev())
     model.precision = "bf16x6"
@@ -356,6 +368,34 @@ def test_bf16x6_refuses_what_it_does_not_cover(golden):
     model.train_precision = "bf16x6"
     with pytest.raises(NotImplementedError):
         model(x)
+
+
+def test_bf16x6_as_the_process_default_runs_uncovered_chains_in_exact_f32(golden, monkeypatch):
+    """`FFN_PRECISION=bf16x6` (the environment-wide default, what `pytest --precision bf16x6` sets) is
+    "the mode wherever it has kernels": a 512-wide chain built under it runs the EXACT-f32 kernels
+    -- logits bit-identical to an exact-mode model -- while a 256-wide one runs the three-part ones."""
+    from fourier_feature_nets_amd import _lib
+    from tests.test_kernels_gpu import _load_fourier
+    exact, _ = _load_fourier(golden("models"), "gaussian512")
+    exact.precision = exact.train_precision = "f32"
+    exact._precision_is_default = False
+    monkeypatch.setenv("FFN_PRECISION", "bf16x6")
+    wide, _ = _load_fourier(golden("models"), "gaussian512")
+    narrow, _ = _load_fourier(golden("models"), "gaussian")
+    assert wide.precision == narrow.precision == "bf16x6" and wide._precision_is_default
+    seen = []
+    real = _lib.call
+    monkeypatch.setattr(_lib, "call", lambda name, *a: (seen.append(name), real(name, *a))[1])
+    x = torch.rand(100, 3, device=dev())
+    with torch.no_grad():
+        assert torch.equal(wide(x), exact(x))
+    assert "ffn_mlp_forward" in seen and not any("bf16x6" in n for n in seen)
+    wide(x).square().sum().backward()          # the training pass falls back the same way
+    assert not any("bf16x6" in n for n in seen)
+    del seen[:]
+    with torch.no_grad():
+        narrow(x)
+    assert "ffn_mlp_forward_bf16x6" in seen
 
 
 # ----------------------------------------------------------------------------------- look-ahead sampling
