@@ -35,7 +35,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-TRAFFIC_PROFILE = "profiles/r05_hbm_traffic.json"
+TRAFFIC_PROFILE = "profiles/r06_hbm_traffic.json"
 
 KERNEL_OF = {"ffn_mlp_forward": "mlp_forward_kernel<train>",
              "ffn_mlp_backward_data": "mlp_backward_data_kernel",
@@ -379,10 +379,10 @@ def traffic_of(kernel_name, args):
               "in separate passes over this bench.py; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
               "(gfx950 FETCH_SIZE correction, MI355X_MICROARCH.md section HBM)"}
     if not os.path.exists(path):
-        fallback = os.path.join(ROOT, "profiles", "r04_hbm_traffic.json")
+        fallback = os.path.join(ROOT, "profiles", "r05_hbm_traffic.json")
         if not os.path.exists(fallback):
             return None, None
-        path, source["file"] = fallback, "profiles/r04_hbm_traffic.json"
+        path, source["file"] = fallback, "profiles/r05_hbm_traffic.json"
     with open(path) as f:
         doc = json.load(f)
     source["profiled_commit"] = doc.get("commit")

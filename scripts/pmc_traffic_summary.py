@@ -1,4 +1,4 @@
-"""Folds the FETCH_SIZE / WRITE_SIZE passes of scripts/gpu/profile_round2.sh into profiles/*.json:
+"""Folds the FETCH_SIZE / WRITE_SIZE passes of scripts/gpu/profile.sh into profiles/*.json:
 
     python scripts/pmc_traffic_summary.py gpurun_out/traffic profiles/r02_hbm_traffic.json [commit]
 
@@ -44,7 +44,7 @@ def main(src, out, commit=None, rays=65536, samples=64, command=None):
     command = command or ("python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-target-shape "
                           "--no-config3 --no-config5 --no-skip-leg --no-bf16-leg")
     doc = {"note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on "
-                   "`" + command + "` (scripts/gpu/profile_round3.sh), MI355X; "
+                   "`" + command + "` (scripts/gpu/profile.sh), MI355X; "
                    "KB per launch averaged over launches; hbm_bytes = (2*FETCH_SIZE + "
                    "WRITE_SIZE)*1024 (gfx950: FETCH_SIZE counts 128-B requests as 64 B for wide "
                    "streaming reads, MI355X_MICROARCH.md section HBM)",

@@ -15,20 +15,27 @@ tests/psnr_parity.py written in the reference's NPZ schema; seed k fixes the ini
     python -m tests.psnr_ensemble hip --reference tests/golden/psnr_ensemble_reference.json \\
         --out profiles/r04_psnr_ensemble.json
 
-Round-5 fixtures (reference halves, build container; HIP halves: scripts/gpu/r5_ensembles.sh,
-r5_nerf_fine.sh):
+Fixtures of rounds 5 and 6 (reference halves, build container; HIP halves: scripts/gpu/ensembles.sh):
 
     # slower-diverging protocol, 24 seeds (28 min per seed on 3 threads; the committed file was
     # computed by four such processes over disjoint seed ranges: tests/golden/merge_ensemble_parts.py)
     python -m tests.psnr_ensemble reference --rays 4096 --lr 1e-4 --steps 500 --crop-steps 125 \
         --report-interval 125 --anneal-steps 250 --threads 3 --seeds 24 \
         --out tests/golden/psnr_ensemble_reference_slow.json
-    # config 3: full NeRF + a frozen voxel opacity model, 6 seeds x 300 steps inside the crop phase
+    # config 3: full NeRF + a frozen voxel opacity model, 300 steps inside the crop phase (round 5: 6
+    # seeds; round 6 continued the same file with --resume --seeds 24 for as many seeds as the round's
+    # CPU-hours gave, `complete: false` says how many of the planned 24 it holds)
     python -m tests.psnr_ensemble reference --model nerf --opacity voxels --size 128 --cameras 20 \
         --val-cameras 4 --samples 128 --rays 1024 --steps 300 --crop-steps 1000 --report-interval 100 \
         --anneal-steps 150 --threads 4 --seeds 6 --out tests/golden/psnr_ensemble_reference_nerf.json
     # ... its first seed with --threads 2 --seeds 1 -> psnr_ensemble_reference_nerf_2threads.json
     # ... with --steps 100 --report-interval 10 --seeds 2 -> psnr_ensemble_reference_nerf_fine.json
+    # config 3, slow-diverging (round 6): 4096 rays, lr 1e-4, 300 steps, a report every 25 (~2 h per
+    # seed on 3 threads of a busy 8-core container)
+    python -m tests.psnr_ensemble reference --model nerf --opacity voxels --size 128 --cameras 20 \
+        --val-cameras 4 --samples 128 --rays 4096 --lr 1e-4 --steps 300 --crop-steps 1000 \
+        --report-interval 25 --anneal-steps 150 --threads 3 --seeds 8 --resume \
+        --out tests/golden/psnr_ensemble_reference_nerf_slow.json
 
 Only the per-seed PSNR curves (numbers) are committed as the fixture; the reference never
 travels.  Verdict: |mean_hip - mean_ref| of the final validation PSNR < 0.05 dB, or < 2 standard
