@@ -377,6 +377,7 @@ extern "C" int ffn_mlp_forward_bf16x3_train(const ffn_mlp_chain* chain, const ui
                                             const float* bias, const float* positions, const float* views,
                                             int64_t n, float* logits, float* saved, uint32_t* masks,
                                             void* stream) {
+    if (n == 0) return 0;          // (an empty batch has empty slabs: nothing to write, no pointers to check)
     if (saved == nullptr || masks == nullptr) return fail_arg("ffn_mlp_forward_bf16x3_train: saved and masks are required");
     return launch_forward16("ffn_mlp_forward_bf16x3_train: unsupported chain or size", chain, packed_w, bias,
                             positions, views, n, logits, saved, masks, stream);

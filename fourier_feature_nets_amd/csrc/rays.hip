@@ -290,6 +290,9 @@ extern "C" int ffn_sample_materialise(const float* near_far, int64_t num_rays_to
                                       float* t_out, float* positions, float* views, void* stream) {
     if (num_rays == 0) return 0;
     if (num_rays < 0 || count <= 0) return fail_arg("ffn_sample_materialise: shape");
+    // (the kernel stores whole float4: every chunk of 1024 samples starts 16-byte aligned in all three outputs)
+    if ((((uintptr_t)t_out) | ((uintptr_t)positions) | ((uintptr_t)views)) & 15)
+        return fail_arg("ffn_sample_materialise: t_out, positions and views must be 16-byte aligned");
     const int64_t chunks = ((int64_t)num_rays * count + kSmChunk - 1) / kSmChunk;
     hipLaunchKernelGGL(sample_materialise_kernel, dim3((unsigned)chunks), dim3(256), 0,
                        (hipStream_t)stream, near_far, num_rays_total, starts, directions, ray_index,

@@ -78,7 +78,9 @@ int ffn_materialise_samples(const float* starts, const float* directions,
 /* K2a + K2b in one launch (ray_sampler.py:372-397 for a sampler WITHOUT an opacity model, where
  * nothing merges into t between the two): the arguments of ffn_sample_t with t_stride == count,
  * plus the ray starts / directions; t_out (R,count), positions / views (R,count,3), views may be
- * NULL.  Bit-identical to ffn_sample_t followed by ffn_materialise_samples. */
+ * NULL.  Bit-identical to ffn_sample_t followed by ffn_materialise_samples.  The three outputs
+ * must be 16-byte aligned (the kernel stores whole float4 lines of 1024-sample chunks); a pointer
+ * that is not is refused with an error, never written through. */
 int ffn_sample_materialise(const float* near_far, int64_t num_rays_total, const float* starts,
                            const float* directions, const int64_t* ray_index, int num_rays,
                            int count, const float* unit, const float* noise, float anneal,

@@ -13,6 +13,8 @@ S=$(date +%s); timeout 1500 python -m pytest tests -m gpu -q > $OUT/tests.log 2>
 grep -n "passed\|failed\|^FAILED\|^ERROR" $OUT/tests.log | tail -12
 S=$(date +%s); timeout 1500 python -m pytest tests -m gpu -q --precision bf16x6 -rs > $OUT/tests_bf16x6.log 2>&1; echo "tests --precision bf16x6 rc=$? $(( $(date +%s) - S ))s"
 grep -n "passed\|failed\|^FAILED\|^ERROR\|^SKIPPED" $OUT/tests_bf16x6.log | cut -c1-200 | tail -16
+S=$(date +%s); timeout 1500 python -m pytest tests -m gpu -q --precision bf16x3 -rs > $OUT/tests_bf16x3.log 2>&1; echo "tests --precision bf16x3 (NOT an f32-accurate mode: tolerance failures expected) rc=$? $(( $(date +%s) - S ))s"
+grep -n "passed\|failed" $OUT/tests_bf16x3.log | tail -2
 B="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-target-shape --no-config3 --no-config5 --no-skip-leg --no-bf16-leg --no-render"
 M="python scripts/microbench_train_kernels.py --iters 3 --modes f32,bf16x3,bf16x6"
 rocprofv3 --kernel-trace --stats -d $OUT -o stats --output-format csv -- $B > $OUT/stats.log 2>&1

@@ -24,8 +24,8 @@ def pytest_addoption(parser):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu)")
-    config.addinivalue_line("markers", "exact_only(reason): the test pins something of the exact-f32 kernels "
-                                       "themselves; skipped under --precision bf16x6 / bf16x3")
+    config.addinivalue_line("markers", "exact_only(reason, modes=...): the test pins something of the exact-f32 kernels "
+                                       "themselves; skipped under --precision bf16x6 / bf16x3 (or only in `modes`)")
     mode = config.getoption("--precision")
     if mode != "f32":
         os.environ["FFN_PRECISION"] = mode
@@ -45,7 +45,9 @@ def pytest_collection_modifyitems(config, items):
     if mode != "f32":
         for item in items:
             marker = item.get_closest_marker("exact_only")
-            if marker is not None:
+            # (`modes=(...)`: only in those opt-in modes -- a 512-wide model falls back to exact f32 under
+            # bf16x6, which has no kernels for it, but computes in bf16x3, which does)
+            if marker is not None and mode in marker.kwargs.get("modes", (mode,)):
                 why = marker.kwargs.get("reason") or (marker.args[0] if marker.args else "pins the exact-f32 kernels")
                 item.add_marker(pytest.mark.skip(reason="--precision %s: %s" % (mode, why)))
     if have_gpu:

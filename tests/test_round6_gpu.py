@@ -1,5 +1,7 @@
 """Round-6 GPU tests (MI355X, all through the C ABI): `FourierFeatureMLP.keep_activations` served
-from the activation slab (fourier_feature_models.py:70-75), ...
+from the activation slab (fourier_feature_models.py:70-75); the one-launch sampling kernel (K2a + K2b,
+ray_sampler.py:359-403) in its round-6 form -- 1024-sample chunks, aligned float4 stores -- against the
+two launches at chunk edges.
 
 Tolerances: the hidden activations are what the logits tests hold the chain to -- 3e-5 of their
 scale (1e-4 for the dense Gaussian B matrix, as in tests/test_kernels_gpu.py)."""
@@ -79,3 +81,34 @@ def test_keep_activations_on_a_padded_width_and_an_empty_batch():
     with torch.no_grad():
         model(x[:0])
     assert model.activations[0].shape == (0, 96)
+
+
+# ----------------------------------------------------------------------------------- K2: chunk edges of the one-launch sampler
+@pytest.mark.parametrize("rays,samples", [(1, 1), (1, 3), (5, 2), (7, 64), (16, 64), (17, 64), (1023, 1), (1024, 1),
+                                          (1025, 1), (341, 3), (342, 3), (100, 100), (33, 128), (9, 257)])
+@pytest.mark.parametrize("stratified", [False, True])
+def test_one_launch_sampling_equals_the_two_launches_at_chunk_edges(rays, samples, stratified):
+    """`ffn_sample_materialise` works on chunks of 1024 consecutive (ray, sample) elements -- one float4 of
+    t per thread, three float4 of positions / views per thread from an LDS copy -- so its edges are the
+    sample counts that do not divide 1024, a last chunk of any fill, rays that straddle chunks and
+    tails that are not a multiple of four: t-values, positions and view directions BIT-identical to
+    `ffn_sample_t` + `ffn_materialise_samples` (which the reference goldens pin), with and without
+    jitter, annealing and the view output."""
+    from fourier_feature_nets_amd import ops
+    gen = torch.Generator(device=dev()).manual_seed(rays * 1000 + samples)
+    total = 4 * rays + 3
+    near = torch.rand(total, device=dev(), generator=gen) * 2 + 1
+    near_far = torch.stack([near, near + torch.rand(total, device=dev(), generator=gen) * 3 + 0.1]).contiguous()
+    starts = torch.randn(total, 3, device=dev(), generator=gen)
+    dirs = torch.nn.functional.normalize(torch.randn(total, 3, device=dev(), generator=gen), dim=1)
+    idx = torch.randint(0, total, (rays,), device=dev(), generator=gen)
+    unit = torch.linspace(0, 1, samples).to(dev())
+    noise = torch.rand(rays, samples, device=dev(), generator=gen) if stratified else None
+    for anneal in (None, 0.35):
+        t = ops.sample_t(near_far, idx, samples, unit, noise, anneal)
+        pos, views = ops.materialise_samples(starts, dirs, idx, t)
+        t1, pos1, views1 = ops.sample_materialise(near_far, starts, dirs, idx, samples, unit, noise, anneal)
+        assert torch.equal(t1, t) and torch.equal(pos1, pos) and torch.equal(views1, views)
+        # without the view output
+        t2, pos2, none = ops.sample_materialise(near_far, starts, dirs, idx, samples, unit, noise, anneal, want_views=False)
+        assert none is None and torch.equal(t2, t) and torch.equal(pos2, pos)
