@@ -33,6 +33,7 @@ SOURCES = {
     # (two waves per SIMD: packed-f32 VALU instructions collide with the other wave's matrix
     # instructions -- keep the compiler from re-packing the unpacked feature / split arithmetic)
     "mlp_bf16_ws.hip": ["-fno-slp-vectorize"],
+    "mlp_bf16_mv.hip": ["-fno-slp-vectorize"],
     "wgrad.hip": [],
     "wgrad_bf16.hip": [],
     "wgrad_bf16x6.hip": [],

@@ -210,6 +210,76 @@ __device__ __forceinline__ void features16_unpacked(const Enc16& enc, int G, int
     }
 }
 
+// features16_unpacked with the four angles walked LEVEL BY LEVEL (the same operations in the same order per
+// angle: identical bits): four independent dependency chains in flight instead of one after the other.  A
+// wave that is alone with its vector work (the vector waves of mlp_bf16_mv.hip) issues a lone dependent
+// chain every ~8.5 cycles, independent instructions every ~5.
+template <bool TRIG_ONLY>
+__device__ __forceinline__ void features16_lockstep(const Enc16& enc, int G, int h, float x0, float x1,
+                                                    float x2, float (&v)[8]) {
+    const int k0 = 8 * G + 4 * h;
+    const int kk = k0 < kEncRowPitch - 4 ? k0 : kEncRowPitch - 4;
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(enc.tab + kk);
+    const f32x4 b1 = *reinterpret_cast<const f32x4*>(enc.tab + kEncRowPitch + kk);
+    const f32x4 b2 = *reinterpret_cast<const f32x4*>(enc.tab + 2 * kEncRowPitch + kk);
+    const f32x4 amp = *reinterpret_cast<const f32x4*>(enc.tab + 3 * kEncRowPitch + kk);
+    const float s0 = enc.scale * x0, s1 = enc.scale * x1, s2 = enc.scale * x2;
+    float ang[4], k[4], r[4], z[4], sp[4], cp[4], hf[4], sn[4], cs[4];
+#define FFN_L4 _Pragma("unroll") for (int i = 0; i < 4; ++i)
+    FFN_L4 ang[i] = b0[i] * s0;                     // same operation order as the f32 kernel
+    FFN_L4 ang[i] = __builtin_fmaf(s1, b1[i], ang[i]);
+    FFN_L4 ang[i] = __builtin_fmaf(s2, b2[i], ang[i]);
+    FFN_L4 k[i] = __builtin_rintf(ang[i] * 0.6366197466850281f);      // fast_sincos, level by level
+    FFN_L4 r[i] = __builtin_fmaf(-k[i], 1.5707963705062866f, ang[i]);
+    FFN_L4 r[i] = __builtin_fmaf(-k[i], -4.371138828673793e-08f, r[i]);
+    FFN_L4 r[i] = __builtin_fmaf(-k[i], -1.7151245100058819e-15f, r[i]);
+    FFN_L4 z[i] = r[i] * r[i];
+    FFN_L4 sp[i] = __builtin_fmaf(-1.9515295891e-4f, z[i], 8.3321608736e-3f);
+    FFN_L4 cp[i] = __builtin_fmaf(2.443315711809948e-5f, z[i], -1.388731625493765e-3f);
+    FFN_L4 sp[i] = __builtin_fmaf(sp[i], z[i], -1.6666654611e-1f);
+    FFN_L4 cp[i] = __builtin_fmaf(cp[i], z[i], 4.166664568298827e-2f);
+    FFN_L4 hf[i] = __builtin_fmaf(-0.5f, z[i], 1.0f);
+    FFN_L4 sp[i] = __builtin_fmaf(sp[i] * z[i], r[i], r[i]);
+    FFN_L4 cp[i] = __builtin_fmaf(cp[i] * z[i], z[i], hf[i]);
+    FFN_L4 {
+        const int q = (int)k[i];
+        const bool swap = (q & 1) != 0;
+        const float s_0 = swap ? cp[i] : sp[i];
+        const float c_0 = swap ? sp[i] : cp[i];
+        sn[i] = (q & 2) ? -s_0 : s_0;
+        cs[i] = ((q + 1) & 2) ? -c_0 : c_0;
+    }
+    FFN_L4 {
+        const float c = amp[i] * cs[i], s = amp[i] * sn[i];
+        if (TRIG_ONLY) {
+            v[2 * i] = c;
+            v[2 * i + 1] = s;
+        } else {
+            const int kf = k0 + i;
+            const int off = 2 * (kf - enc.F);
+            const float raw_even = (enc.raw && off == 0) ? x0 : ((enc.raw && off == 2) ? x2 : 0.0f);
+            const float raw_odd = (enc.raw && off == 0) ? x1 : 0.0f;
+            const bool trig = kf < enc.F;
+            v[2 * i] = trig ? c : raw_even;
+            v[2 * i + 1] = trig ? s : raw_odd;
+        }
+    }
+#undef FFN_L4
+}
+
+// split8x3 level by level over the eight values (identical bits; see features16_lockstep)
+__device__ __forceinline__ void split8x3_lockstep(const float (&x)[8], bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+    __bf16 h[8], m[8];
+    float r[8];
+#define FFN_L8 _Pragma("unroll") for (int j = 0; j < 8; ++j)
+    FFN_L8 h[j] = (__bf16)x[j];
+    FFN_L8 r[j] = x[j] - (float)h[j];
+    FFN_L8 m[j] = (__bf16)r[j];
+    FFN_L8 r[j] = r[j] - (float)m[j];
+    FFN_L8 { hi[j] = h[j]; mid[j] = m[j]; lo[j] = (__bf16)r[j]; }
+#undef FFN_L8
+}
+
 // Hardware sin / cos for the split-bf16 kernels: exact two-constant reduction by 2 pi (the angle is
 // the f32 kernels' angle, bit for bit), then v_sin_f32 / v_cos_f32 on the remainder in revolutions
 // -- 7 instructions per angle where the polynomial pair with its quadrant logic takes ~25, on the
@@ -273,6 +343,17 @@ int launch_forward_bf16x6(const ffn_mlp_chain* chain, const uint16_t* packed_w, 
                           float* saved, uint32_t* masks, void* stream);
 int launch_backward_bf16x6(const ffn_mlp_chain* chain, const uint16_t* packed_wt, const float* d_logits,
                            int64_t n, const uint32_t* masks, float* dz, void* stream);
+// The matrix-waves / vector-waves organisation of the bf16x6 chains (mlp_bf16_mv.hip) for the chains it
+// covers (mv_covers: a features-only first step, then 256 -> 256 steps); FFN_BF16X6_ORG=ws keeps the
+// two-waves-per-SIMD kernels for them too (A/B).
+bool mv_covers(const ffn_mlp_chain* chain, int* num_units);
+int launch_forward_bf16x6_mv(const ffn_mlp_chain* chain, const uint16_t* packed_w, const float* bias,
+                             const float* positions, const float* views, int64_t n, float* logits,
+                             float* saved, uint32_t* masks, int num_units, void* stream);
+inline bool bf16x6_prefers_mv() {
+    const char* v = getenv("FFN_BF16X6_ORG");
+    return !(v != nullptr && v[0] == 'w');
+}
 inline bool prefer_ws_kernels(bool by_default) {     // read per launch: tests flip it inside one process
     const char* v = getenv("FFN_BF16_KERNELS");
     if (v != nullptr && v[0] == 'r') return false;

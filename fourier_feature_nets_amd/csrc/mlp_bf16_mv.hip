@@ -1,0 +1,707 @@
+// bf16x6 chain kernels, third organisation: MATRIX WAVES AND VECTOR WAVES (OPT-IN arithmetic mode,
+// separately labelled; the exact-f32 kernels of mlp.hip stay the parity mode and the headline).
+//
+// What bounds the two-waves-per-SIMD kernels of mlp_bf16_ws.hip (round 6, cycle stamps): every wave
+// there is both -- it multiplies its tile, then runs its epilogue -- and the two waves of a SIMD do not
+// share the matrix pipe evenly (issue is arbitrated by priority, then age), so a step ends with the
+// younger wave's epilogue, the X refill and two barriers exposed (5.3 k of 18.8 k cycles per hidden
+// step), and every K loop starts cold behind a barrier (0.9 k) -- eight times per features-only step.
+// Here the two waves of a SIMD have DIFFERENT JOBS for the whole kernel:
+//
+//   * waves 0..3 (one per SIMD, the older ones) are MATRIX waves: wave m owns the output tiles m
+//     ("A") and m + 4 ("B") of every step for the pass's two 32-sample blocks and issues nothing but
+//     matrix instructions, LDS operand reads and weight requests -- ONE uninterrupted stream of
+//     "units" (one tile x one K block: 12 matrix instructions, 6 operand reads or none, 3 weight
+//     requests) through tiles, steps and passes; its weights stream L2 -> registers three units ahead
+//     out of a ring of four (the order of the units is a table in LDS);
+//   * waves 4..7 (their SIMD partners) are VECTOR waves: they generate the encoding features and run
+//     EVERY epilogue (ReLU, sign bits, slab stores, fused heads, the three-way bf16 split, the X
+//     stores) -- a tile's accumulators reach wave m + 4 through a 32 KiB hand-over buffer in LDS;
+//   * a hidden step runs tile A then tile B: the epilogue of A (writing K blocks 0..7 of the next
+//     X image IN PLACE, once every matrix wave is past K block 7 of tile B) runs under the K loop of B,
+//     the epilogue of B (K blocks 8..15) under the first half of the NEXT step's K loop of A, which
+//     reads K blocks 0..7 only: 96 KiB of X, 32 KiB of hand-over -- the LDS the ws kernels allocate;
+//   * the barriers ("S1: K blocks 8..15 are in X", "S2: A handed over", "S3: K blocks 0..7 consumed",
+//     "S3b: K blocks 0..7 of the next image are in X", "S4: B handed over") sit INSIDE the matrix
+//     waves' stream, in front of the operand reads they guard: no K loop starts cold;
+//   * a features-only step multiplies both tiles per K block (the features of a segment of eight K
+//     blocks are gone after it) while the vector waves generate the next segment, one barrier per
+//     segment; its LAST segment runs tile by tile like a hidden step, so that the first epilogue
+//     hides too.
+//
+// Arithmetic per accumulator is mlp_bf16_ws.hip's (the six partial products of a K block in the same
+// order, K blocks ascending, one accumulator in the forward): hidden activations, slabs and sign
+// masks are bit-identical; the fused heads' partial sums meet in another order (1e-7).
+//
+// Covers chains whose first step is features-only (a multiple of sixteen K blocks) and whose other
+// steps are 256 -> 256 (sixteen activation K blocks, eight output tiles): the tiny NeRF / Fourier
+// MLP family.  Everything else runs the ws kernels (mv_covers).
+#include <type_traits>
+
+#include "bf16_ring.h"
+
+namespace ffn {
+
+constexpr int kMvXBytes = 96 * 1024;               // X[K block 0..15][block 0..1][part 0..2][lane] x 16 B
+constexpr int kMvHandBytes = 32 * 1024;            // hand[matrix wave][block][register quad][lane] x 16 B
+constexpr int kMvBiasFloats = 4096;
+constexpr int kMvMaxUnits = 1024;                  // units of a pass (tiny NeRF: 128)
+constexpr int kMvLogitBytes = 4096;                // [vector wave][block][sample] x 16 B: the partial logits of a pass
+constexpr size_t kMvLdsBytes = (size_t)kMvXBytes + kMvHandBytes + kEncTableBytes + kMvBiasFloats * 4 + kMvMaxUnits * 4 +
+                               kMvLogitBytes;      // 160 KiB: all of a CU's LDS
+constexpr int kMvKbVecs = 384;                     // float4 per K block of X: 2 blocks x 3 parts x 64 lanes
+constexpr int kMvBlkVecs = 192;
+constexpr int kMvTileVecs = 192;                   // float4 per (K block, tile) of the packs: 3 parts x 64 lanes
+constexpr int kMvThreads = 512;
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// -DMV_STAMPS (scripts/probes/mv_stamps.py builds that variant library): cycle stamps of one pass of
+// workgroup 0 -- (id, s_memtime) pairs of its matrix wave 0 and its vector wave 4
+#ifdef MV_STAMPS
+__device__ long long mv_stamp_buf[2][1024];
+#define MV_STAMP(w, id) mv_stamp((w), (id))
+#else
+#define MV_STAMP(w, id) ((void)0)
+#endif
+
+struct MvCtx {
+    int lane, h, s, wave, m;       // m = wave & 3: the SIMD pair; tiles m and m + 4
+    f32x4* xbuf;                   // LDS
+    f32x4* hand;                   // LDS
+    f32x4* logit_lds;              // LDS
+    const float* enc_table;        // LDS
+    const float* bias_lds;         // LDS copy of the head of the bias buffer
+    const float* bias_glb;
+    const i32x4* tbl4;             // LDS: refill table, entry t = units 4t+3 .. 4t+6 (mod U)
+    int trips_total;               // U / 4
+    const f32x4* gw;               // the chain's operand packs
+    int64_t block0, num_blocks;
+    float* saved;
+    char* masks;
+#ifdef MV_STAMPS
+    mutable int stamp_on, stamp_n;
+#endif
+};
+
+#ifdef MV_STAMPS
+__device__ __forceinline__ void mv_stamp(const MvCtx& w, int id) {
+    if (w.stamp_on && w.stamp_n < 510) {
+        const long long t = __builtin_readcyclecounter();
+        if (w.lane == 0) {
+            mv_stamp_buf[w.wave >> 2][2 * w.stamp_n] = id;
+            mv_stamp_buf[w.wave >> 2][2 * w.stamp_n + 1] = t;
+        }
+        w.stamp_n += 1;
+    }
+}
+#endif
+
+__device__ __forceinline__ void mv_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
+// the matrix wave's registers that live across tiles, steps and passes
+struct MvMat {
+    bf16x8 wr[4][3];               // weight ring: slot = unit & 3, three parts
+    bf16x8 x[2][2][3];             // operand sets [parity][block][part]
+    i32x4 cur;                     // refill entries of the coming trip
+    int tq;                        // index of `cur` in the table
+};
+
+// (weight part, operand part) of the six partial products, smallest first (mlp_bf16_ws.hip)
+struct MvProducts {
+    static constexpr int W[6] = {0, 2, 1, 0, 1, 0};
+    static constexpr int X[6] = {2, 0, 1, 1, 0, 0};
+};
+
+typedef const f32x4 __attribute__((address_space(1)))* mv_gptr;
+
+// One unit: the 12 matrix instructions of (one tile, one K block) out of ring slot J and operand
+// set HB.  READX: the operands of the next K block stream into the other set behind the first six;
+// the ring slot of the unit before this one is requested again (three units ahead) behind the next
+// three.  bar (uniform): a workgroup barrier in front of the unit -- in front of the operand reads it
+// guards.  Every group (one matrix instruction, at most one memory instruction) is fenced.
+template <int J, int HB, bool READX>
+__device__ __forceinline__ void mv_unit(const MvCtx& w, f32x16 (&acc)[2], MvMat& r, const f32x4* xnext, mv_gptr refill, bool bar) {
+    const int lane = w.lane;
+    typedef MvProducts P;
+    if (bar) {
+        MV_STAMP(w, 30);
+        mv_barrier();
+        MV_STAMP(w, 31);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    auto group = [&](auto qc, auto bc) {
+        constexpr int q = decltype(qc)::value, b = decltype(bc)::value;
+        constexpr int g = 2 * q + b;
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.wr[J][P::W[q]], r.x[HB][b][P::X[q]], acc[b], 0, 0, 0);
+        if constexpr (READX && g < 6) {
+            // (set HB ^ 1 was last used by the unit before this one; parts in the order they are needed)
+            constexpr int rb = g & 1, rp = 2 - (g >> 1);
+            r.x[HB ^ 1][rb][rp] = __builtin_bit_cast(bf16x8, xnext[rb * kMvBlkVecs + rp * 64]);
+        }
+        constexpr int g0 = READX ? 6 : 2;
+        if constexpr (g >= g0 && g < g0 + 3)
+            r.wr[(J + 3) & 3][g - g0] = __builtin_bit_cast(bf16x8, refill[(g - g0) * 64 + lane]);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    typedef std::integral_constant<int, 0> i0;
+    typedef std::integral_constant<int, 1> i1;
+    group(i0{}, i0{}); group(i0{}, i1{});
+    group(i1{}, i0{}); group(i1{}, i1{});
+    group(std::integral_constant<int, 2>{}, i0{}); group(std::integral_constant<int, 2>{}, i1{});
+    group(std::integral_constant<int, 3>{}, i0{}); group(std::integral_constant<int, 3>{}, i1{});
+    group(std::integral_constant<int, 4>{}, i0{}); group(std::integral_constant<int, 4>{}, i1{});
+    group(std::integral_constant<int, 5>{}, i0{}); group(std::integral_constant<int, 5>{}, i1{});
+}
+
+// the refill bases of a trip (four SGPR pointers) and the table entry of the next one
+__device__ __forceinline__ void mv_trip_bases(const MvCtx& w, MvMat& r, mv_gptr (&base)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int e = __builtin_amdgcn_readfirstlane(r.cur[j]);
+        base[j] = (mv_gptr)(w.gw + (int64_t)(e + w.m) * kMvTileVecs);
+        asm volatile("" : "+s"(base[j]));
+    }
+    r.tq = r.tq + 1 < w.trips_total ? r.tq + 1 : 0;
+    r.cur = w.tbl4[r.tq];
+}
+
+// The K loop of ONE tile over `trips` x 4 K blocks of X from K block g0 (operands of g0 already in
+// set 0); the last unit streams K block g_after in -- the first one of whatever comes next.
+// bars: bit 4 t + j = barrier in front of unit j of trip t.
+__device__ __forceinline__ void mv_k_loop(const MvCtx& w, MvMat& r, f32x16 (&acc)[2], int g0, int trips, int g_after,
+                                          unsigned bars) {
+    const f32x4* xb = w.xbuf + w.lane;
+    for (int t = 0; t < trips; ++t) {
+        const int g = g0 + 4 * t;
+        const int g4 = t + 1 == trips ? g_after : g + 4;
+        mv_gptr base[4];
+        mv_trip_bases(w, r, base);
+        const unsigned bt = bars >> (4 * t);
+        mv_unit<0, 0, true>(w, acc, r, xb + (g + 1) * kMvKbVecs, base[0], (bt & 1u) != 0);
+        mv_unit<1, 1, true>(w, acc, r, xb + (g + 2) * kMvKbVecs, base[1], (bt & 2u) != 0);
+        mv_unit<2, 0, true>(w, acc, r, xb + (g + 3) * kMvKbVecs, base[2], (bt & 4u) != 0);
+        mv_unit<3, 1, true>(w, acc, r, xb + g4 * kMvKbVecs, base[3], (bt & 8u) != 0);
+    }
+}
+
+// `pairs` x 2 K blocks, BOTH tiles per K block (features-only steps): units (k, A), (k, B), (k + 1, A),
+// (k + 1, B); every fourth trip (the last one of a segment of eight K blocks) has a barrier in front of
+// (k + 1, A) -- in front of the reads of the next segment's first K block.
+__device__ __forceinline__ void mv_pair_loop(const MvCtx& w, MvMat& r, f32x16 (&acc_a)[2], f32x16 (&acc_b)[2],
+                                             int pairs) {
+    const f32x4* xb = w.xbuf + w.lane;
+    for (int t = 0; t < pairs; ++t) {
+        const int k = 2 * t;
+        mv_gptr base[4];
+        mv_trip_bases(w, r, base);
+        mv_unit<0, 0, true>(w, acc_a, r, xb + ((k + 1) & 15) * kMvKbVecs, base[0], false);
+        mv_unit<1, 0, false>(w, acc_b, r, nullptr, base[1], false);
+        mv_unit<2, 1, true>(w, acc_a, r, xb + ((k + 2) & 15) * kMvKbVecs, base[2], (t & 3) == 3);
+        mv_unit<3, 1, false>(w, acc_b, r, nullptr, base[3], false);
+    }
+}
+
+// operand set 0 <- X K block G (a cold start: the first step of a pass)
+__device__ __forceinline__ void mv_read_x0(const MvCtx& w, MvMat& r, int G) {
+    const f32x4* p = w.xbuf + G * kMvKbVecs + w.lane;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int part = 0; part < 3; ++part)
+            r.x[0][b][part] = __builtin_bit_cast(bf16x8, p[b * kMvBlkVecs + part * 64]);
+}
+
+__device__ __forceinline__ void mv_init_bias(const MvCtx& w, const ffn_step& L, int o, f32x16 (&acc)[2]) {
+    const float* bv = w.bias_lds + L.b_off + 32 * o + 4 * w.h;       // (mv_covers: the whole bias buffer is staged)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(bv + 8 * q);
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) acc[b][4 * q + p] = b4[p];
+    }
+}
+
+// a tile's accumulators into the hand-over buffer of this SIMD pair
+__device__ __forceinline__ void mv_hand_over(const MvCtx& w, const f32x16 (&acc)[2]) {
+    f32x4* dst = w.hand + (w.m * 2) * 256 + w.lane;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 v;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) v[p] = acc[b][4 * q + p];
+            dst[(b * 4 + q) * 64] = v;
+        }
+}
+__device__ __forceinline__ void mv_take_over(const MvCtx& w, f32x16 (&acc)[2]) {
+    const f32x4* src = w.hand + (w.m * 2) * 256 + w.lane;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = src[(b * 4 + q) * 64];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) acc[b][4 * q + p] = v[p];
+        }
+}
+
+// (X K block of feature K block k: k & 15 -- segments of eight K blocks alternate between the two halves
+// of X; the number of segments is even (mv_covers), so the LAST segment of the step sits in K blocks
+// 8..15: its epilogue of tile A writes K blocks 0..7 of the next image while tile B still reads it, and
+// the FIRST one in K blocks 0..7: the vector waves generate it, for the next pass, while the last step's
+// tile B reads K blocks 8..15)
+
+// ---------------------------------------------------------------------------------- the matrix waves
+// Barriers of a step, in order (the vector waves' code has the same list):
+//   features-only: F_0 .. F_{segments-2} (segment s + 1 is in X, segment s consumed), S2, S3, S3b, S4
+//   hidden:        S1, S2, S3, S3b, S4
+__device__ __forceinline__ void mv_matrix_features(const ffn_step& L, const MvCtx& w, MvMat& r) {
+    const int segments = L.aux_groups >> 4;        // (K blocks: a multiple of sixteen, mv_covers)
+    f32x16 acc_a[2], acc_b[2];
+    mv_init_bias(w, L, w.m, acc_a);
+    mv_init_bias(w, L, w.m + 4, acc_b);
+    mv_read_x0(w, r, 0);                           // (segment 0 is in X: the first pass's prologue, or S4 of the pass before)
+    MV_STAMP(w, 9);
+    mv_pair_loop(w, r, acc_a, acc_b, 4 * (segments - 1));                                    // F_0 .. F_{segments-2}
+    MV_STAMP(w, 10);
+    // the last segment (K blocks 8..15 of X), tile by tile
+    mv_k_loop(w, r, acc_a, 8, 2, 8, 0u);
+    MV_STAMP(w, 11);
+    mv_hand_over(w, acc_a);
+    mv_barrier();                                                                            // S2
+    MV_STAMP(w, 12);
+    mv_k_loop(w, r, acc_b, 8, 2, 0, 0x88u);                                                  // S3, S3b: units 3, 7
+    MV_STAMP(w, 13);
+    mv_hand_over(w, acc_b);
+    mv_barrier();                                                                            // S4
+    MV_STAMP(w, 14);
+}
+
+__device__ __forceinline__ void mv_matrix_hidden(const ffn_step& L, const MvCtx& w, MvMat& r) {
+    f32x16 acc_a[2], acc_b[2];
+    mv_init_bias(w, L, w.m, acc_a);
+    mv_init_bias(w, L, w.m + 4, acc_b);
+    MV_STAMP(w, 20);
+    mv_k_loop(w, r, acc_a, 0, 4, 0, 0x80u);                                                  // S1: unit 7
+    MV_STAMP(w, 21);
+    mv_hand_over(w, acc_a);
+    mv_barrier();                                                                            // S2
+    MV_STAMP(w, 22);
+    mv_k_loop(w, r, acc_b, 0, 4, 0, 0x880u);                                                 // S3, S3b: units 7, 11
+    MV_STAMP(w, 23);
+    mv_hand_over(w, acc_b);
+    mv_barrier();                                                                            // S4
+    MV_STAMP(w, 24);
+}
+
+// ---------------------------------------------------------------------------------- the vector waves
+struct MvVec {
+    float x0, x1, x2, v0, v1, v2;  // inputs of this wave's feature block (wave & 1)
+    float logit[2][4];             // fused heads: partial sums over the tiles of this SIMD pair
+};
+
+// feature K blocks k0 .. k0 + count - 1 of this wave's block into X; wave `rank` of `stride` generators
+__device__ __forceinline__ void mv_generate(const ffn_mlp_chain& ch, const ffn_step& L, const MvCtx& w, const MvVec& v,
+                                            int64_t block0, int k0, int count, int rank, int stride) {
+    Enc16 enc;
+    const ffn_encoding& e = ch.enc[L.enc_id];
+    enc.tab = w.enc_table + L.enc_id * kEncTablePitch;
+    enc.F = e.num_freq;
+    enc.raw = (e.include_input != 0 || e.num_freq == 0) ? 1 : 0;
+    enc.scale = e.scale;
+    const float p0 = L.enc_id == 0 ? v.x0 : v.v0;
+    const float p1 = L.enc_id == 0 ? v.x1 : v.v1;
+    const float p2 = L.enc_id == 0 ? v.x2 : v.v2;
+    const int g_trig = e.num_freq >> 3;            // K blocks whose eight frequencies are all real
+    const int fb = w.wave & 1;
+    f32x4* fsave = nullptr;
+    if (w.saved != nullptr && L.save_enc_slot >= 0 && block0 + fb < w.num_blocks)
+        fsave = reinterpret_cast<f32x4*>(w.saved + ch.slot_offset[L.save_enc_slot] * w.num_blocks * 32) +
+                (block0 + fb) * (int64_t)(ch.slot_channels[L.save_enc_slot] * 8);
+    // two items per trip: eight independent dependency chains in flight (a vector wave beside a saturated
+    // matrix pipe is latency-bound on one item's four)
+    auto item = [&](int G, float (&f)[8]) {
+        const int k = k0 + G;
+        if (k < g_trig) features16_lockstep<true>(enc, k, w.h, p0, p1, p2, f);
+        else features16_lockstep<false>(enc, k, w.h, p0, p1, p2, f);
+    };
+    auto emit = [&](int G, const float (&f)[8]) {
+        const int k = k0 + G;
+        if (fsave != nullptr) {
+            const int cq = 4 * k + 2 * w.h;
+            f32x4 f0, f1;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) { f0[p] = f[p]; f1[p] = f[4 + p]; }
+            __builtin_nontemporal_store(f0, &fsave[saved_index16(cq, w.s)]);
+            __builtin_nontemporal_store(f1, &fsave[saved_index16(cq + 1, w.s)]);
+        }
+        bf16x8 fp[3];
+        split8x3_lockstep(f, fp[0], fp[1], fp[2]);
+        f32x4* dst = w.xbuf + (k & 15) * kMvKbVecs + fb * kMvBlkVecs + w.lane;
+#pragma unroll
+        for (int part = 0; part < 3; ++part) dst[64 * part] = __builtin_bit_cast(f32x4, fp[part]);
+    };
+    int G = rank;
+    for (; G + stride < count; G += 2 * stride) {
+        float fa[8], fb8[8];
+        if (k0 + G + stride < g_trig) {            // (both items all-trig: one basic block, the chains interleave)
+            features16_lockstep<true>(enc, k0 + G, w.h, p0, p1, p2, fa);
+            features16_lockstep<true>(enc, k0 + G + stride, w.h, p0, p1, p2, fb8);
+        } else {
+            item(G, fa);
+            item(G + stride, fb8);
+        }
+        emit(G, fa);
+        emit(G + stride, fb8);
+    }
+    if (G < count) {
+        float fa[8];
+        item(G, fa);
+        emit(G, fa);
+    }
+}
+
+// sign-mask byte of (slot, block, lane, tile o) for a step of eight tiles (mlp.hip's format)
+__device__ __forceinline__ int64_t mv_mask_at(int slot, int64_t num_blocks, int64_t block, int lane, int o) {
+    return (((int64_t)slot * num_blocks + block) * 64 + lane) * 16 + 4 * (o >> 1) + ((o & 1) ? 0 : 2);
+}
+
+// The epilogue of tile o (accumulators in acc): ReLU, sign bits, slab stores, fused head, the
+// three-way split into res -- everything but the X stores.
+__device__ __forceinline__ void mv_epilogue(const ffn_mlp_chain& ch, const ffn_step& L, bool last_step, const MvCtx& w,
+                                            MvVec& v, int o, const f32x16 (&acc)[2], bf16x8 (&res)[2][2][3]) {
+    const bool fused_head = L.head_off >= 0;
+    const float* hw = w.bias_lds + (fused_head ? L.head_off : 0) + 4 + 16 * w.h;
+    if (fused_head && o == 0 && w.h == 0) {
+        const f32x4 hb = *reinterpret_cast<const f32x4*>(w.bias_lds + L.head_off);
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v.logit[b][c] += hb[c];
+    }
+    const int relu_floor = L.relu ? 0 : (int)0x80000000;
+    int save_s = w.s, save_h = w.h, e_lane = w.lane;
+    asm volatile("" : "+v"(save_s), "+v"(save_h), "+v"(e_lane));     // (see mlp_bf16.hip: no hoisted address tables)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const bool live = w.block0 + b < w.num_blocks;
+        f32x4* save_out = nullptr;
+        if (w.saved != nullptr && L.out_slot >= 0 && live)
+            save_out = reinterpret_cast<f32x4*>(w.saved + ch.slot_offset[L.out_slot] * w.num_blocks * 32) +
+                       (w.block0 + b) * (int64_t)(ch.slot_channels[L.out_slot] * 8);
+        unsigned sign_bits = 0u;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            float y[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float a = acc[b][8 * half + j];
+                sign_bits = __builtin_amdgcn_alignbit(sign_bits, __builtin_bit_cast(unsigned, 0.0f - a), 31);
+                y[j] = __builtin_bit_cast(float, __builtin_elementwise_max(__builtin_bit_cast(int, a), relu_floor));
+            }
+            if (save_out != nullptr) {
+                f32x4 y0, y1;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) { y0[p] = y[p]; y1[p] = y[4 + p]; }
+                const int cq = 2 * (4 * o + 2 * half) + save_h;
+                __builtin_nontemporal_store(y0, &save_out[saved_index16(cq, save_s)]);
+                __builtin_nontemporal_store(y1, &save_out[saved_index16(cq + 2, save_s)]);
+            }
+            if (fused_head) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int group = 4 * o + 2 * half + (j >> 2);
+                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(hw + group * 32 + (j & 3) * 4);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v.logit[b][c] = __builtin_fmaf(y[j], w4[c], v.logit[b][c]);
+                }
+            }
+            if (!last_step) split8x3_lockstep(y, res[b][half][0], res[b][half][1], res[b][half][2]);
+        }
+        if (w.masks != nullptr && L.relu && L.mask_slot >= 0 && live)
+            *reinterpret_cast<uint16_t*>(w.masks + mv_mask_at(L.mask_slot, w.num_blocks, w.block0 + b, e_lane, o)) =
+                (uint16_t)(sign_bits & 0xffffu);
+    }
+}
+
+// tile o's output = K blocks 2 o, 2 o + 1 of the next X image
+__device__ __forceinline__ void mv_store_x(const MvCtx& w, int o, const bf16x8 (&res)[2][2][3]) {
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            f32x4* dst = w.xbuf + (2 * o + half) * kMvKbVecs + b * kMvBlkVecs + w.lane;
+#pragma unroll
+            for (int part = 0; part < 3; ++part) dst[64 * part] = __builtin_bit_cast(f32x4, res[b][half][part]);
+        }
+}
+
+// a step seen from a vector wave, from its barrier S2 on (what comes before differs: the features'
+// segments, or S1).  next != nullptr (the LAST step of a pass that has a successor): segment 0 of the
+// NEXT pass's features is generated between S3b and S4 -- K blocks 0..7 of X are free from S3 on, the
+// matrix waves start the next pass on them right behind S4.
+__device__ __forceinline__ void mv_vector_tail(const ffn_mlp_chain& ch, const ffn_step& L, bool last_step,
+                                               const MvCtx& w, MvVec& v, const MvVec* next, int64_t next_block0) {
+    f32x16 acc[2];
+    bf16x8 res[2][2][3];
+    MV_STAMP(w, 60);
+    mv_barrier();                                  // S2: tile A handed over
+    MV_STAMP(w, 61);
+    mv_take_over(w, acc);
+    mv_epilogue(ch, L, last_step, w, v, w.m, acc, res);
+    MV_STAMP(w, 62);
+    mv_barrier();                                  // S3: K blocks 0..7 of X are consumed
+    MV_STAMP(w, 63);
+    if (!last_step) mv_store_x(w, w.m, res);
+    MV_STAMP(w, 64);
+    mv_barrier();                                  // S3b: K blocks 0..7 of the next image are in X
+    MV_STAMP(w, 65);
+    if (next != nullptr) {
+        mv_generate(ch, ch.step[0], w, *next, next_block0, 0, 8, (w.wave - 4) >> 1, 2);
+        MV_STAMP(w, 68);
+    }
+    mv_barrier();                                  // S4: tile B handed over, X consumed
+    MV_STAMP(w, 66);
+    mv_take_over(w, acc);
+    mv_epilogue(ch, L, last_step, w, v, w.m + 4, acc, res);
+    if (!last_step) mv_store_x(w, w.m + 4, res);
+    MV_STAMP(w, 67);
+    // (the next barrier -- S1 of the next step, or F_0 of the next pass -- publishes K blocks 8..15)
+}
+
+// the SIMD pairs' partial logits of a pass meet through LDS: every vector wave leaves its sums there, and
+// behind the next barrier (F_0 of the next pass) waves 4 and 5 add the four up, a block each
+__device__ __forceinline__ void mv_leave_logits(const MvCtx& w, const MvVec& v) {
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        f32x4 part;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) part[c] = v.logit[b][c] + __shfl_xor(v.logit[b][c], 32);
+        if (w.h == 0) w.logit_lds[(w.m * 2 + b) * 32 + w.s] = part;
+    }
+}
+__device__ __forceinline__ void mv_collect_logits(const MvCtx& w, int64_t block0, int64_t n, float* logits) {
+    if (w.wave < 6 && w.h == 0) {
+        const int b = w.wave - 4;
+        const int64_t block = block0 + b;
+        const int64_t sample = block * 32 + w.s;
+        f32x4 out = w.logit_lds[b * 32 + w.s];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) out += w.logit_lds[(k * 2 + b) * 32 + w.s];
+        if (block < w.num_blocks && sample < n) reinterpret_cast<f32x4*>(logits)[sample] = out;
+    }
+}
+
+// ---------------------------------------------------------------------------------- the kernel
+// units of a pass in the matrix waves' order: entry = (flat K block of the chain) * 8 + (0: tile A, 4: tile B)
+__device__ __forceinline__ int mv_build_units(const ffn_mlp_chain& ch, int* units) {
+    int u = 0, flat = 0;
+    for (int li = 0; li < ch.num_steps; ++li) {
+        const int kb_act = ch.step[li].act_groups >> 1, kb_feat = ch.step[li].aux_groups >> 1;
+        if (kb_act == 0) {
+            const int k_last = kb_feat - 8;
+            for (int k = 0; k < k_last; ++k) {
+                units[u++] = (flat + k) * 8;
+                units[u++] = (flat + k) * 8 + 4;
+            }
+            for (int t = 0; t < 2; ++t)
+                for (int k = k_last; k < kb_feat; ++k) units[u++] = (flat + k) * 8 + 4 * t;
+            flat += kb_feat;
+        } else {
+            for (int t = 0; t < 2; ++t)
+                for (int k = 0; k < kb_act; ++k) units[u++] = (flat + k) * 8 + 4 * t;
+            flat += kb_act;
+        }
+    }
+    return u;
+}
+
+__global__ void __launch_bounds__(kMvThreads)
+mlp_forward_bf16_mv_kernel(const ffn_mlp_chain ch, const uint16_t* __restrict__ packed,
+                           const float* __restrict__ bias, const float* __restrict__ positions,
+                           const float* __restrict__ views, int64_t n, float* __restrict__ logits,
+                           float* __restrict__ saved, uint32_t* __restrict__ masks, int num_units) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* enc_table = reinterpret_cast<float*>(smem + kMvXBytes + kMvHandBytes);
+    float* bias_lds = reinterpret_cast<float*>(smem + kMvXBytes + kMvHandBytes + kEncTableBytes);
+    int* tbl = reinterpret_cast<int*>(smem + kMvXBytes + kMvHandBytes + kEncTableBytes + kMvBiasFloats * 4);
+    stage_encoding_tables(ch.enc, enc_table, threadIdx.x, kMvThreads);
+    {
+        const int staged = ch.bias_floats < kMvBiasFloats ? ch.bias_floats : kMvBiasFloats;
+        for (int i = threadIdx.x; i < staged; i += kMvThreads) bias_lds[i] = bias[i];
+    }
+    if (threadIdx.x == 0) {
+        // the refill table: tbl[i] = unit (i + 3) mod U, so that int4 entry t holds what trip t refills
+        int* units = reinterpret_cast<int*>(smem);             // (X is not in use yet)
+        const int u_total = mv_build_units(ch, units);
+        for (int i = 0; i < u_total; ++i) tbl[i] = units[(i + 3) % u_total];
+    }
+    MvCtx w;
+    w.lane = threadIdx.x & 63;
+    w.h = w.lane >> 5;
+    w.s = w.lane & 31;
+    w.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    w.m = w.wave & 3;
+    w.xbuf = reinterpret_cast<f32x4*>(smem);
+    w.hand = reinterpret_cast<f32x4*>(smem + kMvXBytes);
+    w.logit_lds = reinterpret_cast<f32x4*>(smem + kMvXBytes + kMvHandBytes + kEncTableBytes + kMvBiasFloats * 4 + kMvMaxUnits * 4);
+    w.enc_table = enc_table;
+    w.bias_lds = bias_lds;
+    w.bias_glb = bias;
+    w.tbl4 = reinterpret_cast<const i32x4*>(tbl);
+    w.trips_total = num_units >> 2;
+    w.gw = reinterpret_cast<const f32x4*>(packed + ch.step[0].w_off);
+    w.saved = saved;
+    w.masks = reinterpret_cast<char*>(masks);
+    w.num_blocks = (n + 31) / 32;
+    const int64_t passes = (w.num_blocks + 1) / 2;
+    const bool matrix = w.wave < 4;
+    __syncthreads();                               // tables, biases and the unit table are staged
+
+    const ffn_step& L0 = ch.step[0];
+    const int segments = L0.aux_groups >> 4;
+    const int fb = w.wave & 1;
+    auto inputs_of = [&](int64_t pass, MvVec& dst) {
+        int64_t block = pass * 2 + fb;
+        block = block < w.num_blocks ? block : w.num_blocks - 1;
+        const int64_t sample = block * 32 + w.s;
+        const int64_t src = sample < n ? sample : n - 1;
+        dst.x0 = positions[src * 3 + 0]; dst.x1 = positions[src * 3 + 1]; dst.x2 = positions[src * 3 + 2];
+        dst.v0 = dst.v1 = dst.v2 = 0.0f;
+        if (views != nullptr) {
+            dst.v0 = views[src * 3 + 0]; dst.v1 = views[src * 3 + 1]; dst.v2 = views[src * 3 + 2];
+        }
+    };
+    // ---- the first pass's first segment of features: every wave generates (2 items each)
+    MvVec v, vnext;
+    inputs_of(blockIdx.x, v);
+    mv_generate(ch, L0, w, v, (int64_t)blockIdx.x * 2, 0, 8, w.wave >> 1, 4);
+    mv_barrier();                                                                            // P1
+
+    if (matrix) {
+        // (the matrix pipe must never wait for an issue slot the partner's vector work took)
+        __builtin_amdgcn_s_setprio(3);
+        MvMat r;
+        // units 0, 1, 2 into ring slots 0, 1, 2 (table entry T - 1 = units U-1, 0, 1, 2); entry 0 next
+        const i32x4 first = w.tbl4[w.trips_total - 1];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int e = __builtin_amdgcn_readfirstlane(first[j + 1]);
+            mv_gptr base = (mv_gptr)(w.gw + (int64_t)(e + w.m) * kMvTileVecs);
+#pragma unroll
+            for (int part = 0; part < 3; ++part) r.wr[j][part] = __builtin_bit_cast(bf16x8, base[part * 64 + w.lane]);
+        }
+        r.tq = 0;
+        r.cur = w.tbl4[0];
+        for (int64_t pass = blockIdx.x; pass < passes; pass += gridDim.x) {
+#ifdef MV_STAMPS
+            w.stamp_on = blockIdx.x == 0 && pass == blockIdx.x + 2 * (int64_t)gridDim.x && w.wave == 0;
+            w.stamp_n = 0;
+#endif
+            MV_STAMP(w, 1);
+            mv_matrix_features(L0, w, r);
+            for (int li = 1; li < ch.num_steps; ++li) mv_matrix_hidden(ch.step[li], w, r);
+        }
+        mv_barrier();                                                                        // R: the last pass's logits
+        return;
+    }
+
+    // ---- a vector wave
+    bool pending = false;                          // the partial logits of the pass before wait in LDS
+    int64_t pending_block0 = 0;
+    for (int64_t pass = blockIdx.x; pass < passes; pass += gridDim.x) {
+#ifdef MV_STAMPS
+        w.stamp_on = blockIdx.x == 0 && pass == blockIdx.x + 2 * (int64_t)gridDim.x && w.wave == 4;
+        w.stamp_n = 0;
+#endif
+        MV_STAMP(w, 1);
+        w.block0 = pass * 2;
+        const bool has_next = pass + gridDim.x < passes;
+        if (has_next) inputs_of(pass + gridDim.x, vnext);
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v.logit[b][c] = 0.0f;
+        for (int seg = 1; seg < segments; ++seg) {
+            mv_generate(ch, L0, w, v, w.block0, 8 * seg, 8, (w.wave - 4) >> 1, 2);
+            MV_STAMP(w, 50);
+            mv_barrier();                                                                    // F_{seg-1}
+            MV_STAMP(w, 51);
+            if (seg == 1 && pending) {
+                mv_collect_logits(w, pending_block0, n, logits);
+                pending = false;
+            }
+        }
+        mv_vector_tail(ch, L0, false, w, v, nullptr, 0);
+        for (int li = 1; li < ch.num_steps; ++li) {
+            const bool last = li + 1 == ch.num_steps;
+            MV_STAMP(w, 70);
+            mv_barrier();                                                                    // S1
+            MV_STAMP(w, 71);
+            mv_vector_tail(ch, ch.step[li], last, w, v, (last && has_next) ? &vnext : nullptr, w.block0 + 2 * (int64_t)gridDim.x);
+        }
+        mv_leave_logits(w, v);
+        pending = true;
+        pending_block0 = w.block0;
+        if (has_next) {
+            v.x0 = vnext.x0; v.x1 = vnext.x1; v.x2 = vnext.x2;
+            v.v0 = vnext.v0; v.v1 = vnext.v1; v.v2 = vnext.v2;
+        }
+    }
+    mv_barrier();                                                                            // R
+    if (pending) mv_collect_logits(w, pending_block0, n, logits);
+}
+
+// Chains this organisation covers: a features-only first step of 16 j K blocks, then 256 -> 256 steps;
+// eight output tiles everywhere; a bias buffer that fits its LDS copy.
+bool mv_covers(const ffn_mlp_chain* chain, int* num_units) {
+    if (chain->num_steps < 2 || chain->wide != 0 || chain->bias_floats > kMvBiasFloats) return false;
+    int units = 0;
+    for (int i = 0; i < chain->num_steps; ++i) {
+        const ffn_step& L = chain->step[i];
+        const int kb_act = L.act_groups >> 1, kb_feat = L.aux_groups >> 1;
+        if (L.out_tiles != 8) return false;
+        if (i == 0) {
+            if (kb_act != 0 || kb_feat < 16 || (kb_feat & 15) != 0) return false;
+            units += 2 * kb_feat;
+        } else {
+            if (kb_act != 16 || kb_feat != 0) return false;
+            units += 32;
+        }
+    }
+    if (units > kMvMaxUnits) return false;
+    *num_units = units;
+    return true;
+}
+
+int launch_forward_bf16x6_mv(const ffn_mlp_chain* chain, const uint16_t* packed_w, const float* bias,
+                             const float* positions, const float* views, int64_t n, float* logits,
+                             float* saved, uint32_t* masks, int num_units, void* stream) {
+    int cus = 256, dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int val = 0;
+        if (hipDeviceGetAttribute(&val, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && val > 0) cus = val;
+    }
+    const int64_t passes = ((n + 31) / 32 + 1) / 2;
+    const int64_t grid = passes < cus ? passes : cus;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_forward_bf16_mv_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMvLdsBytes);
+    hipLaunchKernelGGL(mlp_forward_bf16_mv_kernel, dim3((unsigned)grid), dim3(kMvThreads), kMvLdsBytes,
+                       (hipStream_t)stream, *chain, packed_w, bias, positions, views, n, logits, saved, masks, num_units);
+    return 0;
+}
+
+}  // namespace ffn
+
+#ifdef MV_STAMPS
+extern "C" int ffn_debug_mv_stamps(long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(ffn::mv_stamp_buf), sizeof(long long) * 2 * 1024);
+}
+#endif

@@ -1012,6 +1012,9 @@ int launch_forward_bf16x6(const ffn_mlp_chain* chain, const uint16_t* packed_w, 
                           float* saved, uint32_t* masks, void* stream) {
     // (inference launches run the saving instantiation with null slabs: see ws_launch_fwd_modes)
     const char* two = getenv("FFN_BF16X6_FWD_ACCS");
+    int mv_units = 0;
+    if (bf16x6_prefers_mv() && !bf16x6_nine_products() && (two == nullptr || two[0] != '2') && mv_covers(chain, &mv_units))
+        return launch_forward_bf16x6_mv(chain, packed_w, bias, positions, views, n, logits, saved, masks, mv_units, stream);
     if (bf16x6_nine_products()) ws_launch_fwd<WsSplit9, true, false>(chain, packed_w, bias, positions, views, n, logits, saved, masks, stream);
     else if (two == nullptr || two[0] != '2') ws_launch_fwd<WsSplit6one, true, false>(chain, packed_w, bias, positions, views, n, logits, saved, masks, stream);
     else ws_launch_fwd<WsSplit6, true, false>(chain, packed_w, bias, positions, views, n, logits, saved, masks, stream);

@@ -67,6 +67,8 @@ probe(const f32x4* __restrict__ pack, float* out, int passes, long long* cycles)
     bf16x8 wr[DEPTH][NT][3];
     bf16x8 x[2][2][3];
     float fill[8];
+    float fc0 = 1.0001f, fc1 = 0.5f;
+    asm volatile("" : "+v"(fc0), "+v"(fc1));
 #pragma unroll
     for (int i = 0; i < 8; ++i) fill[i] = lane + i;
     // prologue: DEPTH K blocks of weights in flight, X of K block 0
@@ -115,8 +117,11 @@ probe(const f32x4* __restrict__ pack, float* out, int passes, long long* cycles)
                             }
 #pragma unroll
                             for (int j = 0; j < FILL; ++j) {
+                                // (inline assembly: left to itself hipcc packs pairs of these into
+                                // v_pk_fma_f32, which is slow beside matrix instructions -- the first
+                                // version of this probe measured THAT: 3.4 cycles per filler)
                                 const int idx = (g * FILL + j) & 7;
-                                fill[idx] = __builtin_fmaf(fill[idx], 1.0001f, 0.5f);
+                                asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(fill[idx]) : "v"(fc0), "v"(fc1));
                             }
                             __builtin_amdgcn_sched_barrier(0);
                         }
@@ -174,10 +179,16 @@ int main() {
     run<1, 8, 0, true, true>(pack, out, cyc);
     run<1, 8, 2, true, true>(pack, out, cyc);        // + vector work in the shadows
     run<1, 8, 4, true, true>(pack, out, cyc);
+    run<1, 8, 5, true, true>(pack, out, cyc);
+    run<1, 8, 6, true, true>(pack, out, cyc);
+    run<1, 8, 8, true, true>(pack, out, cyc);
+    run<1, 4, 4, false, false>(pack, out, cyc);      // (fillers beside the bare matrix stream)
+    run<1, 4, 6, false, false>(pack, out, cyc);
     run<2, 2, 0, true, true>(pack, out, cyc);        // two tiles per wave and K block: half the LDS reads per instruction
     run<2, 4, 0, true, true>(pack, out, cyc);
     run<2, 4, 2, true, true>(pack, out, cyc);
     run<2, 4, 4, true, true>(pack, out, cyc);
+    run<2, 4, 6, true, true>(pack, out, cyc);
     // with a second wave per SIMD in vector + LDS work (an epilogue beside the K loop), at equal
     // priority and with the K-loop waves at s_setprio 1
     run<1, 2, 0, true, true, 1>(pack, out, cyc);

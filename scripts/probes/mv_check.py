@@ -1,0 +1,116 @@
+"""bf16x6 chain kernels: the matrix-waves / vector-waves organisation (csrc/mlp_bf16_mv.hip) against the
+two-waves-per-SIMD one (csrc/mlp_bf16_ws.hip) on the chains both cover -- buffers compared bit for bit
+(slabs, masks, dZ), logits to 1e-6, then timings interleaved in one process (FFN_BF16X6_ORG is read per
+launch).  Run on a GPU box:  python scripts/probes/mv_check.py [--time-only] [--n 4194304]"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import fourier_feature_nets_amd as ffn  # noqa: E402
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def models():
+    torch.manual_seed(7)
+    out = {
+        "tiny_nerf": ffn.PositionalFourierMLP(3, 4, 5.5, num_layers=3, num_channels=256, embedding_size=256),
+        "gaussian": ffn.GaussianFourierMLP(3, 4, 3.0, num_layers=4, num_channels=256, embedding_size=256),
+        "positional_8": ffn.PositionalFourierMLP(3, 4, 5.5, num_layers=8, num_channels=256, embedding_size=256),
+    }
+    return {k: m.to(dev()) for k, m in out.items()}
+
+
+def run(prog, x, n, org, train):
+    os.environ["FFN_BF16X6_ORG"] = org
+    buf = torch.zeros((prog.saved_floats(n),), dtype=torch.float32, device=dev()) if train else None
+    logits = prog.forward(x, None, buf, precision="bf16x6")
+    torch.cuda.synchronize()
+    return logits, buf
+
+
+def check(name, model):
+    prog = model.program()
+    worst = 0.0
+    for n in (1, 31, 64, 65, 1000, 4097, 70000):
+        torch.manual_seed(n)
+        x = torch.rand(n, 3, device=dev()) * 2 - 1
+        ref_l, ref_s = run(prog, x, n, "ws", True)
+        new_l, new_s = run(prog, x, n, "mv", True)
+        scale = max(float(ref_l.abs().max()), 1.0)
+        err = float((new_l - ref_l).abs().max()) / scale
+        worst = max(worst, err)
+        assert err <= 2e-6, (name, n, "logits", err)
+        assert torch.equal(ref_s.view(torch.int32), new_s.view(torch.int32)), (name, n, "slabs / masks differ",
+                                                                                int((ref_s.view(torch.int32) != new_s.view(torch.int32)).sum()))
+        inf_l, _ = run(prog, x, n, "mv", False)
+        assert torch.equal(inf_l, new_l), (name, n, "inference != training forward")
+        if prog.bwd_x6 is not None:
+            d_logits = torch.randn(n, 4, device=dev()) / n
+            ws = prog.workspace(n)
+            got = {}
+            for org in ("ws", "mv"):
+                os.environ["FFN_BF16X6_ORG"] = org
+                ws.dz.zero_()
+                flat = torch.zeros((prog.num_grad_floats,), dtype=torch.float32, device=dev())
+                prog.backward(d_logits, x, None, ref_s, flat, precision="bf16x6")
+                torch.cuda.synchronize()
+                got[org] = (ws.dz.clone(), flat)
+            assert torch.equal(got["ws"][0].view(torch.int32), got["mv"][0].view(torch.int32)), (name, n, "dZ differs")
+            assert torch.equal(got["ws"][1], got["mv"][1]), (name, n, "gradients differ")
+    print("%-14s parity ok (logits within %.1e of the ws kernels'; slabs, masks, dZ, gradients bit-identical)" % (name, worst), flush=True)
+
+
+def timeit(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def timing(name, model, n, reps):
+    prog = model.program()
+    torch.manual_seed(1)
+    x = torch.rand(n, 3, device=dev()) * 2 - 1
+    buf = torch.zeros((prog.saved_floats(n),), dtype=torch.float32, device=dev())
+    d_logits = torch.randn(n, 4, device=dev()) / n
+    flat = torch.zeros((prog.num_grad_floats,), dtype=torch.float32, device=dev())
+    prog.forward(x, None, buf, precision="bf16x6")
+    rows = {}
+    for rnd in range(2):
+        for org in ("ws", "mv"):
+            os.environ["FFN_BF16X6_ORG"] = org
+            rows.setdefault(org, {}).setdefault("inference_ms", []).append(
+                round(timeit(lambda: prog.forward(x, None, None, precision="bf16x6"), reps), 3))
+            rows[org].setdefault("train_forward_ms", []).append(
+                round(timeit(lambda: prog.forward(x, None, buf, precision="bf16x6"), reps), 3))
+            rows[org].setdefault("backward_ms", []).append(
+                round(timeit(lambda: prog.backward(d_logits, x, None, buf, flat, precision="bf16x6"), reps), 3))
+    print(json.dumps({"model": name, "samples": n, "ms": rows}), flush=True)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--time-only", action="store_true")
+    ap.add_argument("--check-only", action="store_true")
+    ap.add_argument("--n", type=int, default=4194304)
+    ap.add_argument("--reps", type=int, default=5)
+    args = ap.parse_args()
+    ms = models()
+    if not args.time_only:
+        for k, m in ms.items():
+            check(k, m)
+    if not args.check_only:
+        for k, m in ms.items():
+            timing(k, m, args.n, args.reps)
