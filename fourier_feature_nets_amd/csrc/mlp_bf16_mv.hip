@@ -52,7 +52,9 @@ constexpr size_t kMvLdsBytes = (size_t)kMvXBytes + kMvHandBytes + kEncTableBytes
 constexpr int kMvKbVecs = 384;                     // float4 per K block of X: 2 blocks x 3 parts x 64 lanes
 constexpr int kMvBlkVecs = 192;
 constexpr int kMvTileVecs = 192;                   // float4 per (K block, tile) of the packs: 3 parts x 64 lanes
-constexpr int kMvThreads = 512;
+constexpr int kMvVecPerSimd = 2;                   // vector waves beside every matrix wave: a 32-sample block each
+constexpr int kMvWaves = 4 + 4 * kMvVecPerSimd;
+constexpr int kMvThreads = 64 * kMvWaves;
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
@@ -66,7 +68,8 @@ __device__ long long mv_stamp_buf[2][1024];
 #endif
 
 struct MvCtx {
-    int lane, h, s, wave, m;       // m = wave & 3: the SIMD pair; tiles m and m + 4
+    int lane, h, s, wave, m;       // m = wave & 3: the SIMD; tiles m and m + 4
+    int sub;                       // vector waves: (wave - 4) >> 2, the block of the pass whose epilogues this wave runs
     f32x4* xbuf;                   // LDS
     f32x4* hand;                   // LDS
     f32x4* logit_lds;              // LDS
@@ -105,7 +108,11 @@ __device__ __forceinline__ void mv_barrier() {
 // the matrix wave's registers that live across tiles, steps and passes
 struct MvMat {
     bf16x8 wr[4][3];               // weight ring: slot = unit & 3, three parts
-    bf16x8 x[2][2][3];             // operand sets [parity][block][part]
+    // operands of the K block being multiplied, per 32-sample block: the hi parts double-buffered (a K
+    // block's last product needs them), the mid and lo parts REPLACED IN PLACE behind their last use
+    // (lo: the first product, mid: the fourth) by those of the next K block -- 32 registers instead of 48:
+    // with three waves per SIMD a wave has 168
+    bf16x8 xh[2][2], xm[2], xl[2];
     i32x4 cur;                     // refill entries of the coming trip
     int tq;                        // index of `cur` in the table
 };
@@ -118,15 +125,16 @@ struct MvProducts {
 
 typedef const f32x4 __attribute__((address_space(1)))* mv_gptr;
 
-// One unit: the 12 matrix instructions of (one tile, one K block) out of ring slot J and operand
-// set HB.  READX: the operands of the next K block stream into the other set behind the first six;
-// the ring slot of the unit before this one is requested again (three units ahead) behind the next
-// three.  bar (uniform): a workgroup barrier in front of the unit -- in front of the operand reads it
-// guards.  Every group (one matrix instruction, at most one memory instruction) is fenced.
+// One unit: the 12 matrix instructions of (one tile, one K block) out of ring slot J and hi-operand
+// set HB.  READX: the operands of the next K block stream in behind the matrix instructions that free
+// their registers (lo behind the first product, hi -- other set -- behind the second, mid behind the
+// fourth); the ring slot of the unit before this one is requested again (three units ahead) behind
+// the others.  bar (uniform): a workgroup barrier in front of the unit -- in front of the operand reads
+// it guards.  Every group (one matrix instruction, at most one memory instruction) is fenced.
 template <int J, int HB, bool READX>
 __device__ __forceinline__ void mv_unit(const MvCtx& w, f32x16 (&acc)[2], MvMat& r, const f32x4* xnext, mv_gptr refill, bool bar) {
-    const int lane = w.lane;
     typedef MvProducts P;
+    const int lane = w.lane;
     if (bar) {
         MV_STAMP(w, 30);
         mv_barrier();
@@ -136,15 +144,16 @@ __device__ __forceinline__ void mv_unit(const MvCtx& w, f32x16 (&acc)[2], MvMat&
     auto group = [&](auto qc, auto bc) {
         constexpr int q = decltype(qc)::value, b = decltype(bc)::value;
         constexpr int g = 2 * q + b;
-        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.wr[J][P::W[q]], r.x[HB][b][P::X[q]], acc[b], 0, 0, 0);
-        if constexpr (READX && g < 6) {
-            // (set HB ^ 1 was last used by the unit before this one; parts in the order they are needed)
-            constexpr int rb = g & 1, rp = 2 - (g >> 1);
-            r.x[HB ^ 1][rb][rp] = __builtin_bit_cast(bf16x8, xnext[rb * kMvBlkVecs + rp * 64]);
-        }
-        constexpr int g0 = READX ? 6 : 2;
-        if constexpr (g >= g0 && g < g0 + 3)
-            r.wr[(J + 3) & 3][g - g0] = __builtin_bit_cast(bf16x8, refill[(g - g0) * 64 + lane]);
+        const bf16x8 operand = P::X[q] == 0 ? r.xh[HB][b] : (P::X[q] == 1 ? r.xm[b] : r.xl[b]);
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.wr[J][P::W[q]], operand, acc[b], 0, 0, 0);
+        if constexpr (READX && q == 0) r.xl[b] = __builtin_bit_cast(bf16x8, xnext[b * kMvBlkVecs + 2 * 64]);
+        if constexpr (READX && q == 1) r.xh[HB ^ 1][b] = __builtin_bit_cast(bf16x8, xnext[b * kMvBlkVecs]);
+        if constexpr (READX && q == 3) r.xm[b] = __builtin_bit_cast(bf16x8, xnext[b * kMvBlkVecs + 64]);
+        // the weight requests: behind products 2 (both blocks) and 4 (block 0) -- groups 4, 5, 8 -- with
+        // operand reads in the unit, else behind groups 2, 3, 4
+        constexpr int slot = READX ? (g == 4 ? 0 : (g == 5 ? 1 : (g == 8 ? 2 : -1))) : (g >= 2 && g < 5 ? g - 2 : -1);
+        if constexpr (slot >= 0)
+            r.wr[(J + 3) & 3][slot] = __builtin_bit_cast(bf16x8, refill[slot * 64 + lane]);
         __builtin_amdgcn_sched_barrier(0);
     };
     typedef std::integral_constant<int, 0> i0;
@@ -175,6 +184,10 @@ __device__ __forceinline__ void mv_trip_bases(const MvCtx& w, MvMat& r, mv_gptr 
 __device__ __forceinline__ void mv_k_loop(const MvCtx& w, MvMat& r, f32x16 (&acc)[2], int g0, int trips, int g_after,
                                           unsigned bars) {
     const f32x4* xb = w.xbuf + w.lane;
+    // (not unrolled: with constant trip counts hipcc unrolls, turns the operand addresses beyond the 64 KiB
+    // immediate range into values it keeps -- and SPILLS them: scratch traffic inside the stream, in
+    // order with the weight requests)
+#pragma nounroll
     for (int t = 0; t < trips; ++t) {
         const int g = g0 + 4 * t;
         const int g4 = t + 1 == trips ? g_after : g + 4;
@@ -189,30 +202,33 @@ __device__ __forceinline__ void mv_k_loop(const MvCtx& w, MvMat& r, f32x16 (&acc
 }
 
 // `pairs` x 2 K blocks, BOTH tiles per K block (features-only steps): units (k, A), (k, B), (k + 1, A),
-// (k + 1, B); every fourth trip (the last one of a segment of eight K blocks) has a barrier in front of
-// (k + 1, A) -- in front of the reads of the next segment's first K block.
+// (k + 1, B); the B units stream the next K block's operands in (both units of a K block multiply out
+// of the same registers).  Every fourth trip (the last one of a segment of eight K blocks) has a
+// barrier in front of (k + 1, B) -- in front of the reads of the next segment's first K block.
 __device__ __forceinline__ void mv_pair_loop(const MvCtx& w, MvMat& r, f32x16 (&acc_a)[2], f32x16 (&acc_b)[2],
                                              int pairs) {
     const f32x4* xb = w.xbuf + w.lane;
+#pragma nounroll
     for (int t = 0; t < pairs; ++t) {
         const int k = 2 * t;
         mv_gptr base[4];
         mv_trip_bases(w, r, base);
-        mv_unit<0, 0, true>(w, acc_a, r, xb + ((k + 1) & 15) * kMvKbVecs, base[0], false);
-        mv_unit<1, 0, false>(w, acc_b, r, nullptr, base[1], false);
-        mv_unit<2, 1, true>(w, acc_a, r, xb + ((k + 2) & 15) * kMvKbVecs, base[2], (t & 3) == 3);
-        mv_unit<3, 1, false>(w, acc_b, r, nullptr, base[3], false);
+        mv_unit<0, 0, false>(w, acc_a, r, nullptr, base[0], false);
+        mv_unit<1, 0, true>(w, acc_b, r, xb + ((k + 1) & 15) * kMvKbVecs, base[1], false);
+        mv_unit<2, 1, false>(w, acc_a, r, nullptr, base[2], false);
+        mv_unit<3, 1, true>(w, acc_b, r, xb + ((k + 2) & 15) * kMvKbVecs, base[3], (t & 3) == 3);
     }
 }
 
-// operand set 0 <- X K block G (a cold start: the first step of a pass)
+// the operand registers <- X K block G, hi set 0 (a cold start: the first step of a pass)
 __device__ __forceinline__ void mv_read_x0(const MvCtx& w, MvMat& r, int G) {
     const f32x4* p = w.xbuf + G * kMvKbVecs + w.lane;
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int part = 0; part < 3; ++part)
-            r.x[0][b][part] = __builtin_bit_cast(bf16x8, p[b * kMvBlkVecs + part * 64]);
+    for (int b = 0; b < 2; ++b) {
+        r.xh[0][b] = __builtin_bit_cast(bf16x8, p[b * kMvBlkVecs]);
+        r.xm[b] = __builtin_bit_cast(bf16x8, p[b * kMvBlkVecs + 64]);
+        r.xl[b] = __builtin_bit_cast(bf16x8, p[b * kMvBlkVecs + 128]);
+    }
 }
 
 __device__ __forceinline__ void mv_init_bias(const MvCtx& w, const ffn_step& L, int o, f32x16 (&acc)[2]) {
@@ -240,16 +256,14 @@ __device__ __forceinline__ void mv_hand_over(const MvCtx& w, const f32x16 (&acc)
             dst[(b * 4 + q) * 64] = v;
         }
 }
-__device__ __forceinline__ void mv_take_over(const MvCtx& w, f32x16 (&acc)[2]) {
-    const f32x4* src = w.hand + (w.m * 2) * 256 + w.lane;
+__device__ __forceinline__ void mv_take_over(const MvCtx& w, f32x16& acc) {
+    const f32x4* src = w.hand + (w.m * 2 + w.sub) * 256 + w.lane;
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 v = src[q * 64];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 v = src[(b * 4 + q) * 64];
-#pragma unroll
-            for (int p = 0; p < 4; ++p) acc[b][4 * q + p] = v[p];
-        }
+        for (int p = 0; p < 4; ++p) acc[4 * q + p] = v[p];
+    }
 }
 
 // (X K block of feature K block k: k & 15 -- segments of eight K blocks alternate between the two halves
@@ -284,7 +298,7 @@ __device__ __forceinline__ void mv_matrix_features(const ffn_step& L, const MvCt
     MV_STAMP(w, 14);
 }
 
-__device__ __forceinline__ void mv_matrix_hidden(const ffn_step& L, const MvCtx& w, MvMat& r) {
+__device__ __forceinline__ void mv_matrix_hidden(const ffn_step& L, bool last_step, const MvCtx& w, MvMat& r) {
     f32x16 acc_a[2], acc_b[2];
     mv_init_bias(w, L, w.m, acc_a);
     mv_init_bias(w, L, w.m + 4, acc_b);
@@ -294,7 +308,9 @@ __device__ __forceinline__ void mv_matrix_hidden(const ffn_step& L, const MvCtx&
     mv_hand_over(w, acc_a);
     mv_barrier();                                                                            // S2
     MV_STAMP(w, 22);
-    mv_k_loop(w, r, acc_b, 0, 4, 0, 0x880u);                                                 // S3, S3b: units 7, 11
+    // (the last step stores nothing into X: S3b right behind S3, and the vector waves have the rest of
+    // this K loop for the next pass's first segment of features)
+    mv_k_loop(w, r, acc_b, 0, 4, 0, last_step ? 0x180u : 0x880u);                            // S3, S3b: units 7, 11 (7, 8)
     MV_STAMP(w, 23);
     mv_hand_over(w, acc_b);
     mv_barrier();                                                                            // S4
@@ -304,7 +320,7 @@ __device__ __forceinline__ void mv_matrix_hidden(const ffn_step& L, const MvCtx&
 // ---------------------------------------------------------------------------------- the vector waves
 struct MvVec {
     float x0, x1, x2, v0, v1, v2;  // inputs of this wave's feature block (wave & 1)
-    float logit[2][4];             // fused heads: partial sums over the tiles of this SIMD pair
+    float logit[4];                // fused heads: partial sums over the two tiles of this SIMD, this wave's block
 };
 
 // feature K blocks k0 .. k0 + count - 1 of this wave's block into X; wave `rank` of `stride` generators
@@ -325,15 +341,11 @@ __device__ __forceinline__ void mv_generate(const ffn_mlp_chain& ch, const ffn_s
     if (w.saved != nullptr && L.save_enc_slot >= 0 && block0 + fb < w.num_blocks)
         fsave = reinterpret_cast<f32x4*>(w.saved + ch.slot_offset[L.save_enc_slot] * w.num_blocks * 32) +
                 (block0 + fb) * (int64_t)(ch.slot_channels[L.save_enc_slot] * 8);
-    // two items per trip: eight independent dependency chains in flight (a vector wave beside a saturated
-    // matrix pipe is latency-bound on one item's four)
-    auto item = [&](int G, float (&f)[8]) {
+    for (int G = rank; G < count; G += stride) {
         const int k = k0 + G;
+        float f[8];
         if (k < g_trig) features16_lockstep<true>(enc, k, w.h, p0, p1, p2, f);
         else features16_lockstep<false>(enc, k, w.h, p0, p1, p2, f);
-    };
-    auto emit = [&](int G, const float (&f)[8]) {
-        const int k = k0 + G;
         if (fsave != nullptr) {
             const int cq = 4 * k + 2 * w.h;
             f32x4 f0, f1;
@@ -347,24 +359,6 @@ __device__ __forceinline__ void mv_generate(const ffn_mlp_chain& ch, const ffn_s
         f32x4* dst = w.xbuf + (k & 15) * kMvKbVecs + fb * kMvBlkVecs + w.lane;
 #pragma unroll
         for (int part = 0; part < 3; ++part) dst[64 * part] = __builtin_bit_cast(f32x4, fp[part]);
-    };
-    int G = rank;
-    for (; G + stride < count; G += 2 * stride) {
-        float fa[8], fb8[8];
-        if (k0 + G + stride < g_trig) {            // (both items all-trig: one basic block, the chains interleave)
-            features16_lockstep<true>(enc, k0 + G, w.h, p0, p1, p2, fa);
-            features16_lockstep<true>(enc, k0 + G + stride, w.h, p0, p1, p2, fb8);
-        } else {
-            item(G, fa);
-            item(G + stride, fb8);
-        }
-        emit(G, fa);
-        emit(G + stride, fb8);
-    }
-    if (G < count) {
-        float fa[8];
-        item(G, fa);
-        emit(G, fa);
     }
 }
 
@@ -373,74 +367,68 @@ __device__ __forceinline__ int64_t mv_mask_at(int slot, int64_t num_blocks, int6
     return (((int64_t)slot * num_blocks + block) * 64 + lane) * 16 + 4 * (o >> 1) + ((o & 1) ? 0 : 2);
 }
 
-// The epilogue of tile o (accumulators in acc): ReLU, sign bits, slab stores, fused head, the
-// three-way split into res -- everything but the X stores.
+// The epilogue of (tile o, this wave's block): ReLU, sign bits, slab stores, fused head, the three-way
+// split into res -- everything but the X stores.
 __device__ __forceinline__ void mv_epilogue(const ffn_mlp_chain& ch, const ffn_step& L, bool last_step, const MvCtx& w,
-                                            MvVec& v, int o, const f32x16 (&acc)[2], bf16x8 (&res)[2][2][3]) {
+                                            MvVec& v, int o, const f32x16& acc, bf16x8 (&res)[2][3]) {
     const bool fused_head = L.head_off >= 0;
     const float* hw = w.bias_lds + (fused_head ? L.head_off : 0) + 4 + 16 * w.h;
     if (fused_head && o == 0 && w.h == 0) {
         const f32x4 hb = *reinterpret_cast<const f32x4*>(w.bias_lds + L.head_off);
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) v.logit[b][c] += hb[c];
+        for (int c = 0; c < 4; ++c) v.logit[c] += hb[c];
     }
     const int relu_floor = L.relu ? 0 : (int)0x80000000;
     int save_s = w.s, save_h = w.h, e_lane = w.lane;
     asm volatile("" : "+v"(save_s), "+v"(save_h), "+v"(e_lane));     // (see mlp_bf16.hip: no hoisted address tables)
+    const int64_t block = w.block0 + w.sub;
+    const bool live = block < w.num_blocks;
+    f32x4* save_out = nullptr;
+    if (w.saved != nullptr && L.out_slot >= 0 && live)
+        save_out = reinterpret_cast<f32x4*>(w.saved + ch.slot_offset[L.out_slot] * w.num_blocks * 32) +
+                   block * (int64_t)(ch.slot_channels[L.out_slot] * 8);
+    unsigned sign_bits = 0u;
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const bool live = w.block0 + b < w.num_blocks;
-        f32x4* save_out = nullptr;
-        if (w.saved != nullptr && L.out_slot >= 0 && live)
-            save_out = reinterpret_cast<f32x4*>(w.saved + ch.slot_offset[L.out_slot] * w.num_blocks * 32) +
-                       (w.block0 + b) * (int64_t)(ch.slot_channels[L.out_slot] * 8);
-        unsigned sign_bits = 0u;
+    for (int half = 0; half < 2; ++half) {
+        float y[8];
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            float y[8];
+        for (int j = 0; j < 8; ++j) {
+            const float a = acc[8 * half + j];
+            sign_bits = __builtin_amdgcn_alignbit(sign_bits, __builtin_bit_cast(unsigned, 0.0f - a), 31);
+            y[j] = __builtin_bit_cast(float, __builtin_elementwise_max(__builtin_bit_cast(int, a), relu_floor));
+        }
+        if (save_out != nullptr) {
+            f32x4 y0, y1;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) { y0[p] = y[p]; y1[p] = y[4 + p]; }
+            const int cq = 2 * (4 * o + 2 * half) + save_h;
+            __builtin_nontemporal_store(y0, &save_out[saved_index16(cq, save_s)]);
+            __builtin_nontemporal_store(y1, &save_out[saved_index16(cq + 2, save_s)]);
+        }
+        if (fused_head) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float a = acc[b][8 * half + j];
-                sign_bits = __builtin_amdgcn_alignbit(sign_bits, __builtin_bit_cast(unsigned, 0.0f - a), 31);
-                y[j] = __builtin_bit_cast(float, __builtin_elementwise_max(__builtin_bit_cast(int, a), relu_floor));
-            }
-            if (save_out != nullptr) {
-                f32x4 y0, y1;
+                const int group = 4 * o + 2 * half + (j >> 2);
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(hw + group * 32 + (j & 3) * 4);
 #pragma unroll
-                for (int p = 0; p < 4; ++p) { y0[p] = y[p]; y1[p] = y[4 + p]; }
-                const int cq = 2 * (4 * o + 2 * half) + save_h;
-                __builtin_nontemporal_store(y0, &save_out[saved_index16(cq, save_s)]);
-                __builtin_nontemporal_store(y1, &save_out[saved_index16(cq + 2, save_s)]);
+                for (int c = 0; c < 4; ++c) v.logit[c] = __builtin_fmaf(y[j], w4[c], v.logit[c]);
             }
-            if (fused_head) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int group = 4 * o + 2 * half + (j >> 2);
-                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(hw + group * 32 + (j & 3) * 4);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) v.logit[b][c] = __builtin_fmaf(y[j], w4[c], v.logit[b][c]);
-                }
-            }
-            if (!last_step) split8x3_lockstep(y, res[b][half][0], res[b][half][1], res[b][half][2]);
         }
-        if (w.masks != nullptr && L.relu && L.mask_slot >= 0 && live)
-            *reinterpret_cast<uint16_t*>(w.masks + mv_mask_at(L.mask_slot, w.num_blocks, w.block0 + b, e_lane, o)) =
-                (uint16_t)(sign_bits & 0xffffu);
+        if (!last_step) split8x3_lockstep(y, res[half][0], res[half][1], res[half][2]);
     }
+    if (w.masks != nullptr && L.relu && L.mask_slot >= 0 && live)
+        *reinterpret_cast<uint16_t*>(w.masks + mv_mask_at(L.mask_slot, w.num_blocks, block, e_lane, o)) =
+            (uint16_t)(sign_bits & 0xffffu);
 }
 
-// tile o's output = K blocks 2 o, 2 o + 1 of the next X image
-__device__ __forceinline__ void mv_store_x(const MvCtx& w, int o, const bf16x8 (&res)[2][2][3]) {
+// (tile o, this wave's block) of the output = its share of K blocks 2 o, 2 o + 1 of the next X image
+__device__ __forceinline__ void mv_store_x(const MvCtx& w, int o, const bf16x8 (&res)[2][3]) {
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int half = 0; half < 2; ++half) {
+        f32x4* dst = w.xbuf + (2 * o + half) * kMvKbVecs + w.sub * kMvBlkVecs + w.lane;
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            f32x4* dst = w.xbuf + (2 * o + half) * kMvKbVecs + b * kMvBlkVecs + w.lane;
-#pragma unroll
-            for (int part = 0; part < 3; ++part) dst[64 * part] = __builtin_bit_cast(f32x4, res[b][half][part]);
-        }
+        for (int part = 0; part < 3; ++part) dst[64 * part] = __builtin_bit_cast(f32x4, res[half][part]);
+    }
 }
 
 // a step seen from a vector wave, from its barrier S2 on (what comes before differs: the features'
@@ -449,8 +437,8 @@ __device__ __forceinline__ void mv_store_x(const MvCtx& w, int o, const bf16x8 (
 // matrix waves start the next pass on them right behind S4.
 __device__ __forceinline__ void mv_vector_tail(const ffn_mlp_chain& ch, const ffn_step& L, bool last_step,
                                                const MvCtx& w, MvVec& v, const MvVec* next, int64_t next_block0) {
-    f32x16 acc[2];
-    bf16x8 res[2][2][3];
+    f32x16 acc;
+    bf16x8 res[2][3];
     MV_STAMP(w, 60);
     mv_barrier();                                  // S2: tile A handed over
     MV_STAMP(w, 61);
@@ -464,7 +452,7 @@ __device__ __forceinline__ void mv_vector_tail(const ffn_mlp_chain& ch, const ff
     mv_barrier();                                  // S3b: K blocks 0..7 of the next image are in X
     MV_STAMP(w, 65);
     if (next != nullptr) {
-        mv_generate(ch, ch.step[0], w, *next, next_block0, 0, 8, (w.wave - 4) >> 1, 2);
+        mv_generate(ch, ch.step[0], w, *next, next_block0, 0, 8, (w.wave - 4) >> 1, 2 * kMvVecPerSimd);
         MV_STAMP(w, 68);
     }
     mv_barrier();                                  // S4: tile B handed over, X consumed
@@ -479,17 +467,14 @@ __device__ __forceinline__ void mv_vector_tail(const ffn_mlp_chain& ch, const ff
 // the SIMD pairs' partial logits of a pass meet through LDS: every vector wave leaves its sums there, and
 // behind the next barrier (F_0 of the next pass) waves 4 and 5 add the four up, a block each
 __device__ __forceinline__ void mv_leave_logits(const MvCtx& w, const MvVec& v) {
+    f32x4 part;
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        f32x4 part;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) part[c] = v.logit[b][c] + __shfl_xor(v.logit[b][c], 32);
-        if (w.h == 0) w.logit_lds[(w.m * 2 + b) * 32 + w.s] = part;
-    }
+    for (int c = 0; c < 4; ++c) part[c] = v.logit[c] + __shfl_xor(v.logit[c], 32);
+    if (w.h == 0) w.logit_lds[(w.m * 2 + w.sub) * 32 + w.s] = part;
 }
 __device__ __forceinline__ void mv_collect_logits(const MvCtx& w, int64_t block0, int64_t n, float* logits) {
-    if (w.wave < 6 && w.h == 0) {
-        const int b = w.wave - 4;
+    if (w.m == 0 && w.h == 0) {                    // (waves 4 and 8: a block each)
+        const int b = w.sub;
         const int64_t block = block0 + b;
         const int64_t sample = block * 32 + w.s;
         f32x4 out = w.logit_lds[b * 32 + w.s];
@@ -549,6 +534,7 @@ mlp_forward_bf16_mv_kernel(const ffn_mlp_chain ch, const uint16_t* __restrict__ 
     w.s = w.lane & 31;
     w.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     w.m = w.wave & 3;
+    w.sub = w.wave >= 4 ? (w.wave - 4) >> 2 : 0;
     w.xbuf = reinterpret_cast<f32x4*>(smem);
     w.hand = reinterpret_cast<f32x4*>(smem + kMvXBytes);
     w.logit_lds = reinterpret_cast<f32x4*>(smem + kMvXBytes + kMvHandBytes + kEncTableBytes + kMvBiasFloats * 4 + kMvMaxUnits * 4);
@@ -582,7 +568,7 @@ mlp_forward_bf16_mv_kernel(const ffn_mlp_chain ch, const uint16_t* __restrict__ 
     // ---- the first pass's first segment of features: every wave generates (2 items each)
     MvVec v, vnext;
     inputs_of(blockIdx.x, v);
-    mv_generate(ch, L0, w, v, (int64_t)blockIdx.x * 2, 0, 8, w.wave >> 1, 4);
+    mv_generate(ch, L0, w, v, (int64_t)blockIdx.x * 2, 0, 8, w.wave >> 1, kMvWaves / 2);
     mv_barrier();                                                                            // P1
 
     if (matrix) {
@@ -607,7 +593,7 @@ mlp_forward_bf16_mv_kernel(const ffn_mlp_chain ch, const uint16_t* __restrict__ 
 #endif
             MV_STAMP(w, 1);
             mv_matrix_features(L0, w, r);
-            for (int li = 1; li < ch.num_steps; ++li) mv_matrix_hidden(ch.step[li], w, r);
+            for (int li = 1; li < ch.num_steps; ++li) mv_matrix_hidden(ch.step[li], li + 1 == ch.num_steps, w, r);
         }
         mv_barrier();                                                                        // R: the last pass's logits
         return;
@@ -626,11 +612,9 @@ mlp_forward_bf16_mv_kernel(const ffn_mlp_chain ch, const uint16_t* __restrict__ 
         const bool has_next = pass + gridDim.x < passes;
         if (has_next) inputs_of(pass + gridDim.x, vnext);
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) v.logit[b][c] = 0.0f;
+        for (int c = 0; c < 4; ++c) v.logit[c] = 0.0f;
         for (int seg = 1; seg < segments; ++seg) {
-            mv_generate(ch, L0, w, v, w.block0, 8 * seg, 8, (w.wave - 4) >> 1, 2);
+            mv_generate(ch, L0, w, v, w.block0, 8 * seg, 8, (w.wave - 4) >> 1, 2 * kMvVecPerSimd);
             MV_STAMP(w, 50);
             mv_barrier();                                                                    // F_{seg-1}
             MV_STAMP(w, 51);
