@@ -108,11 +108,12 @@ __device__ __forceinline__ void mv_barrier() {
 // the matrix wave's registers that live across tiles, steps and passes
 struct MvMat {
     bf16x8 wr[4][3];               // weight ring: slot = unit & 3, three parts
-    // operands of the K block being multiplied, per 32-sample block: the hi parts double-buffered (a K
-    // block's last product needs them), the mid and lo parts REPLACED IN PLACE behind their last use
-    // (lo: the first product, mid: the fourth) by those of the next K block -- 32 registers instead of 48:
-    // with three waves per SIMD a wave has 168
-    bf16x8 xh[2][2], xm[2], xl[2];
+    // operands of the K block being multiplied, per 32-sample block: the hi and mid parts double-buffered
+    // (the last products of a K block need them), the lo part REPLACED IN PLACE behind its only use (the
+    // first product) by the next K block's -- 40 registers instead of 48: with three waves per SIMD a
+    // wave has 168.  (The mid part in place too -- behind the fourth product, eight matrix instructions
+    // before its next use -- is 8 registers less and measurably slower: the LDS round trip shows.)
+    bf16x8 xh[2][2], xm[2][2], xl[2];
     i32x4 cur;                     // refill entries of the coming trip
     int tq;                        // index of `cur` in the table
 };
@@ -127,11 +128,14 @@ typedef const f32x4 __attribute__((address_space(1)))* mv_gptr;
 
 // One unit: the 12 matrix instructions of (one tile, one K block) out of ring slot J and hi-operand
 // set HB.  READX: the operands of the next K block stream in behind the matrix instructions that free
-// their registers (lo behind the first product, hi -- other set -- behind the second, mid behind the
-// fourth); the ring slot of the unit before this one is requested again (three units ahead) behind
+// their registers (lo behind the first product; hi and mid -- other set -- behind the second and third);
+// the ring slot of the unit before this one is requested again (three units ahead) behind
 // the others.  bar (uniform): a workgroup barrier in front of the unit -- in front of the operand reads
 // it guards.  Every group (one matrix instruction, at most one memory instruction) is fenced.
-template <int J, int HB, bool READX>
+// FIRST: the first unit of a tile's K loop -- acc[0] holds the BIAS (read straight from LDS into its
+// registers, mv_load_bias), and the first product of block 1 accumulates onto it before the first
+// product of block 0 overwrites it: no accumulator is ever initialised by vector instructions.
+template <int J, int HB, int READX, bool FIRST = false>       // READX: bit 0 = the lo parts (in place), bit 1 = the hi and mid parts (other set)
 __device__ __forceinline__ void mv_unit(const MvCtx& w, f32x16 (&acc)[2], MvMat& r, const f32x4* xnext, mv_gptr refill, bool bar) {
     typedef MvProducts P;
     const int lane = w.lane;
@@ -144,21 +148,34 @@ __device__ __forceinline__ void mv_unit(const MvCtx& w, f32x16 (&acc)[2], MvMat&
     auto group = [&](auto qc, auto bc) {
         constexpr int q = decltype(qc)::value, b = decltype(bc)::value;
         constexpr int g = 2 * q + b;
-        const bf16x8 operand = P::X[q] == 0 ? r.xh[HB][b] : (P::X[q] == 1 ? r.xm[b] : r.xl[b]);
-        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.wr[J][P::W[q]], operand, acc[b], 0, 0, 0);
-        if constexpr (READX && q == 0) r.xl[b] = __builtin_bit_cast(bf16x8, xnext[b * kMvBlkVecs + 2 * 64]);
-        if constexpr (READX && q == 1) r.xh[HB ^ 1][b] = __builtin_bit_cast(bf16x8, xnext[b * kMvBlkVecs]);
-        if constexpr (READX && q == 3) r.xm[b] = __builtin_bit_cast(bf16x8, xnext[b * kMvBlkVecs + 64]);
-        // the weight requests: behind products 2 (both blocks) and 4 (block 0) -- groups 4, 5, 8 -- with
-        // operand reads in the unit, else behind groups 2, 3, 4
-        constexpr int slot = READX ? (g == 4 ? 0 : (g == 5 ? 1 : (g == 8 ? 2 : -1))) : (g >= 2 && g < 5 ? g - 2 : -1);
+        const bf16x8 operand = P::X[q] == 0 ? r.xh[HB][b] : (P::X[q] == 1 ? r.xm[HB][b] : r.xl[b]);
+        if constexpr (FIRST && q == 0)
+            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.wr[J][P::W[q]], operand, acc[0], 0, 0, 0);
+        else
+            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.wr[J][P::W[q]], operand, acc[b], 0, 0, 0);
+#ifdef MV_KO_PAIR_X
+        if constexpr (READX == 3) {
+#else
+        {
+#endif
+        if constexpr ((READX & 1) != 0 && q == 0) r.xl[b] = __builtin_bit_cast(bf16x8, xnext[b * kMvBlkVecs + 2 * 64]);
+        if constexpr ((READX & 2) != 0 && q == 1) r.xh[HB ^ 1][b] = __builtin_bit_cast(bf16x8, xnext[b * kMvBlkVecs]);
+        if constexpr ((READX & 2) != 0 && q == 2) r.xm[HB ^ 1][b] = __builtin_bit_cast(bf16x8, xnext[b * kMvBlkVecs + 64]);
+        }
+        // the weight requests: behind groups 6, 7, 8
+        constexpr int slot = g >= 6 && g < 9 ? g - 6 : -1;
+#ifdef MV_KO_PAIR_W
+        if constexpr (slot >= 0 && READX == 3)
+#else
         if constexpr (slot >= 0)
+#endif
             r.wr[(J + 3) & 3][slot] = __builtin_bit_cast(bf16x8, refill[slot * 64 + lane]);
         __builtin_amdgcn_sched_barrier(0);
     };
     typedef std::integral_constant<int, 0> i0;
     typedef std::integral_constant<int, 1> i1;
-    group(i0{}, i0{}); group(i0{}, i1{});
+    if constexpr (FIRST) { group(i0{}, i1{}); group(i0{}, i0{}); }
+    else { group(i0{}, i0{}); group(i0{}, i1{}); }
     group(i1{}, i0{}); group(i1{}, i1{});
     group(std::integral_constant<int, 2>{}, i0{}); group(std::integral_constant<int, 2>{}, i1{});
     group(std::integral_constant<int, 3>{}, i0{}); group(std::integral_constant<int, 3>{}, i1{});
@@ -178,45 +195,35 @@ __device__ __forceinline__ void mv_trip_bases(const MvCtx& w, MvMat& r, mv_gptr 
     r.cur = w.tbl4[r.tq];
 }
 
-// The K loop of ONE tile over `trips` x 4 K blocks of X from K block g0 (operands of g0 already in
-// set 0); the last unit streams K block g_after in -- the first one of whatever comes next.
-// bars: bit 4 t + j = barrier in front of unit j of trip t.
+// The K loop of ONE tile over `trips` x 4 K blocks of X from K block g0 (operands of g0 already in the
+// registers); the last unit streams K block g_after in -- the first one of whatever comes next.
+// bars: bit 4 t + j = barrier in front of unit j of trip t.  FIRST: the tile starts here (acc[0] = bias).
+template <bool FIRST = false>
 __device__ __forceinline__ void mv_k_loop(const MvCtx& w, MvMat& r, f32x16 (&acc)[2], int g0, int trips, int g_after,
                                           unsigned bars) {
     const f32x4* xb = w.xbuf + w.lane;
+    if constexpr (FIRST) {
+        mv_gptr base[4];
+        mv_trip_bases(w, r, base);
+        mv_unit<0, 0, 3, true>(w, acc, r, xb + (g0 + 1) * kMvKbVecs, base[0], (bars & 1u) != 0);
+        mv_unit<1, 1, 3>(w, acc, r, xb + (g0 + 2) * kMvKbVecs, base[1], (bars & 2u) != 0);
+        mv_unit<2, 0, 3>(w, acc, r, xb + (g0 + 3) * kMvKbVecs, base[2], (bars & 4u) != 0);
+        mv_unit<3, 1, 3>(w, acc, r, xb + (trips == 1 ? g_after : g0 + 4) * kMvKbVecs, base[3], (bars & 8u) != 0);
+    }
     // (not unrolled: with constant trip counts hipcc unrolls, turns the operand addresses beyond the 64 KiB
     // immediate range into values it keeps -- and SPILLS them: scratch traffic inside the stream, in
     // order with the weight requests)
 #pragma nounroll
-    for (int t = 0; t < trips; ++t) {
+    for (int t = FIRST ? 1 : 0; t < trips; ++t) {
         const int g = g0 + 4 * t;
         const int g4 = t + 1 == trips ? g_after : g + 4;
         mv_gptr base[4];
         mv_trip_bases(w, r, base);
         const unsigned bt = bars >> (4 * t);
-        mv_unit<0, 0, true>(w, acc, r, xb + (g + 1) * kMvKbVecs, base[0], (bt & 1u) != 0);
-        mv_unit<1, 1, true>(w, acc, r, xb + (g + 2) * kMvKbVecs, base[1], (bt & 2u) != 0);
-        mv_unit<2, 0, true>(w, acc, r, xb + (g + 3) * kMvKbVecs, base[2], (bt & 4u) != 0);
-        mv_unit<3, 1, true>(w, acc, r, xb + g4 * kMvKbVecs, base[3], (bt & 8u) != 0);
-    }
-}
-
-// `pairs` x 2 K blocks, BOTH tiles per K block (features-only steps): units (k, A), (k, B), (k + 1, A),
-// (k + 1, B); the B units stream the next K block's operands in (both units of a K block multiply out
-// of the same registers).  Every fourth trip (the last one of a segment of eight K blocks) has a
-// barrier in front of (k + 1, B) -- in front of the reads of the next segment's first K block.
-__device__ __forceinline__ void mv_pair_loop(const MvCtx& w, MvMat& r, f32x16 (&acc_a)[2], f32x16 (&acc_b)[2],
-                                             int pairs) {
-    const f32x4* xb = w.xbuf + w.lane;
-#pragma nounroll
-    for (int t = 0; t < pairs; ++t) {
-        const int k = 2 * t;
-        mv_gptr base[4];
-        mv_trip_bases(w, r, base);
-        mv_unit<0, 0, false>(w, acc_a, r, nullptr, base[0], false);
-        mv_unit<1, 0, true>(w, acc_b, r, xb + ((k + 1) & 15) * kMvKbVecs, base[1], false);
-        mv_unit<2, 1, false>(w, acc_a, r, nullptr, base[2], false);
-        mv_unit<3, 1, true>(w, acc_b, r, xb + ((k + 2) & 15) * kMvKbVecs, base[3], (t & 3) == 3);
+        mv_unit<0, 0, 3>(w, acc, r, xb + (g + 1) * kMvKbVecs, base[0], (bt & 1u) != 0);
+        mv_unit<1, 1, 3>(w, acc, r, xb + (g + 2) * kMvKbVecs, base[1], (bt & 2u) != 0);
+        mv_unit<2, 0, 3>(w, acc, r, xb + (g + 3) * kMvKbVecs, base[2], (bt & 4u) != 0);
+        mv_unit<3, 1, 3>(w, acc, r, xb + g4 * kMvKbVecs, base[3], (bt & 8u) != 0);
     }
 }
 
@@ -226,20 +233,19 @@ __device__ __forceinline__ void mv_read_x0(const MvCtx& w, MvMat& r, int G) {
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         r.xh[0][b] = __builtin_bit_cast(bf16x8, p[b * kMvBlkVecs]);
-        r.xm[b] = __builtin_bit_cast(bf16x8, p[b * kMvBlkVecs + 64]);
+        r.xm[0][b] = __builtin_bit_cast(bf16x8, p[b * kMvBlkVecs + 64]);
         r.xl[b] = __builtin_bit_cast(bf16x8, p[b * kMvBlkVecs + 128]);
     }
 }
 
-__device__ __forceinline__ void mv_init_bias(const MvCtx& w, const ffn_step& L, int o, f32x16 (&acc)[2]) {
+// the bias of output tile o in the accumulator layout of one block, straight into a tile's acc[0] (see FIRST)
+__device__ __forceinline__ void mv_load_bias(const MvCtx& w, const ffn_step& L, int o, f32x16& acc0) {
     const float* bv = w.bias_lds + L.b_off + 32 * o + 4 * w.h;       // (mv_covers: the whole bias buffer is staged)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const f32x4 b4 = *reinterpret_cast<const f32x4*>(bv + 8 * q);
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int p = 0; p < 4; ++p) acc[b][4 * q + p] = b4[p];
+        for (int p = 0; p < 4; ++p) acc0[4 * q + p] = b4[p];
     }
 }
 
@@ -276,45 +282,55 @@ __device__ __forceinline__ void mv_take_over(const MvCtx& w, f32x16& acc) {
 // Barriers of a step, in order (the vector waves' code has the same list):
 //   features-only: F_0 .. F_{segments-2} (segment s + 1 is in X, segment s consumed), S2, S3, S3b, S4
 //   hidden:        S1, S2, S3, S3b, S4
-__device__ __forceinline__ void mv_matrix_features(const ffn_step& L, const MvCtx& w, MvMat& r) {
+// (the accumulators of the two tiles live across steps: the barrier that publishes a hand-over sits in
+// front of the SECOND unit of whatever the matrix wave multiplies next -- the hand-over's LDS stores and
+// the barrier's wait for them run under the first unit's matrix instructions)
+struct MvAcc {
+    f32x16 a[2], b[2];
+};
+
+__device__ __forceinline__ void mv_matrix_features(const ffn_step& L, const ffn_step& L1, const MvCtx& w, MvMat& r, MvAcc& c) {
     const int segments = L.aux_groups >> 4;        // (K blocks: a multiple of sixteen, mv_covers)
-    f32x16 acc_a[2], acc_b[2];
-    mv_init_bias(w, L, w.m, acc_a);
-    mv_init_bias(w, L, w.m + 4, acc_b);
+    mv_load_bias(w, L, w.m, c.a[0]);
+    mv_load_bias(w, L, w.m + 4, c.b[0]);
     mv_read_x0(w, r, 0);                           // (segment 0 is in X: the first pass's prologue, or S4 of the pass before)
     MV_STAMP(w, 9);
-    mv_pair_loop(w, r, acc_a, acc_b, 4 * (segments - 1));                                    // F_0 .. F_{segments-2}
+    // every segment tile by tile (eight K blocks of tile A, then the same eight of tile B): the barrier F
+    // in front of the last unit of B -- in front of its reads of the next segment's first K block
+    MV_STAMP(w, 32);
+    mv_k_loop<true>(w, r, c.a, 0, 2, 0, 0u);
+    mv_k_loop<true>(w, r, c.b, 0, 2, 8, 0x80u);                                              // F_0: unit 7
+#pragma nounroll
+    for (int seg = 1; seg + 1 < segments; ++seg) {
+        const int g0 = (seg & 1) * 8;
+        MV_STAMP(w, 32);
+        mv_k_loop(w, r, c.a, g0, 2, g0, 0u);
+        mv_k_loop(w, r, c.b, g0, 2, g0 ^ 8, 0x80u);                                          // F_seg: unit 7
+    }
     MV_STAMP(w, 10);
-    // the last segment (K blocks 8..15 of X), tile by tile
-    mv_k_loop(w, r, acc_a, 8, 2, 8, 0u);
+    // the last segment (K blocks 8..15 of X)
+    mv_k_loop(w, r, c.a, 8, 2, 8, 0u);
     MV_STAMP(w, 11);
-    mv_hand_over(w, acc_a);
-    mv_barrier();                                                                            // S2
-    MV_STAMP(w, 12);
-    mv_k_loop(w, r, acc_b, 8, 2, 0, 0x88u);                                                  // S3, S3b: units 3, 7
+    mv_hand_over(w, c.a);
+    mv_load_bias(w, L1, w.m, c.a[0]);              // (tile A of the next step starts from it)
+    mv_k_loop(w, r, c.b, 8, 2, 0, 0xA2u);                                                    // S2, S3, S3b: units 1, 5, 7
     MV_STAMP(w, 13);
-    mv_hand_over(w, acc_b);
-    mv_barrier();                                                                            // S4
-    MV_STAMP(w, 14);
+    // (tile B is handed over in front of the next step's tile A)
 }
 
-__device__ __forceinline__ void mv_matrix_hidden(const ffn_step& L, bool last_step, const MvCtx& w, MvMat& r) {
-    f32x16 acc_a[2], acc_b[2];
-    mv_init_bias(w, L, w.m, acc_a);
-    mv_init_bias(w, L, w.m + 4, acc_b);
+__device__ __forceinline__ void mv_matrix_hidden(const ffn_step& L, const ffn_step& next, bool last_step, const MvCtx& w,
+                                                 MvMat& r, MvAcc& c) {
     MV_STAMP(w, 20);
-    mv_k_loop(w, r, acc_a, 0, 4, 0, 0x80u);                                                  // S1: unit 7
+    mv_hand_over(w, c.b);                          // tile B of the step before
+    mv_load_bias(w, L, w.m + 4, c.b[0]);
+    mv_k_loop<true>(w, r, c.a, 0, 4, 0, 0x82u);                                              // S4, S1: units 1, 7
     MV_STAMP(w, 21);
-    mv_hand_over(w, acc_a);
-    mv_barrier();                                                                            // S2
-    MV_STAMP(w, 22);
+    mv_hand_over(w, c.a);
+    if (!last_step) mv_load_bias(w, next, w.m, c.a[0]);
     // (the last step stores nothing into X: S3b right behind S3, and the vector waves have the rest of
     // this K loop for the next pass's first segment of features)
-    mv_k_loop(w, r, acc_b, 0, 4, 0, last_step ? 0x180u : 0x880u);                            // S3, S3b: units 7, 11 (7, 8)
+    mv_k_loop<true>(w, r, c.b, 0, 4, 0, last_step ? 0x182u : 0x882u);                        // S2, S3, S3b: units 1, 7, 11 (1, 7, 8)
     MV_STAMP(w, 23);
-    mv_hand_over(w, acc_b);
-    mv_barrier();                                                                            // S4
-    MV_STAMP(w, 24);
 }
 
 // ---------------------------------------------------------------------------------- the vector waves
@@ -491,13 +507,9 @@ __device__ __forceinline__ int mv_build_units(const ffn_mlp_chain& ch, int* unit
     for (int li = 0; li < ch.num_steps; ++li) {
         const int kb_act = ch.step[li].act_groups >> 1, kb_feat = ch.step[li].aux_groups >> 1;
         if (kb_act == 0) {
-            const int k_last = kb_feat - 8;
-            for (int k = 0; k < k_last; ++k) {
-                units[u++] = (flat + k) * 8;
-                units[u++] = (flat + k) * 8 + 4;
-            }
-            for (int t = 0; t < 2; ++t)
-                for (int k = k_last; k < kb_feat; ++k) units[u++] = (flat + k) * 8 + 4 * t;
+            for (int k0 = 0; k0 < kb_feat; k0 += 8)          // segment by segment, tile A then tile B
+                for (int t = 0; t < 2; ++t)
+                    for (int k = k0; k < k0 + 8; ++k) units[u++] = (flat + k) * 8 + 4 * t;
             flat += kb_feat;
         } else {
             for (int t = 0; t < 2; ++t)
@@ -575,6 +587,7 @@ mlp_forward_bf16_mv_kernel(const ffn_mlp_chain ch, const uint16_t* __restrict__ 
         // (the matrix pipe must never wait for an issue slot the partner's vector work took)
         __builtin_amdgcn_s_setprio(3);
         MvMat r;
+        MvAcc c;
         // units 0, 1, 2 into ring slots 0, 1, 2 (table entry T - 1 = units U-1, 0, 1, 2); entry 0 next
         const i32x4 first = w.tbl4[w.trips_total - 1];
 #pragma unroll
@@ -592,8 +605,14 @@ mlp_forward_bf16_mv_kernel(const ffn_mlp_chain ch, const uint16_t* __restrict__ 
             w.stamp_n = 0;
 #endif
             MV_STAMP(w, 1);
-            mv_matrix_features(L0, w, r);
-            for (int li = 1; li < ch.num_steps; ++li) mv_matrix_hidden(ch.step[li], li + 1 == ch.num_steps, w, r);
+            mv_matrix_features(L0, ch.step[1], w, r, c);
+            for (int li = 1; li < ch.num_steps; ++li) {
+                const bool last = li + 1 == ch.num_steps;
+                mv_matrix_hidden(ch.step[li], ch.step[last ? li : li + 1], last, w, r, c);
+            }
+            mv_hand_over(w, c.b);                  // (the last tile of the pass: nothing follows to carry its barrier)
+            mv_barrier();                                                                    // S4
+            MV_STAMP(w, 24);
         }
         mv_barrier();                                                                        // R: the last pass's logits
         return;

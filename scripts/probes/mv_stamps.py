@@ -16,22 +16,22 @@ NAMES = {1: "pass start", 2: "after P0", 3: "generated segment 0", 4: "after P1"
          10: "features: pair trips done", 11: "K(A) of the last segment done", 12: "A handed over, after S2",
          13: "K(B) done", 14: "B handed over, after S4", 20: "hidden: start", 21: "hidden: K(A) done",
          22: "hidden: after S2", 23: "hidden: K(B) done", 24: "hidden: after S4", 30: "  barrier in the stream: arrive",
-         31: "  barrier in the stream: leave", 40: "before R1", 41: "after R1", 50: "generated a segment",
+         31: "  barrier in the stream: leave", 32: "  feature segment (8 K blocks x 2 tiles, 192 matrix instructions)", 40: "before R1", 41: "after R1", 50: "generated a segment",
          51: "after F", 60: "before S2", 61: "after S2", 62: "epilogue A computed", 63: "after S3",
          64: "X stores of A", 65: "after S3b", 66: "after S4", 67: "epilogue B + X stores", 70: "before S1", 71: "after S1"}
 
 
-def build():
+def build(extra=(), out=OUT):
     sys.path.insert(0, ROOT)
     from fourier_feature_nets_amd import build as b
     b.build_library()
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     obj = os.path.join(b.CSRC, "build", "mlp_bf16_mv_stamps.o")
-    subprocess.run([b._hipcc()] + b.COMMON + b.SOURCES["mlp_bf16_mv.hip"] + ["-DMV_STAMPS", "-c",
+    subprocess.run([b._hipcc()] + b.COMMON + b.SOURCES["mlp_bf16_mv.hip"] + ["-DMV_STAMPS"] + list(extra) + ["-c",
                    os.path.join(b.CSRC, "mlp_bf16_mv.hip"), "-o", obj], check=True, capture_output=True)
     objects = [os.path.join(b.CSRC, "build", n.replace(".hip", ".o")) for n in b.SOURCES if n != "mlp_bf16_mv.hip"]
-    subprocess.run([b._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, obj] + objects, check=True)
-    print(OUT)
+    subprocess.run([b._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, obj] + objects, check=True)
+    print(out)
 
 
 def run(train):
@@ -72,5 +72,7 @@ def run(train):
 if __name__ == "__main__":
     if sys.argv[1] == "build":
         build()
+        for ko in sys.argv[2:]:                    # timing-only knock-outs: build MV_KO_PAIR_W MV_KO_PAIR_X
+            build(["-D" + ko], OUT.replace("mvstamps", "mvstamps_" + ko.lower()))
     else:
         run("--train" in sys.argv)
