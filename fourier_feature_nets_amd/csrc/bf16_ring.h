@@ -350,6 +350,9 @@ bool mv_covers(const ffn_mlp_chain* chain, int* num_units);
 int launch_forward_bf16x6_mv(const ffn_mlp_chain* chain, const uint16_t* packed_w, const float* bias,
                              const float* positions, const float* views, int64_t n, float* logits,
                              float* saved, uint32_t* masks, int num_units, void* stream);
+bool mv_covers_bwd(const ffn_mlp_chain* chain, int* num_units);
+int launch_backward_bf16x6_mv(const ffn_mlp_chain* chain, const uint16_t* packed_wt, const float* d_logits,
+                              int64_t n, const uint32_t* masks, float* dz, int num_units, void* stream);
 inline bool bf16x6_prefers_mv() {
     const char* v = getenv("FFN_BF16X6_ORG");
     return !(v != nullptr && v[0] == 'w');

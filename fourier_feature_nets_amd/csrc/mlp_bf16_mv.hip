@@ -132,11 +132,14 @@ typedef const f32x4 __attribute__((address_space(1)))* mv_gptr;
 // the ring slot of the unit before this one is requested again (three units ahead) behind
 // the others.  bar (uniform): a workgroup barrier in front of the unit -- in front of the operand reads
 // it guards.  Every group (one matrix instruction, at most one memory instruction) is fenced.
-// FIRST: the first unit of a tile's K loop -- acc[0] holds the BIAS (read straight from LDS into its
-// registers, mv_load_bias), and the first product of block 1 accumulates onto it before the first
-// product of block 0 overwrites it: no accumulator is ever initialised by vector instructions.
-template <int J, int HB, int READX, bool FIRST = false>       // READX: bit 0 = the lo parts (in place), bit 1 = the hi and mid parts (other set)
-__device__ __forceinline__ void mv_unit(const MvCtx& w, f32x16 (&acc)[2], MvMat& r, const f32x4* xnext, mv_gptr refill, bool bar) {
+// FIRST = 1: the first unit of a tile's K loop in a FORWARD chain -- acc[0] holds the BIAS (read straight
+// from LDS into its registers, mv_load_bias), and the first product of block 1 accumulates onto it
+// before the first product of block 0 overwrites it: no accumulator is ever initialised by vector
+// instructions.  FIRST = 2: a BACKWARD chain's -- the first products start from zero.
+// TWO (backward data): the five small partial products accumulate on `lo`, h.h on `acc` (mlp_bf16_ws.hip:
+// the matrix unit's accumulation is not round-to-nearest); they meet at the end of the K loop.
+template <int J, int HB, int READX, int FIRST = 0, bool TWO = false>       // READX: bit 0 = the lo parts (in place), bit 1 = the hi and mid parts (other set)
+__device__ __forceinline__ void mv_unit(const MvCtx& w, f32x16 (&acc)[2], f32x16 (&lo)[2], MvMat& r, const f32x4* xnext, mv_gptr refill, bool bar) {
     typedef MvProducts P;
     const int lane = w.lane;
     if (bar) {
@@ -149,10 +152,17 @@ __device__ __forceinline__ void mv_unit(const MvCtx& w, f32x16 (&acc)[2], MvMat&
         constexpr int q = decltype(qc)::value, b = decltype(bc)::value;
         constexpr int g = 2 * q + b;
         const bf16x8 operand = P::X[q] == 0 ? r.xh[HB][b] : (P::X[q] == 1 ? r.xm[HB][b] : r.xl[b]);
-        if constexpr (FIRST && q == 0)
+        if constexpr (TWO) {
+            const f32x16 zero = (f32x16)(0.0f);
+            if constexpr (q == 5)
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.wr[J][P::W[q]], operand, FIRST == 2 ? zero : acc[b], 0, 0, 0);
+            else
+                lo[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.wr[J][P::W[q]], operand, (FIRST == 2 && q == 0) ? zero : lo[b], 0, 0, 0);
+        } else if constexpr (FIRST == 1 && q == 0) {
             acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.wr[J][P::W[q]], operand, acc[0], 0, 0, 0);
-        else
+        } else {
             acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.wr[J][P::W[q]], operand, acc[b], 0, 0, 0);
+        }
 #ifdef MV_KO_PAIR_X
         if constexpr (READX == 3) {
 #else
@@ -174,7 +184,7 @@ __device__ __forceinline__ void mv_unit(const MvCtx& w, f32x16 (&acc)[2], MvMat&
     };
     typedef std::integral_constant<int, 0> i0;
     typedef std::integral_constant<int, 1> i1;
-    if constexpr (FIRST) { group(i0{}, i1{}); group(i0{}, i0{}); }
+    if constexpr (FIRST == 1) { group(i0{}, i1{}); group(i0{}, i0{}); }
     else { group(i0{}, i0{}); group(i0{}, i1{}); }
     group(i1{}, i0{}); group(i1{}, i1{});
     group(std::integral_constant<int, 2>{}, i0{}); group(std::integral_constant<int, 2>{}, i1{});
@@ -197,34 +207,40 @@ __device__ __forceinline__ void mv_trip_bases(const MvCtx& w, MvMat& r, mv_gptr 
 
 // The K loop of ONE tile over `trips` x 4 K blocks of X from K block g0 (operands of g0 already in the
 // registers); the last unit streams K block g_after in -- the first one of whatever comes next.
-// bars: bit 4 t + j = barrier in front of unit j of trip t.  FIRST: the tile starts here (acc[0] = bias).
-template <bool FIRST = false>
-__device__ __forceinline__ void mv_k_loop(const MvCtx& w, MvMat& r, f32x16 (&acc)[2], int g0, int trips, int g_after,
-                                          unsigned bars) {
+// bars: bit 4 t + j = barrier in front of unit j of trip t.  FIRST != 0: the tile starts here (1: acc[0]
+// = bias, 2: from zero).  TWO: see mv_unit.
+template <int FIRST, bool TWO>
+__device__ __forceinline__ void mv_k_loop2(const MvCtx& w, MvMat& r, f32x16 (&acc)[2], f32x16 (&lo)[2], int g0, int trips,
+                                           int g_after, unsigned bars) {
     const f32x4* xb = w.xbuf + w.lane;
-    if constexpr (FIRST) {
+    if constexpr (FIRST != 0) {
         mv_gptr base[4];
         mv_trip_bases(w, r, base);
-        mv_unit<0, 0, 3, true>(w, acc, r, xb + (g0 + 1) * kMvKbVecs, base[0], (bars & 1u) != 0);
-        mv_unit<1, 1, 3>(w, acc, r, xb + (g0 + 2) * kMvKbVecs, base[1], (bars & 2u) != 0);
-        mv_unit<2, 0, 3>(w, acc, r, xb + (g0 + 3) * kMvKbVecs, base[2], (bars & 4u) != 0);
-        mv_unit<3, 1, 3>(w, acc, r, xb + (trips == 1 ? g_after : g0 + 4) * kMvKbVecs, base[3], (bars & 8u) != 0);
+        mv_unit<0, 0, 3, FIRST, TWO>(w, acc, lo, r, xb + (g0 + 1) * kMvKbVecs, base[0], (bars & 1u) != 0);
+        mv_unit<1, 1, 3, 0, TWO>(w, acc, lo, r, xb + (g0 + 2) * kMvKbVecs, base[1], (bars & 2u) != 0);
+        mv_unit<2, 0, 3, 0, TWO>(w, acc, lo, r, xb + (g0 + 3) * kMvKbVecs, base[2], (bars & 4u) != 0);
+        mv_unit<3, 1, 3, 0, TWO>(w, acc, lo, r, xb + (trips == 1 ? g_after : g0 + 4) * kMvKbVecs, base[3], (bars & 8u) != 0);
     }
     // (not unrolled: with constant trip counts hipcc unrolls, turns the operand addresses beyond the 64 KiB
     // immediate range into values it keeps -- and SPILLS them: scratch traffic inside the stream, in
     // order with the weight requests)
 #pragma nounroll
-    for (int t = FIRST ? 1 : 0; t < trips; ++t) {
+    for (int t = FIRST != 0 ? 1 : 0; t < trips; ++t) {
         const int g = g0 + 4 * t;
         const int g4 = t + 1 == trips ? g_after : g + 4;
         mv_gptr base[4];
         mv_trip_bases(w, r, base);
         const unsigned bt = bars >> (4 * t);
-        mv_unit<0, 0, 3>(w, acc, r, xb + (g + 1) * kMvKbVecs, base[0], (bt & 1u) != 0);
-        mv_unit<1, 1, 3>(w, acc, r, xb + (g + 2) * kMvKbVecs, base[1], (bt & 2u) != 0);
-        mv_unit<2, 0, 3>(w, acc, r, xb + (g + 3) * kMvKbVecs, base[2], (bt & 4u) != 0);
-        mv_unit<3, 1, 3>(w, acc, r, xb + g4 * kMvKbVecs, base[3], (bt & 8u) != 0);
+        mv_unit<0, 0, 3, 0, TWO>(w, acc, lo, r, xb + (g + 1) * kMvKbVecs, base[0], (bt & 1u) != 0);
+        mv_unit<1, 1, 3, 0, TWO>(w, acc, lo, r, xb + (g + 2) * kMvKbVecs, base[1], (bt & 2u) != 0);
+        mv_unit<2, 0, 3, 0, TWO>(w, acc, lo, r, xb + (g + 3) * kMvKbVecs, base[2], (bt & 4u) != 0);
+        mv_unit<3, 1, 3, 0, TWO>(w, acc, lo, r, xb + g4 * kMvKbVecs, base[3], (bt & 8u) != 0);
     }
+}
+template <bool FIRST = false>
+__device__ __forceinline__ void mv_k_loop(const MvCtx& w, MvMat& r, f32x16 (&acc)[2], int g0, int trips, int g_after,
+                                          unsigned bars) {
+    mv_k_loop2<FIRST ? 1 : 0, false>(w, r, acc, acc, g0, trips, g_after, bars);
 }
 
 // the operand registers <- X K block G, hi set 0 (a cold start: the first step of a pass)
@@ -698,6 +714,276 @@ int launch_forward_bf16x6_mv(const ffn_mlp_chain* chain, const uint16_t* packed_
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMvLdsBytes);
     hipLaunchKernelGGL(mlp_forward_bf16_mv_kernel, dim3((unsigned)grid), dim3(kMvThreads), kMvLdsBytes,
                        (hipStream_t)stream, *chain, packed_w, bias, positions, views, n, logits, saved, masks, num_units);
+    return 0;
+}
+
+// ================================================================================== backward data
+// The same organisation for the backward-data chain of the same models: step 0 takes d(loss)/d(logits)
+// through the fused head (one K block of operands and a zero one, written by the vector waves), every
+// other step is 256 -> 256.  Two accumulators per (tile, block) -- one tile at a time in the matrix
+// wave's registers: it adds them up and hands the tile over before the next one starts.  The vector
+// waves' epilogue: the ReLU mask of the layer being differentiated, the dZ slab, the three-way split.
+constexpr size_t kMvBwdLdsBytes = (size_t)kMvXBytes + kMvHandBytes + kMvMaxUnits * 4;
+
+struct MvAcc2 {
+    f32x16 main[2], lo[2];
+};
+
+__device__ __forceinline__ void mv_meet_and_hand_over(const MvCtx& w, MvAcc2& c) {
+#pragma unroll
+    for (int b = 0; b < 2; ++b) c.main[b] += c.lo[b];
+    mv_hand_over(w, c.main);
+}
+
+// step 0 (the d_logits term only: X K blocks 0 and 1, both tiles in ONE trip of four units)
+__device__ __forceinline__ void mv_matrix_bwd_first(const MvCtx& w, MvMat& r, MvAcc2& c) {
+    const f32x4* xb = w.xbuf + w.lane;
+    mv_read_x0(w, r, 0);                           // (published by the prologue, or by S4 of the pass before)
+    mv_gptr base[4];
+    mv_trip_bases(w, r, base);
+    mv_unit<0, 0, 3, 2, true>(w, c.main, c.lo, r, xb + kMvKbVecs, base[0], false);
+    mv_unit<1, 1, 3, 0, true>(w, c.main, c.lo, r, xb, base[1], false);
+    mv_meet_and_hand_over(w, c);                   // tile A
+    mv_barrier();                                                                            // S2
+    mv_unit<2, 0, 3, 2, true>(w, c.main, c.lo, r, xb + kMvKbVecs, base[2], false);
+    mv_unit<3, 1, 0, 0, true>(w, c.main, c.lo, r, nullptr, base[3], false);
+    mv_barrier();                                                                            // S3: K blocks 0, 1 consumed
+    mv_meet_and_hand_over(w, c);                   // tile B (its barrier S4: in front of the next step's second unit)
+    mv_barrier();                                                                            // S3b: K blocks 0..7 of the next image are in X
+    mv_read_x0(w, r, 0);
+}
+
+__device__ __forceinline__ void mv_matrix_bwd_hidden(bool last_step, const MvCtx& w, MvMat& r, MvAcc2& c) {
+    mv_k_loop2<2, true>(w, r, c.main, c.lo, 0, 4, 0, 0x82u);                                 // S4, S1: units 1, 7
+    mv_meet_and_hand_over(w, c);                   // tile A
+    mv_k_loop2<2, true>(w, r, c.main, c.lo, 0, 4, 0, last_step ? 0x182u : 0x882u);           // S2, S3, S3b: units 1, 7, 11 (1, 7, 8)
+    mv_meet_and_hand_over(w, c);                   // tile B
+}
+
+struct MvVecB {
+    f32x4 dl;                      // d(loss)/d(logits) of the block this wave writes operands for (sub), lane's sample
+    const float* d_logits;
+    float* dz;
+    const char* masks;
+    int64_t n;
+};
+
+// the operand K blocks of step 0 for the pass at block0: K block 0 = the logits columns lg_col.. in K rows
+// 0..lg_n-1 (lane half 0), K block 1 = zero; waves m = 0, 1 of either block write one each
+__device__ __forceinline__ void mv_write_dlogits(const ffn_step& L, const MvCtx& w, const f32x4& dl) {
+    if (w.m >= 2) return;
+    const int G = w.m;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = L.lg_col + j;
+        const float d = c == 0 ? dl[0] : (c == 1 ? dl[1] : (c == 2 ? dl[2] : dl[3]));
+        v[j] = (G == 0 && w.h == 0 && j < L.lg_n && c < 4) ? d : 0.0f;
+        v[4 + j] = 0.0f;
+    }
+    bf16x8 dp[3];
+    split8x3(v, dp[0], dp[1], dp[2]);
+    f32x4* dst = w.xbuf + G * kMvKbVecs + w.sub * kMvBlkVecs + w.lane;
+#pragma unroll
+    for (int part = 0; part < 3; ++part) dst[64 * part] = __builtin_bit_cast(f32x4, dp[part]);
+}
+
+__device__ __forceinline__ f32x4 mv_load_dlogits(const MvCtx& w, const MvVecB& v, int64_t block0) {
+    int64_t block = block0 + w.sub;
+    const bool real = block < w.num_blocks;
+    block = real ? block : w.num_blocks - 1;
+    const int64_t sample = block * 32 + w.s;
+    // samples past n (the ragged tail of the last block) contribute zero
+    return (real && sample < v.n) ? reinterpret_cast<const f32x4*>(v.d_logits)[sample] : (f32x4)(0.0f);
+}
+
+__device__ __forceinline__ unsigned mv_load_mask(const ffn_step& L, const MvCtx& w, const MvVecB& v, int o) {
+    if (L.mask_slot < 0) return 0xffffu;
+    int64_t block = w.block0 + w.sub;
+    block = block < w.num_blocks ? block : w.num_blocks - 1;
+    return *reinterpret_cast<const uint16_t*>(v.masks + mv_mask_at(L.mask_slot, w.num_blocks, block, w.lane, o));
+}
+
+// the epilogue of (tile o, this wave's block): mask, dZ slab, the three-way split -- everything but the X stores
+__device__ __forceinline__ void mv_epilogue_bwd(const ffn_mlp_chain& ch, const ffn_step& L, bool last_step, const MvCtx& w,
+                                                const MvVecB& v, int o, unsigned word, const f32x16& acc, bf16x8 (&res)[2][3]) {
+    int save_s = w.s, save_h = w.h;
+    asm volatile("" : "+v"(save_s), "+v"(save_h));
+    const int64_t block = w.block0 + w.sub;
+    f32x4* save_out = nullptr;
+    if (L.out_slot >= 0 && block < w.num_blocks)
+        save_out = reinterpret_cast<f32x4*>(v.dz + ch.slot_offset[L.out_slot] * w.num_blocks * 32) +
+                   block * (int64_t)(ch.slot_channels[L.out_slot] * 8);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        float y[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int bit = 15 - (8 * half + j);
+            const int keep = ((int)(word << (31 - bit))) >> 31;
+            // (through a scalar: __builtin_bit_cast applied to the vector ELEMENT acc[i] reads element 0
+            // whatever i is -- hipcc 7.2; found by the parity check against the ws kernels)
+            const float a = acc[8 * half + j];
+            y[j] = __builtin_bit_cast(float, __builtin_bit_cast(int, a) & keep);
+        }
+        if (save_out != nullptr) {
+            f32x4 y0, y1;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) { y0[p] = y[p]; y1[p] = y[4 + p]; }
+            const int cq = 2 * (4 * o + 2 * half) + save_h;
+            __builtin_nontemporal_store(y0, &save_out[saved_index16(cq, save_s)]);
+            __builtin_nontemporal_store(y1, &save_out[saved_index16(cq + 2, save_s)]);
+        }
+        if (!last_step) split8x3_lockstep(y, res[half][0], res[half][1], res[half][2]);
+    }
+}
+
+// a step seen from a vector wave, from its barrier S2 on.  next: the LAST step of a pass that has a
+// successor writes the next pass's step-0 operands (K blocks 0, 1: free from S3 on) between S3b and S4.
+__device__ __forceinline__ void mv_vector_tail_bwd(const ffn_mlp_chain& ch, const ffn_step& L, bool last_step, const MvCtx& w,
+                                                   const MvVecB& v, bool next, const f32x4& dl_next) {
+    f32x16 acc;
+    bf16x8 res[2][3];
+    const unsigned word_a = mv_load_mask(L, w, v, w.m), word_b = mv_load_mask(L, w, v, w.m + 4);
+    mv_barrier();                                  // S2: tile A handed over
+    mv_take_over(w, acc);
+    mv_epilogue_bwd(ch, L, last_step, w, v, w.m, word_a, acc, res);
+    mv_barrier();                                  // S3: K blocks 0..7 of X are consumed
+    if (!last_step) mv_store_x(w, w.m, res);
+    mv_barrier();                                  // S3b: K blocks 0..7 of the next image are in X
+    if (next) mv_write_dlogits(ch.step[0], w, dl_next);
+    mv_barrier();                                  // S4: tile B handed over, X consumed
+    mv_take_over(w, acc);
+    mv_epilogue_bwd(ch, L, last_step, w, v, w.m + 4, word_b, acc, res);
+    if (!last_step) mv_store_x(w, w.m + 4, res);
+}
+
+__device__ __forceinline__ int mv_build_units_bwd(const ffn_mlp_chain& ch, int* units) {
+    int u = 0, flat = 0;
+    for (int li = 0; li < ch.num_steps; ++li) {
+        const int kb = (ch.step[li].act_groups >> 1) + (ch.step[li].aux_groups > 0 ? 2 : 0);
+        for (int t = 0; t < 2; ++t)
+            for (int k = 0; k < kb; ++k) units[u++] = (flat + k) * 8 + 4 * t;
+        flat += kb;
+    }
+    return u;
+}
+
+__global__ void __launch_bounds__(kMvThreads)
+mlp_backward_bf16_mv_kernel(const ffn_mlp_chain ch, const uint16_t* __restrict__ packed,
+                            const float* __restrict__ d_logits, int64_t n,
+                            const uint32_t* __restrict__ masks, float* __restrict__ dz, int num_units) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* tbl = reinterpret_cast<int*>(smem + kMvXBytes + kMvHandBytes);
+    if (threadIdx.x == 0) {
+        int* units = reinterpret_cast<int*>(smem);             // (X is not in use yet)
+        const int u_total = mv_build_units_bwd(ch, units);
+        for (int i = 0; i < u_total; ++i) tbl[i] = units[(i + 3) % u_total];
+    }
+    MvCtx w;
+    w.lane = threadIdx.x & 63;
+    w.h = w.lane >> 5;
+    w.s = w.lane & 31;
+    w.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    w.m = w.wave & 3;
+    w.sub = w.wave >= 4 ? (w.wave - 4) >> 2 : 0;
+    w.xbuf = reinterpret_cast<f32x4*>(smem);
+    w.hand = reinterpret_cast<f32x4*>(smem + kMvXBytes);
+    w.logit_lds = nullptr;
+    w.enc_table = nullptr;
+    w.bias_lds = nullptr;
+    w.bias_glb = nullptr;
+    w.tbl4 = reinterpret_cast<const i32x4*>(tbl);
+    w.trips_total = num_units >> 2;
+    w.gw = reinterpret_cast<const f32x4*>(packed + ch.step[0].w_off);
+    w.saved = nullptr;
+    w.masks = nullptr;
+    w.num_blocks = (n + 31) / 32;
+    const int64_t passes = (w.num_blocks + 1) / 2;
+    const bool matrix = w.wave < 4;
+    __syncthreads();                               // the unit table is staged
+
+    if (matrix) {
+        __builtin_amdgcn_s_setprio(3);
+        MvMat r;
+        MvAcc2 c;
+        const i32x4 first = w.tbl4[w.trips_total - 1];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int e = __builtin_amdgcn_readfirstlane(first[j + 1]);
+            mv_gptr base = (mv_gptr)(w.gw + (int64_t)(e + w.m) * kMvTileVecs);
+#pragma unroll
+            for (int part = 0; part < 3; ++part) r.wr[j][part] = __builtin_bit_cast(bf16x8, base[part * 64 + w.lane]);
+        }
+        r.tq = 0;
+        r.cur = w.tbl4[0];
+        mv_barrier();                                                                        // P1: the first pass's operands
+        asm volatile("" ::"v"(r.wr[2][2]));        // (see mv_matrix_features)
+        for (int64_t pass = blockIdx.x; pass < passes; pass += gridDim.x) {
+            mv_matrix_bwd_first(w, r, c);
+            for (int li = 1; li < ch.num_steps; ++li) mv_matrix_bwd_hidden(li + 1 == ch.num_steps, w, r, c);
+            mv_barrier();                                                                    // S4 of the last step
+        }
+        return;
+    }
+
+    // ---- a vector wave
+    MvVecB v;
+    v.d_logits = d_logits;
+    v.dz = dz;
+    v.masks = reinterpret_cast<const char*>(masks);
+    v.n = n;
+    w.block0 = (int64_t)blockIdx.x * 2;
+    v.dl = mv_load_dlogits(w, v, w.block0);
+    mv_write_dlogits(ch.step[0], w, v.dl);
+    mv_barrier();                                                                            // P1
+    for (int64_t pass = blockIdx.x; pass < passes; pass += gridDim.x) {
+        w.block0 = pass * 2;
+        const bool has_next = pass + gridDim.x < passes;
+        f32x4 dl_next = (f32x4)(0.0f);
+        if (has_next) dl_next = mv_load_dlogits(w, v, w.block0 + 2 * (int64_t)gridDim.x);
+        mv_vector_tail_bwd(ch, ch.step[0], false, w, v, false, dl_next);
+        for (int li = 1; li < ch.num_steps; ++li) {
+            const bool last = li + 1 == ch.num_steps;
+            mv_barrier();                                                                    // S1
+            mv_vector_tail_bwd(ch, ch.step[li], last, w, v, last && has_next, dl_next);
+        }
+    }
+}
+
+// backward chains this organisation covers: the d_logits term alone in step 0, then 256 -> 256 steps
+bool mv_covers_bwd(const ffn_mlp_chain* chain, int* num_units) {
+    if (chain->num_steps < 2 || chain->wide != 0) return false;
+    int units = 0;
+    for (int i = 0; i < chain->num_steps; ++i) {
+        const ffn_step& L = chain->step[i];
+        if (L.out_tiles != 8) return false;
+        if (i == 0) {
+            if (L.act_groups != 0 || L.aux_groups <= 0) return false;
+            units += 4;
+        } else {
+            if ((L.act_groups >> 1) != 16 || L.aux_groups != 0) return false;
+            units += 32;
+        }
+    }
+    if (units > kMvMaxUnits) return false;
+    *num_units = units;
+    return true;
+}
+
+int launch_backward_bf16x6_mv(const ffn_mlp_chain* chain, const uint16_t* packed_wt, const float* d_logits,
+                              int64_t n, const uint32_t* masks, float* dz, int num_units, void* stream) {
+    int cus = 256, dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int val = 0;
+        if (hipDeviceGetAttribute(&val, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && val > 0) cus = val;
+    }
+    const int64_t passes = ((n + 31) / 32 + 1) / 2;
+    const int64_t grid = passes < cus ? passes : cus;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_backward_bf16_mv_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMvBwdLdsBytes);
+    hipLaunchKernelGGL(mlp_backward_bf16_mv_kernel, dim3((unsigned)grid), dim3(kMvThreads), kMvBwdLdsBytes,
+                       (hipStream_t)stream, *chain, packed_wt, d_logits, n, masks, dz, num_units);
     return 0;
 }
 

@@ -1023,6 +1023,9 @@ int launch_forward_bf16x6(const ffn_mlp_chain* chain, const uint16_t* packed_w, 
 
 int launch_backward_bf16x6(const ffn_mlp_chain* chain, const uint16_t* packed_wt, const float* d_logits,
                            int64_t n, const uint32_t* masks, float* dz, void* stream) {
+    int mv_units = 0;
+    if (bf16x6_prefers_mv() && !bf16x6_nine_products() && mv_covers_bwd(chain, &mv_units))
+        return launch_backward_bf16x6_mv(chain, packed_wt, d_logits, n, masks, dz, mv_units, stream);
     if (bf16x6_nine_products()) ws_launch_bwd<WsSplit9>(chain, packed_wt, d_logits, n, masks, dz, stream);
     else ws_launch_bwd<WsSplit6>(chain, packed_wt, d_logits, n, masks, dz, stream);
     return 0;
@@ -1052,6 +1055,14 @@ static int check_chain_bf16x6(const char* what, const ffn_mlp_chain* chain, int6
         }
     }
     return 0;
+}
+
+extern "C" int ffn_mlp_bf16x6_organisation(const ffn_mlp_chain* chain, int backward) {
+    int units = 0;
+    if (chain == nullptr || !bf16x6_prefers_mv() || bf16x6_nine_products()) return 0;
+    if (backward) return mv_covers_bwd(chain, &units) ? 1 : 0;
+    const char* two = getenv("FFN_BF16X6_FWD_ACCS");
+    return ((two == nullptr || two[0] != '2') && mv_covers(chain, &units)) ? 1 : 0;
 }
 
 extern "C" int ffn_mlp_forward_bf16x6(const ffn_mlp_chain* chain, const uint16_t* packed_w, const float* bias,

@@ -860,6 +860,18 @@ class MlpProgram:
             return self.fwd16 is not None
         return precision == "f32"
 
+    def x6_organisation(self, backward: bool = False) -> str:
+        """Which workgroup organisation a bf16x6 launch of this chain takes (``ffn_mlp_bf16x6_organisation``):
+        "matrix/vector waves" (csrc/mlp_bf16_mv.hip: the tiny NeRF / Fourier MLP family) or "two waves
+        per SIMD" (csrc/mlp_bf16_ws.hip).  Same slab, mask and dZ bits either way; FFN_BF16X6_ORG=ws
+        keeps the second for every chain."""
+        chain = self.bwd_x6 if backward else self.fwd_x6
+        if chain is None:
+            raise NotImplementedError("no bf16x6 kernels for this chain")
+        fn = _lib.load().ffn_mlp_bf16x6_organisation
+        fn.restype = ctypes.c_int
+        return "matrix/vector waves" if fn(ctypes.byref(chain), ctypes.c_int(1 if backward else 0)) == 1 else "two waves per SIMD"
+
     def _x6_ready(self):
         if self.fwd_x6 is None:
             raise NotImplementedError("the bf16x6 kernels cover chains of <= 256 channels per layer "

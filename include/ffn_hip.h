@@ -499,7 +499,16 @@ int ffn_mlp_backward_data_bf16x3(const ffn_mlp_chain* chain, const uint16_t* pac
  * windows -- both read the slabs these kernels write (host: MlpProgram._plan_wgrad;
  * FFN_BF16X6_WGRAD=f32 keeps every unit on the exact-f32 kernel).
  * FFN_BF16X6_PRODUCTS=9 (environment, measurement only) multiplies out all nine partial products.
+ * Two workgroup organisations sit behind these entry points (same packs, same slab / mask / dZ formats,
+ * bit-identical slabs, masks and dZ): chains whose first step is features-only (16 j K blocks) and whose
+ * other steps are 256 -> 256 -- the tiny NeRF / Fourier MLP family -- run the MATRIX WAVES / VECTOR WAVES
+ * kernels (csrc/mlp_bf16_mv.hip: four waves that only multiply, eight that only generate features and
+ * run epilogues), everything else the two-waves-per-SIMD kernels (csrc/mlp_bf16_ws.hip);
+ * FFN_BF16X6_ORG=ws (environment, read per launch) keeps the latter for every chain (A/B).
+ * ffn_mlp_bf16x6_organisation answers which one a launch of `chain` takes: 1 = matrix / vector waves,
+ * 0 = two waves per SIMD (backward != 0: the backward-data chain).
  * Reference arithmetic being matched: fourier_feature_models.py:57-78, nerf_model.py:86-124. */
+int ffn_mlp_bf16x6_organisation(const ffn_mlp_chain* chain, int backward);
 int ffn_mlp_pack_bf16_parts(const float* src, int rows, int cols, int ld, const int32_t* col_map,
                             int kblocks, int tiles, int transpose, int parts, uint16_t* dst,
                             void* stream);

@@ -79,6 +79,16 @@ def timeit(fn, reps):
     return e0.elapsed_time(e1) / reps
 
 
+def backward_data(prog, d_logits, buf, n):
+    """the backward-DATA kernel alone (prog.backward also runs the weight-gradient units)"""
+    import ctypes
+    from fourier_feature_nets_amd import mlp_engine as me
+    ws = prog.workspace(n)
+    _, masks = prog._split_saved(buf, n)
+    me._call("ffn_mlp_backward_data_bf16x6", ctypes.byref(prog.bwd_x6), me._dev(prog.packed_x6_bwd, torch.int16),
+             me._dev(d_logits), me.c_i64(n), me._dev(masks), me._dev(ws.dz))
+
+
 def timing(name, model, n, reps):
     prog = model.program()
     torch.manual_seed(1)
@@ -97,6 +107,7 @@ def timing(name, model, n, reps):
                 round(timeit(lambda: prog.forward(x, None, buf, precision="bf16x6"), reps), 3))
             rows[org].setdefault("backward_ms", []).append(
                 round(timeit(lambda: prog.backward(d_logits, x, None, buf, flat, precision="bf16x6"), reps), 3))
+            rows[org].setdefault("backward_data_ms", []).append(round(timeit(lambda: backward_data(prog, d_logits, buf, n), reps), 3))
     print(json.dumps({"model": name, "samples": n, "ms": rows}), flush=True)
 
 

@@ -112,3 +112,69 @@ def test_one_launch_sampling_equals_the_two_launches_at_chunk_edges(rays, sample
         # without the view output
         t2, pos2, none = ops.sample_materialise(near_far, starts, dirs, idx, samples, unit, noise, anneal, want_views=False)
         assert none is None and torch.equal(t2, t) and torch.equal(pos2, pos)
+
+
+# ----------------------------------------------------------------------------------- bf16x6: the matrix / vector waves organisation
+def _x6_buffers(prog, x, n, org, monkeypatch):
+    monkeypatch.setenv("FFN_BF16X6_ORG", org)
+    saved = torch.zeros((prog.saved_floats(n),), dtype=torch.float32, device=dev())
+    logits = prog.forward(x, None, saved, precision="bf16x6")
+    with torch.no_grad():
+        inference = prog.forward(x, None, None, precision="bf16x6")
+    torch.manual_seed(n)
+    d_logits = torch.randn(n, 4, device=dev()) / n
+    ws = prog.workspace(n)
+    ws.dz.zero_()
+    flat = torch.zeros((prog.num_grad_floats,), dtype=torch.float32, device=dev())
+    prog.backward(d_logits, x, None, saved, flat, precision="bf16x6")
+    torch.cuda.synchronize()
+    return logits, inference, saved, ws.dz.clone(), flat
+
+
+@pytest.mark.parametrize("name", ["positional", "gaussian256", "positional8"])
+def test_bf16x6_matrix_vector_waves_write_the_bits_of_the_two_waves_per_simd_kernels(golden, name, monkeypatch):
+    """The bf16x6 chain kernels of the tiny NeRF / Fourier MLP family run in the matrix-waves / vector-waves
+    organisation (csrc/mlp_bf16_mv.hip); `FFN_BF16X6_ORG=ws` keeps the two-waves-per-SIMD kernels
+    (csrc/mlp_bf16_ws.hip) that every other chain runs and that `test_round5_gpu.py` holds against the
+    exact-f32 kernels and float64.  Same six partial products per K block in the same order per
+    accumulator: activation slabs, feature slabs, sign masks, dZ and with them every gradient are
+    BIT-identical; the logits (the fused head's partial sums meet in another order) within 2e-7 of their
+    scale; inference == training forward.  Sizes: a lone sample, the 32-sample block and the 64-sample
+    pass either side, a ragged tail, and more passes than a workgroup gets at once (the next pass's first
+    feature segment is generated under the last step of the pass before)."""
+    import fourier_feature_nets_amd as ffn
+    torch.manual_seed(5)
+    if name == "positional8":
+        model = ffn.PositionalFourierMLP(3, 4, 5.5, num_layers=8, num_channels=256, embedding_size=256).to(dev())
+    elif name == "gaussian256":
+        model = ffn.GaussianFourierMLP(3, 4, 3.0, num_layers=4, num_channels=256, embedding_size=256).to(dev())
+    else:
+        model, _ = tk._load_fourier(golden("models"), name)
+    prog = model.program()
+    monkeypatch.delenv("FFN_BF16X6_ORG", raising=False)
+    assert prog.x6_organisation() == "matrix/vector waves" and prog.x6_organisation(backward=True) == "matrix/vector waves"
+    monkeypatch.setenv("FFN_BF16X6_ORG", "ws")
+    assert prog.x6_organisation() == "two waves per SIMD"
+    for n in (1, 31, 32, 33, 64, 65, 1000, 4097, 70001):
+        torch.manual_seed(n)
+        x = torch.rand(n, 3, device=dev()) * 2 - 1
+        ref = _x6_buffers(prog, x, n, "ws", monkeypatch)
+        new = _x6_buffers(prog, x, n, "mv", monkeypatch)
+        scale = max(float(ref[0].abs().max()), 1.0)
+        assert float((new[0] - ref[0]).abs().max()) <= 2e-7 * scale, (n, "logits")
+        assert torch.equal(new[0], new[1]), (n, "inference != training forward")
+        assert torch.equal(ref[2].view(torch.int32), new[2].view(torch.int32)), (n, "slabs / masks")
+        assert torch.equal(ref[3].view(torch.int32), new[3].view(torch.int32)), (n, "dZ")
+        assert torch.equal(ref[4], new[4]), (n, "gradients")
+
+
+def test_bf16x6_chains_outside_the_family_keep_the_two_waves_per_simd_kernels(golden):
+    """Full NeRF (a 63-channel encoding, a skip connection, a 128-wide view layer) and a plain MLP (three
+    raw inputs) are not what the matrix / vector waves kernels cover: `x6_organisation` says so, and
+    their launches are the round-5 kernels' (held against the exact kernels by test_round5_gpu.py)."""
+    nerf, _ = tk._load_nerf(golden("models"), "nerf", [4], True)
+    assert nerf.program().x6_organisation() == "two waves per SIMD"
+    assert nerf.program().x6_organisation(backward=True) == "two waves per SIMD"
+    for other in ("mlp", "gaussian", "basic"):        # three raw inputs / an encoding that is not 16 j K blocks
+        model, _ = tk._load_fourier(golden("models"), other)
+        assert model.program().x6_organisation() == "two waves per SIMD", other
