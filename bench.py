@@ -839,10 +839,12 @@ SPLIT_MODES = {
         "kernels": {"ffn_mlp_forward_bf16x6_train": "forward", "ffn_mlp_backward_data_bf16x6": "backward_data",
                     "ffn_mlp_wgrad_units_bf16x6": "weight_gradients",
                     "ffn_mlp_wgrad_units": "weight_gradients_narrow_units_exact_f32"},
-        "bound": "the bf16 matrix pipe at 12 cycles per K (32 for v_mfma_f32_32x32x2_f32): forward / "
-                 "backward data two blocks of 32 samples per pass, phases separated by workgroup barriers "
-                 "(matrix pipe ~0.55 busy); weight gradients 192 matrix instructions per block and unit "
-                 "under a four-stage LDS-DMA ring, conversions pinned between them (DESIGN: bf16x6 section)"},
+        "bound": "the bf16 matrix pipe at 12 cycles per K (32 for v_mfma_f32_32x32x2_f32).  Forward / backward "
+                 "data of the tiny NeRF / Fourier MLP family: matrix waves + vector waves (mlp_bf16_mv.hip: one "
+                 "wave per SIMD only multiplies, two generate features and run epilogues; ~38 cycles per matrix "
+                 "instruction in the stream, ~45 beside an epilogue: vector instructions beside a saturated "
+                 "matrix pipe cost 2-4 cycles each); other chains two waves per SIMD (mlp_bf16_ws.hip, ~0.55 "
+                 "busy); weight gradients 192 matrix instructions per block and unit (DESIGN section 4)"},
 }
 
 
@@ -985,7 +987,15 @@ def bf16_train_leg(device, dataset, rays_per_step, samples, steps=6, mode="bf16x
                     "emulation_ceiling": "2500 TFLOP/s dense bf16 / %d matrix instructions per f32 product" % info["products"],
                     "algorithmic_flop_per_launch": flop["forward"] * n_samples,
                     "avg_launch_ms": fwd["avg_ms"]}
+    organisation = None
+    if mode == "bf16x6":
+        torch.manual_seed(20080524)
+        probe = ffn.PositionalFourierMLP(3, 4, 5.5).to(device).program()
+        organisation = {"forward": probe.x6_organisation(), "backward_data": probe.x6_organisation(backward=True),
+                        "note": "FFN_BF16X6_ORG=ws keeps the two-waves-per-SIMD kernels (bit-identical slabs, masks, dZ)"}
+        del probe
     return {"label": info["label"],
+            "chain_kernel_organisation": organisation,
             "roofline": roofline,
             "ms_per_step": round(best[mode], 3),
             "train_step_ms": {k: round(v, 3) for k, v in best.items()},

@@ -149,6 +149,8 @@ __device__ __forceinline__ void mv_unit(const MvCtx& w, f32x16 (&acc)[2], f32x16
     }
     __builtin_amdgcn_sched_barrier(0);
     auto group = [&](auto qc, auto bc) {
+        // (two accumulators: h.h -- the only product on `acc` -- stays LAST in the unit.  The order matters per
+        // accumulator only, but issued first it costs the backward kernel 18 %: 6.14 -> 7.25 ms, measured.)
         constexpr int q = decltype(qc)::value, b = decltype(bc)::value;
         constexpr int g = 2 * q + b;
         const bf16x8 operand = P::X[q] == 0 ? r.xh[HB][b] : (P::X[q] == 1 ? r.xm[HB][b] : r.xl[b]);
@@ -160,6 +162,8 @@ __device__ __forceinline__ void mv_unit(const MvCtx& w, f32x16 (&acc)[2], f32x16
                 lo[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.wr[J][P::W[q]], operand, (FIRST == 2 && q == 0) ? zero : lo[b], 0, 0, 0);
         } else if constexpr (FIRST == 1 && q == 0) {
             acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.wr[J][P::W[q]], operand, acc[0], 0, 0, 0);
+        } else if constexpr (FIRST == 2 && q == 0) {
+            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.wr[J][P::W[q]], operand, (f32x16)(0.0f), 0, 0, 0);
         } else {
             acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.wr[J][P::W[q]], operand, acc[b], 0, 0, 0);
         }
@@ -399,10 +403,17 @@ __device__ __forceinline__ int64_t mv_mask_at(int slot, int64_t num_blocks, int6
     return (((int64_t)slot * num_blocks + block) * 64 + lane) * 16 + 4 * (o >> 1) + ((o & 1) ? 0 : 2);
 }
 
-// The epilogue of (tile o, this wave's block): ReLU, sign bits, slab stores, fused head, the three-way
-// split into res -- everything but the X stores.
-__device__ __forceinline__ void mv_epilogue(const ffn_mlp_chain& ch, const ffn_step& L, bool last_step, const MvCtx& w,
-                                            MvVec& v, int o, const f32x16& acc, bf16x8 (&res)[2][3]) {
+// The epilogue of (tile o, this wave's block) in two parts.  What the matrix waves wait for -- ReLU, sign bits,
+// fused head, the three-way split into res (the X stores follow behind a barrier) -- and what nobody waits
+// for: the slab and mask stores to HBM (a nontemporal 1 KiB store costs the wave ~200 cycles beside the
+// weight stream), which run BEHIND the barrier the matrix waves are released by.
+struct MvDeferred {
+    float y[16];                   // the tile's outputs for this wave's block (after the activation)
+    unsigned sign_bits;
+};
+
+__device__ __forceinline__ void mv_epilogue(const ffn_step& L, bool last_step, const MvCtx& w, MvVec& v, int o,
+                                            const f32x16& acc, bf16x8 (&res)[2][3], MvDeferred& d) {
     const bool fused_head = L.head_off >= 0;
     const float* hw = w.bias_lds + (fused_head ? L.head_off : 0) + 4 + 16 * w.h;
     if (fused_head && o == 0 && w.h == 0) {
@@ -411,14 +422,6 @@ __device__ __forceinline__ void mv_epilogue(const ffn_mlp_chain& ch, const ffn_s
         for (int c = 0; c < 4; ++c) v.logit[c] += hb[c];
     }
     const int relu_floor = L.relu ? 0 : (int)0x80000000;
-    int save_s = w.s, save_h = w.h, e_lane = w.lane;
-    asm volatile("" : "+v"(save_s), "+v"(save_h), "+v"(e_lane));     // (see mlp_bf16.hip: no hoisted address tables)
-    const int64_t block = w.block0 + w.sub;
-    const bool live = block < w.num_blocks;
-    f32x4* save_out = nullptr;
-    if (w.saved != nullptr && L.out_slot >= 0 && live)
-        save_out = reinterpret_cast<f32x4*>(w.saved + ch.slot_offset[L.out_slot] * w.num_blocks * 32) +
-                   block * (int64_t)(ch.slot_channels[L.out_slot] * 8);
     unsigned sign_bits = 0u;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -428,14 +431,7 @@ __device__ __forceinline__ void mv_epilogue(const ffn_mlp_chain& ch, const ffn_s
             const float a = acc[8 * half + j];
             sign_bits = __builtin_amdgcn_alignbit(sign_bits, __builtin_bit_cast(unsigned, 0.0f - a), 31);
             y[j] = __builtin_bit_cast(float, __builtin_elementwise_max(__builtin_bit_cast(int, a), relu_floor));
-        }
-        if (save_out != nullptr) {
-            f32x4 y0, y1;
-#pragma unroll
-            for (int p = 0; p < 4; ++p) { y0[p] = y[p]; y1[p] = y[4 + p]; }
-            const int cq = 2 * (4 * o + 2 * half) + save_h;
-            __builtin_nontemporal_store(y0, &save_out[saved_index16(cq, save_s)]);
-            __builtin_nontemporal_store(y1, &save_out[saved_index16(cq + 2, save_s)]);
+            d.y[8 * half + j] = y[j];
         }
         if (fused_head) {
 #pragma unroll
@@ -448,9 +444,31 @@ __device__ __forceinline__ void mv_epilogue(const ffn_mlp_chain& ch, const ffn_s
         }
         if (!last_step) split8x3_lockstep(y, res[half][0], res[half][1], res[half][2]);
     }
-    if (w.masks != nullptr && L.relu && L.mask_slot >= 0 && live)
+    d.sign_bits = sign_bits;
+}
+
+__device__ __forceinline__ void mv_epilogue_stores(const ffn_mlp_chain& ch, const ffn_step& L, const MvCtx& w, int o,
+                                                   const MvDeferred& d) {
+    int save_s = w.s, save_h = w.h, e_lane = w.lane;
+    asm volatile("" : "+v"(save_s), "+v"(save_h), "+v"(e_lane));     // (see mlp_bf16.hip: no hoisted address tables)
+    const int64_t block = w.block0 + w.sub;
+    if (block >= w.num_blocks) return;
+    if (w.saved != nullptr && L.out_slot >= 0) {
+        f32x4* save_out = reinterpret_cast<f32x4*>(w.saved + ch.slot_offset[L.out_slot] * w.num_blocks * 32) +
+                          block * (int64_t)(ch.slot_channels[L.out_slot] * 8);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            f32x4 y0, y1;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) { y0[p] = d.y[8 * half + p]; y1[p] = d.y[8 * half + 4 + p]; }
+            const int cq = 2 * (4 * o + 2 * half) + save_h;
+            __builtin_nontemporal_store(y0, &save_out[saved_index16(cq, save_s)]);
+            __builtin_nontemporal_store(y1, &save_out[saved_index16(cq + 2, save_s)]);
+        }
+    }
+    if (w.masks != nullptr && L.relu && L.mask_slot >= 0)
         *reinterpret_cast<uint16_t*>(w.masks + mv_mask_at(L.mask_slot, w.num_blocks, block, e_lane, o)) =
-            (uint16_t)(sign_bits & 0xffffu);
+            (uint16_t)(d.sign_bits & 0xffffu);
 }
 
 // (tile o, this wave's block) of the output = its share of K blocks 2 o, 2 o + 1 of the next X image
@@ -466,16 +484,19 @@ __device__ __forceinline__ void mv_store_x(const MvCtx& w, int o, const bf16x8 (
 // a step seen from a vector wave, from its barrier S2 on (what comes before differs: the features'
 // segments, or S1).  next != nullptr (the LAST step of a pass that has a successor): segment 0 of the
 // NEXT pass's features is generated between S3b and S4 -- K blocks 0..7 of X are free from S3 on, the
-// matrix waves start the next pass on them right behind S4.
+// matrix waves start the next pass on them right behind S4.  The HBM stores of tile B are left to the
+// caller (`late`): they go behind the next barrier.
 __device__ __forceinline__ void mv_vector_tail(const ffn_mlp_chain& ch, const ffn_step& L, bool last_step,
-                                               const MvCtx& w, MvVec& v, const MvVec* next, int64_t next_block0) {
+                                               const MvCtx& w, MvVec& v, const MvVec* next, int64_t next_block0,
+                                               MvDeferred& late) {
     f32x16 acc;
     bf16x8 res[2][3];
+    MvDeferred early;
     MV_STAMP(w, 60);
     mv_barrier();                                  // S2: tile A handed over
     MV_STAMP(w, 61);
     mv_take_over(w, acc);
-    mv_epilogue(ch, L, last_step, w, v, w.m, acc, res);
+    mv_epilogue(L, last_step, w, v, w.m, acc, res, early);
     MV_STAMP(w, 62);
     mv_barrier();                                  // S3: K blocks 0..7 of X are consumed
     MV_STAMP(w, 63);
@@ -483,6 +504,7 @@ __device__ __forceinline__ void mv_vector_tail(const ffn_mlp_chain& ch, const ff
     MV_STAMP(w, 64);
     mv_barrier();                                  // S3b: K blocks 0..7 of the next image are in X
     MV_STAMP(w, 65);
+    mv_epilogue_stores(ch, L, w, w.m, early);
     if (next != nullptr) {
         mv_generate(ch, ch.step[0], w, *next, next_block0, 0, 8, (w.wave - 4) >> 1, 2 * kMvVecPerSimd);
         MV_STAMP(w, 68);
@@ -490,7 +512,7 @@ __device__ __forceinline__ void mv_vector_tail(const ffn_mlp_chain& ch, const ff
     mv_barrier();                                  // S4: tile B handed over, X consumed
     MV_STAMP(w, 66);
     mv_take_over(w, acc);
-    mv_epilogue(ch, L, last_step, w, v, w.m + 4, acc, res);
+    mv_epilogue(L, last_step, w, v, w.m + 4, acc, res, late);
     if (!last_step) mv_store_x(w, w.m + 4, res);
     MV_STAMP(w, 67);
     // (the next barrier -- S1 of the next step, or F_0 of the next pass -- publishes K blocks 8..15)
@@ -658,14 +680,18 @@ mlp_forward_bf16_mv_kernel(const ffn_mlp_chain ch, const uint16_t* __restrict__ 
                 pending = false;
             }
         }
-        mv_vector_tail(ch, L0, false, w, v, nullptr, 0);
+        MvDeferred late;
+        mv_vector_tail(ch, L0, false, w, v, nullptr, 0, late);
         for (int li = 1; li < ch.num_steps; ++li) {
             const bool last = li + 1 == ch.num_steps;
             MV_STAMP(w, 70);
             mv_barrier();                                                                    // S1
             MV_STAMP(w, 71);
-            mv_vector_tail(ch, ch.step[li], last, w, v, (last && has_next) ? &vnext : nullptr, w.block0 + 2 * (int64_t)gridDim.x);
+            mv_epilogue_stores(ch, ch.step[li - 1], w, w.m + 4, late);         // (tile B of the step before)
+            mv_vector_tail(ch, ch.step[li], last, w, v, (last && has_next) ? &vnext : nullptr,
+                           w.block0 + 2 * (int64_t)gridDim.x, late);
         }
+        mv_epilogue_stores(ch, ch.step[ch.num_steps - 1], w, w.m + 4, late);
         mv_leave_logits(w, v);
         pending = true;
         pending_block0 = w.block0;
@@ -723,6 +749,11 @@ int launch_forward_bf16x6_mv(const ffn_mlp_chain* chain, const uint16_t* packed_
 // other step is 256 -> 256.  Two accumulators per (tile, block) -- one tile at a time in the matrix
 // wave's registers: it adds them up and hands the tile over before the next one starts.  The vector
 // waves' epilogue: the ReLU mask of the layer being differentiated, the dZ slab, the three-way split.
+#ifdef MV_KO_BWD_ONE_ACC            // (timing only: all six products on one accumulator)
+constexpr bool kMvBwdTwo = false;
+#else
+constexpr bool kMvBwdTwo = true;
+#endif
 constexpr size_t kMvBwdLdsBytes = (size_t)kMvXBytes + kMvHandBytes + kMvMaxUnits * 4;
 
 struct MvAcc2 {
@@ -730,33 +761,44 @@ struct MvAcc2 {
 };
 
 __device__ __forceinline__ void mv_meet_and_hand_over(const MvCtx& w, MvAcc2& c) {
+    if constexpr (kMvBwdTwo) {
 #pragma unroll
-    for (int b = 0; b < 2; ++b) c.main[b] += c.lo[b];
+        for (int b = 0; b < 2; ++b) c.main[b] += c.lo[b];
+    }
     mv_hand_over(w, c.main);
 }
 
 // step 0 (the d_logits term only: X K blocks 0 and 1, both tiles in ONE trip of four units)
 __device__ __forceinline__ void mv_matrix_bwd_first(const MvCtx& w, MvMat& r, MvAcc2& c) {
     const f32x4* xb = w.xbuf + w.lane;
+    MV_STAMP(w, 80);
     mv_read_x0(w, r, 0);                           // (published by the prologue, or by S4 of the pass before)
     mv_gptr base[4];
     mv_trip_bases(w, r, base);
-    mv_unit<0, 0, 3, 2, true>(w, c.main, c.lo, r, xb + kMvKbVecs, base[0], false);
-    mv_unit<1, 1, 3, 0, true>(w, c.main, c.lo, r, xb, base[1], false);
+    mv_unit<0, 0, 3, 2, kMvBwdTwo>(w, c.main, c.lo, r, xb + kMvKbVecs, base[0], false);
+    mv_unit<1, 1, 3, 0, kMvBwdTwo>(w, c.main, c.lo, r, xb, base[1], false);
+    MV_STAMP(w, 81);
     mv_meet_and_hand_over(w, c);                   // tile A
     mv_barrier();                                                                            // S2
-    mv_unit<2, 0, 3, 2, true>(w, c.main, c.lo, r, xb + kMvKbVecs, base[2], false);
-    mv_unit<3, 1, 0, 0, true>(w, c.main, c.lo, r, nullptr, base[3], false);
+    MV_STAMP(w, 82);
+    mv_unit<2, 0, 3, 2, kMvBwdTwo>(w, c.main, c.lo, r, xb + kMvKbVecs, base[2], false);
+    mv_unit<3, 1, 0, 0, kMvBwdTwo>(w, c.main, c.lo, r, nullptr, base[3], false);
+    MV_STAMP(w, 83);
     mv_barrier();                                                                            // S3: K blocks 0, 1 consumed
+    MV_STAMP(w, 84);
     mv_meet_and_hand_over(w, c);                   // tile B (its barrier S4: in front of the next step's second unit)
     mv_barrier();                                                                            // S3b: K blocks 0..7 of the next image are in X
+    MV_STAMP(w, 85);
     mv_read_x0(w, r, 0);
 }
 
 __device__ __forceinline__ void mv_matrix_bwd_hidden(bool last_step, const MvCtx& w, MvMat& r, MvAcc2& c) {
-    mv_k_loop2<2, true>(w, r, c.main, c.lo, 0, 4, 0, 0x82u);                                 // S4, S1: units 1, 7
+    MV_STAMP(w, 20);
+    mv_k_loop2<2, kMvBwdTwo>(w, r, c.main, c.lo, 0, 4, 0, 0x82u);                                 // S4, S1: units 1, 7
+    MV_STAMP(w, 21);
     mv_meet_and_hand_over(w, c);                   // tile A
-    mv_k_loop2<2, true>(w, r, c.main, c.lo, 0, 4, 0, last_step ? 0x182u : 0x882u);           // S2, S3, S3b: units 1, 7, 11 (1, 7, 8)
+    mv_k_loop2<2, kMvBwdTwo>(w, r, c.main, c.lo, 0, 4, 0, last_step ? 0x182u : 0x882u);           // S2, S3, S3b: units 1, 7, 11 (1, 7, 8)
+    MV_STAMP(w, 23);
     mv_meet_and_hand_over(w, c);                   // tile B
 }
 
@@ -804,16 +846,10 @@ __device__ __forceinline__ unsigned mv_load_mask(const ffn_step& L, const MvCtx&
     return *reinterpret_cast<const uint16_t*>(v.masks + mv_mask_at(L.mask_slot, w.num_blocks, block, w.lane, o));
 }
 
-// the epilogue of (tile o, this wave's block): mask, dZ slab, the three-way split -- everything but the X stores
-__device__ __forceinline__ void mv_epilogue_bwd(const ffn_mlp_chain& ch, const ffn_step& L, bool last_step, const MvCtx& w,
-                                                const MvVecB& v, int o, unsigned word, const f32x16& acc, bf16x8 (&res)[2][3]) {
-    int save_s = w.s, save_h = w.h;
-    asm volatile("" : "+v"(save_s), "+v"(save_h));
-    const int64_t block = w.block0 + w.sub;
-    f32x4* save_out = nullptr;
-    if (L.out_slot >= 0 && block < w.num_blocks)
-        save_out = reinterpret_cast<f32x4*>(v.dz + ch.slot_offset[L.out_slot] * w.num_blocks * 32) +
-                   block * (int64_t)(ch.slot_channels[L.out_slot] * 8);
+// the epilogue of (tile o, this wave's block): mask and the three-way split; the dZ slab goes to HBM behind
+// the next barrier (mv_epilogue_bwd_stores: see MvDeferred)
+__device__ __forceinline__ void mv_epilogue_bwd(bool last_step, unsigned word, const f32x16& acc, bf16x8 (&res)[2][3],
+                                                MvDeferred& d) {
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         float y[8];
@@ -825,36 +861,51 @@ __device__ __forceinline__ void mv_epilogue_bwd(const ffn_mlp_chain& ch, const f
             // whatever i is -- hipcc 7.2; found by the parity check against the ws kernels)
             const float a = acc[8 * half + j];
             y[j] = __builtin_bit_cast(float, __builtin_bit_cast(int, a) & keep);
-        }
-        if (save_out != nullptr) {
-            f32x4 y0, y1;
-#pragma unroll
-            for (int p = 0; p < 4; ++p) { y0[p] = y[p]; y1[p] = y[4 + p]; }
-            const int cq = 2 * (4 * o + 2 * half) + save_h;
-            __builtin_nontemporal_store(y0, &save_out[saved_index16(cq, save_s)]);
-            __builtin_nontemporal_store(y1, &save_out[saved_index16(cq + 2, save_s)]);
+            d.y[8 * half + j] = y[j];
         }
         if (!last_step) split8x3_lockstep(y, res[half][0], res[half][1], res[half][2]);
     }
 }
 
+__device__ __forceinline__ void mv_epilogue_bwd_stores(const ffn_mlp_chain& ch, const ffn_step& L, const MvCtx& w,
+                                                       const MvVecB& v, int o, const MvDeferred& d) {
+    int save_s = w.s, save_h = w.h;
+    asm volatile("" : "+v"(save_s), "+v"(save_h));
+    const int64_t block = w.block0 + w.sub;
+    if (L.out_slot < 0 || block >= w.num_blocks) return;
+    f32x4* save_out = reinterpret_cast<f32x4*>(v.dz + ch.slot_offset[L.out_slot] * w.num_blocks * 32) +
+                      block * (int64_t)(ch.slot_channels[L.out_slot] * 8);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        f32x4 y0, y1;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { y0[p] = d.y[8 * half + p]; y1[p] = d.y[8 * half + 4 + p]; }
+        const int cq = 2 * (4 * o + 2 * half) + save_h;
+        __builtin_nontemporal_store(y0, &save_out[saved_index16(cq, save_s)]);
+        __builtin_nontemporal_store(y1, &save_out[saved_index16(cq + 2, save_s)]);
+    }
+}
+
 // a step seen from a vector wave, from its barrier S2 on.  next: the LAST step of a pass that has a
 // successor writes the next pass's step-0 operands (K blocks 0, 1: free from S3 on) between S3b and S4.
+// The dZ stores of tile B are left to the caller (`late`): behind the next barrier.
 __device__ __forceinline__ void mv_vector_tail_bwd(const ffn_mlp_chain& ch, const ffn_step& L, bool last_step, const MvCtx& w,
-                                                   const MvVecB& v, bool next, const f32x4& dl_next) {
+                                                   const MvVecB& v, bool next, const f32x4& dl_next, MvDeferred& late) {
     f32x16 acc;
     bf16x8 res[2][3];
+    MvDeferred early;
     const unsigned word_a = mv_load_mask(L, w, v, w.m), word_b = mv_load_mask(L, w, v, w.m + 4);
     mv_barrier();                                  // S2: tile A handed over
     mv_take_over(w, acc);
-    mv_epilogue_bwd(ch, L, last_step, w, v, w.m, word_a, acc, res);
+    mv_epilogue_bwd(last_step, word_a, acc, res, early);
     mv_barrier();                                  // S3: K blocks 0..7 of X are consumed
     if (!last_step) mv_store_x(w, w.m, res);
     mv_barrier();                                  // S3b: K blocks 0..7 of the next image are in X
+    mv_epilogue_bwd_stores(ch, L, w, v, w.m, early);
     if (next) mv_write_dlogits(ch.step[0], w, dl_next);
     mv_barrier();                                  // S4: tile B handed over, X consumed
     mv_take_over(w, acc);
-    mv_epilogue_bwd(ch, L, last_step, w, v, w.m + 4, word_b, acc, res);
+    mv_epilogue_bwd(last_step, word_b, acc, res, late);
     if (!last_step) mv_store_x(w, w.m + 4, res);
 }
 
@@ -898,6 +949,10 @@ mlp_backward_bf16_mv_kernel(const ffn_mlp_chain ch, const uint16_t* __restrict__
     w.gw = reinterpret_cast<const f32x4*>(packed + ch.step[0].w_off);
     w.saved = nullptr;
     w.masks = nullptr;
+#ifdef MV_STAMPS
+    w.stamp_on = 0;
+    w.stamp_n = 0;
+#endif
     w.num_blocks = (n + 31) / 32;
     const int64_t passes = (w.num_blocks + 1) / 2;
     const bool matrix = w.wave < 4;
@@ -920,9 +975,14 @@ mlp_backward_bf16_mv_kernel(const ffn_mlp_chain ch, const uint16_t* __restrict__
         mv_barrier();                                                                        // P1: the first pass's operands
         asm volatile("" ::"v"(r.wr[2][2]));        // (see mv_matrix_features)
         for (int64_t pass = blockIdx.x; pass < passes; pass += gridDim.x) {
+#ifdef MV_STAMPS
+            w.stamp_on = blockIdx.x == 0 && pass == blockIdx.x + 2 * (int64_t)gridDim.x && w.wave == 0;
+            w.stamp_n = 0;
+#endif
             mv_matrix_bwd_first(w, r, c);
             for (int li = 1; li < ch.num_steps; ++li) mv_matrix_bwd_hidden(li + 1 == ch.num_steps, w, r, c);
             mv_barrier();                                                                    // S4 of the last step
+            MV_STAMP(w, 24);
         }
         return;
     }
@@ -942,12 +1002,15 @@ mlp_backward_bf16_mv_kernel(const ffn_mlp_chain ch, const uint16_t* __restrict__
         const bool has_next = pass + gridDim.x < passes;
         f32x4 dl_next = (f32x4)(0.0f);
         if (has_next) dl_next = mv_load_dlogits(w, v, w.block0 + 2 * (int64_t)gridDim.x);
-        mv_vector_tail_bwd(ch, ch.step[0], false, w, v, false, dl_next);
+        MvDeferred late;
+        mv_vector_tail_bwd(ch, ch.step[0], false, w, v, false, dl_next, late);
         for (int li = 1; li < ch.num_steps; ++li) {
             const bool last = li + 1 == ch.num_steps;
             mv_barrier();                                                                    // S1
-            mv_vector_tail_bwd(ch, ch.step[li], last, w, v, last && has_next, dl_next);
+            mv_epilogue_bwd_stores(ch, ch.step[li - 1], w, v, w.m + 4, late);  // (tile B of the step before)
+            mv_vector_tail_bwd(ch, ch.step[li], last, w, v, last && has_next, dl_next, late);
         }
+        mv_epilogue_bwd_stores(ch, ch.step[ch.num_steps - 1], w, v, w.m + 4, late);
     }
 }
 

@@ -89,6 +89,30 @@ def backward_data(prog, d_logits, buf, n):
              me._dev(d_logits), me.c_i64(n), me._dev(masks), me._dev(ws.dz))
 
 
+def stress(name, model, n, reps):
+    """the same launch `reps` times at the bench size: every repetition bit-identical to the ws kernels' buffers
+    (a race between the matrix and the vector waves would show as a difference that comes and goes)"""
+    prog = model.program()
+    torch.manual_seed(2)
+    x = torch.rand(n, 3, device=dev()) * 2 - 1
+    d_logits = torch.randn(n, 4, device=dev()) / n
+    ref_l, ref_s = run(prog, x, n, "ws", True)
+    ws = prog.workspace(n)
+    os.environ["FFN_BF16X6_ORG"] = "ws"
+    backward_data(prog, d_logits, ref_s, n)
+    torch.cuda.synchronize()
+    ref_dz = ws.dz.clone()
+    for rep in range(reps):
+        new_l, new_s = run(prog, x, n, "mv", True)
+        assert torch.equal(ref_s.view(torch.int32), new_s.view(torch.int32)), (name, rep, "slabs / masks differ")
+        assert float((new_l - ref_l).abs().max()) <= 2e-7 * max(float(ref_l.abs().max()), 1.0), (name, rep, "logits")
+        ws.dz.zero_()
+        backward_data(prog, d_logits, new_s, n)
+        torch.cuda.synchronize()
+        assert torch.equal(ref_dz.view(torch.int32), ws.dz.view(torch.int32)), (name, rep, "dZ differs")
+    print("%-14s %d repetitions at %d samples: bit-identical every time" % (name, reps, n), flush=True)
+
+
 def timing(name, model, n, reps):
     prog = model.program()
     torch.manual_seed(1)
@@ -115,10 +139,15 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--time-only", action="store_true")
     ap.add_argument("--check-only", action="store_true")
+    ap.add_argument("--stress", type=int, default=0)
     ap.add_argument("--n", type=int, default=4194304)
     ap.add_argument("--reps", type=int, default=5)
     args = ap.parse_args()
     ms = models()
+    if args.stress:
+        for k, m in ms.items():
+            stress(k, m, args.n, args.stress)
+        sys.exit(0)
     if not args.time_only:
         for k, m in ms.items():
             check(k, m)

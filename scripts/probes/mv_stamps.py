@@ -18,7 +18,9 @@ NAMES = {1: "pass start", 2: "after P0", 3: "generated segment 0", 4: "after P1"
          22: "hidden: after S2", 23: "hidden: K(B) done", 24: "hidden: after S4", 30: "  barrier in the stream: arrive",
          31: "  barrier in the stream: leave", 32: "  feature segment (8 K blocks x 2 tiles, 192 matrix instructions)", 40: "before R1", 41: "after R1", 50: "generated a segment",
          51: "after F", 60: "before S2", 61: "after S2", 62: "epilogue A computed", 63: "after S3",
-         64: "X stores of A", 65: "after S3b", 66: "after S4", 67: "epilogue B + X stores", 70: "before S1", 71: "after S1"}
+         64: "X stores of A", 65: "after S3b", 66: "after S4", 67: "epilogue B + X stores", 70: "before S1", 71: "after S1",
+         80: "backward step 0: start", 81: "tile A's two units done", 82: "A handed over, after S2",
+         83: "tile B's two units done", 84: "after S3", 85: "B handed over, after S3b"}
 
 
 def build(extra=(), out=OUT):
@@ -50,11 +52,20 @@ def run(train):
     for _ in range(2):
         prog.forward(x, None, buf, precision="bf16x6")
     torch.cuda.synchronize()
+    if "--bwd" in sys.argv:                        # the backward-data kernel's stamps overwrite the forward's
+        from fourier_feature_nets_amd import mlp_engine as me
+        d_logits = torch.randn(n, 4, device=dev) / n
+        ws = prog.workspace(n)
+        _, masks = prog._split_saved(buf, n)
+        for _ in range(2):
+            me._call("ffn_mlp_backward_data_bf16x6", ctypes.byref(prog.bwd_x6), me._dev(prog.packed_x6_bwd, torch.int16),
+                     me._dev(d_logits), me.c_i64(n), me._dev(masks), me._dev(ws.dz))
+        torch.cuda.synchronize()
     lib = _lib.load() if hasattr(_lib, "load") else ctypes.CDLL(os.environ["FFN_HIP_LIBRARY"])
     host = (ctypes.c_longlong * 2048)()
     rc = lib.ffn_debug_mv_stamps(host)
     assert rc == 0, rc
-    for role, name in ((0, "matrix wave 0"), (1, "vector wave 4")):
+    for role, name in ((0, "matrix wave 0"),) if "--bwd" in sys.argv else ((0, "matrix wave 0"), (1, "vector wave 4")):
         print("== %s (%s)" % (name, "training forward" if train else "inference"))
         rows = []
         for i in range(510):
