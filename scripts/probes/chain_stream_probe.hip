@@ -20,7 +20,10 @@ constexpr int kKBlocks = 64;                 // K blocks of the chain (tiny NeRF
 constexpr int kTiles = 8;
 constexpr int kKbVecs = kTiles * 3 * 64;     // float4 per K block of the pack: 8 tiles x 3 parts x 64 lanes
 
-template <int NT, int DEPTH, int FILL, bool LOADW, bool READX, int PARTNER = 0>
+// PATTERN (round 6, the backward kernels' two accumulators): 0 = every product on acc[t][b]; 1 = the first five
+// products of a K block on a second accumulator set lo[t][b], the sixth on acc (mlp_bf16_ws.hip's backward);
+// 2 = the same with the sixth product issued FIRST; 3 = the second set takes products 0..2, acc 3..5
+template <int NT, int DEPTH, int FILL, bool LOADW, bool READX, int PARTNER = 0, int PATTERN = 0>
 __global__ void __launch_bounds__(PARTNER ? 512 : 256, 1)
 probe(const f32x4* __restrict__ pack, float* out, int passes, long long* cycles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -57,13 +60,13 @@ probe(const f32x4* __restrict__ pack, float* out, int passes, long long* cycles)
     }
     if (PARTNER == 2) __builtin_amdgcn_s_setprio(1);
     typedef const f32x4 __attribute__((address_space(1)))* gptr;
-    f32x16 acc[NT][2];
+    f32x16 acc[NT][2], lo[NT][2];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][b][r] = 0.0f;
+            for (int r = 0; r < 16; ++r) { acc[t][b][r] = 0.0f; lo[t][b][r] = 0.0f; }
     bf16x8 wr[DEPTH][NT][3];
     bf16x8 x[2][2][3];
     float fill[8];
@@ -105,7 +108,10 @@ probe(const f32x4* __restrict__ pack, float* out, int passes, long long* cycles)
                     for (int t = 0; t < NT; ++t)
 #pragma unroll
                         for (int b = 0; b < 2; ++b) {
-                            acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[d][t][PW[q]], x[hb][b][PX[q]], acc[t][b], 0, 0, 0);
+                            const int pq = PATTERN == 2 ? (q == 0 ? 5 : q - 1) : q;       // product issued in slot q
+                            const bool on_lo = PATTERN == 0 ? false : (PATTERN == 3 ? pq < 3 : pq < 5);
+                            if (on_lo) lo[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[d][t][PW[pq]], x[hb][b][PX[pq]], lo[t][b], 0, 0, 0);
+                            else acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[d][t][PW[pq]], x[hb][b][PX[pq]], acc[t][b], 0, 0, 0);
                             const int g = (q * NT + t) * 2 + b;      // group index 0 .. 12 NT - 1
                             if (READX && g < 6) {                    // the six X reads of the next K block
                                 const int rb = g / 3, rp = g % 3;
@@ -136,7 +142,7 @@ probe(const f32x4* __restrict__ pack, float* out, int passes, long long* cycles)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s += acc[t][b][r];
+            for (int r = 0; r < 16; ++r) s += acc[t][b][r] + lo[t][b][r];
 #pragma unroll
     for (int i = 0; i < 8; ++i) s += fill[i];
     if (PARTNER && wave == 0 && lane == 0) *reinterpret_cast<volatile int*>(smem + 16 * 2 * 3 * 64 * 16) = 1;
@@ -144,24 +150,24 @@ probe(const f32x4* __restrict__ pack, float* out, int passes, long long* cycles)
     if (threadIdx.x == 0 && blockIdx.x == 0) cycles[0] = t1 - t0;
 }
 
-template <int NT, int DEPTH, int FILL, bool LOADW, bool READX, int PARTNER = 0>
+template <int NT, int DEPTH, int FILL, bool LOADW, bool READX, int PARTNER = 0, int PATTERN = 0>
 void run(const f32x4* pack, float* out, long long* cyc) {
     const int passes = 64, grid = 256;
     const size_t lds = 16 * 2 * 3 * 64 * 16 + 64 + 4 * 64 * 8 * 16;
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&probe<NT, DEPTH, FILL, LOADW, READX, PARTNER>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&probe<NT, DEPTH, FILL, LOADW, READX, PARTNER, PATTERN>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    probe<NT, DEPTH, FILL, LOADW, READX, PARTNER><<<grid, PARTNER ? 512 : 256, lds>>>(pack, out, 2, cyc);
+    probe<NT, DEPTH, FILL, LOADW, READX, PARTNER, PATTERN><<<grid, PARTNER ? 512 : 256, lds>>>(pack, out, 2, cyc);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    probe<NT, DEPTH, FILL, LOADW, READX, PARTNER><<<grid, PARTNER ? 512 : 256, lds>>>(pack, out, passes, cyc);
+    probe<NT, DEPTH, FILL, LOADW, READX, PARTNER, PATTERN><<<grid, PARTNER ? 512 : 256, lds>>>(pack, out, passes, cyc);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     long long h; hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);
     const double per_wave = (double)passes * kKBlocks * 12 * NT;
     const double mfma = (double)grid * 4 * per_wave;
-    printf("partner %d  tiles/wave %d  depth %d  fill %d  weights %s  X %s: %8.3f ms  %7.1f TFLOP/s issued (2500 peak)  %5.1f ticks/MFMA  "
-           "weights %.2f TB/s\n", PARTNER, NT, DEPTH, FILL, LOADW ? "L2  " : "none", READX ? "LDS " : "none", ms,
+    printf("pattern %d  partner %d  tiles/wave %d  depth %d  fill %d  weights %s  X %s: %8.3f ms  %7.1f TFLOP/s issued (2500 peak)  %5.1f ticks/MFMA  "
+           "weights %.2f TB/s\n", PATTERN, PARTNER, NT, DEPTH, FILL, LOADW ? "L2  " : "none", READX ? "LDS " : "none", ms,
            mfma * 32768 / ms / 1e9, (double)h / per_wave,
            LOADW ? (double)grid * 4 * passes * kKBlocks * NT * 3072.0 / ms / 1e9 : 0.0);
 }
@@ -195,5 +201,14 @@ int main() {
     run<1, 2, 0, true, true, 2>(pack, out, cyc);
     run<1, 4, 0, true, true, 1>(pack, out, cyc);
     run<1, 4, 0, true, true, 2>(pack, out, cyc);
+    // two accumulator sets (the backward kernels)
+    run<1, 4, 0, true, true, 0, 0>(pack, out, cyc);
+    run<1, 4, 0, true, true, 0, 1>(pack, out, cyc);
+    run<1, 4, 0, true, true, 0, 2>(pack, out, cyc);
+    run<1, 4, 0, true, true, 0, 3>(pack, out, cyc);
+    run<1, 4, 0, false, false, 0, 0>(pack, out, cyc);
+    run<1, 4, 0, false, false, 0, 1>(pack, out, cyc);
+    run<1, 4, 0, false, false, 0, 2>(pack, out, cyc);
+    run<1, 4, 0, false, false, 0, 3>(pack, out, cyc);
     return 0;
 }
