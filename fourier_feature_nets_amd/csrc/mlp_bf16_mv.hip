@@ -6,36 +6,41 @@
 // share the matrix pipe evenly (issue is arbitrated by priority, then age), so a step ends with the
 // younger wave's epilogue, the X refill and two barriers exposed (5.3 k of 18.8 k cycles per hidden
 // step), and every K loop starts cold behind a barrier (0.9 k) -- eight times per features-only step.
-// Here the two waves of a SIMD have DIFFERENT JOBS for the whole kernel:
+// Here the waves of a SIMD have DIFFERENT JOBS for the whole kernel (twelve waves, three per SIMD):
 //
-//   * waves 0..3 (one per SIMD, the older ones) are MATRIX waves: wave m owns the output tiles m
-//     ("A") and m + 4 ("B") of every step for the pass's two 32-sample blocks and issues nothing but
-//     matrix instructions, LDS operand reads and weight requests -- ONE uninterrupted stream of
-//     "units" (one tile x one K block: 12 matrix instructions, 6 operand reads or none, 3 weight
-//     requests) through tiles, steps and passes; its weights stream L2 -> registers three units ahead
-//     out of a ring of four (the order of the units is a table in LDS);
-//   * waves 4..7 (their SIMD partners) are VECTOR waves: they generate the encoding features and run
-//     EVERY epilogue (ReLU, sign bits, slab stores, fused heads, the three-way bf16 split, the X
-//     stores) -- a tile's accumulators reach wave m + 4 through a 32 KiB hand-over buffer in LDS;
+//   * waves 0..3 (one per SIMD, the oldest) are MATRIX waves: wave m owns the output tiles m ("A") and
+//     m + 4 ("B") of every step for the pass's two 32-sample blocks and issues nothing but matrix
+//     instructions, LDS operand reads and weight requests -- ONE stream of "units" (one tile x one K
+//     block: 12 matrix instructions, 6 operand reads, 3 weight requests) through tiles, steps and
+//     passes; its weights stream L2 -> registers three units ahead out of a ring of four (the order of
+//     the units is a table in LDS); the bias enters as the addend of a tile's first product;
+//   * waves 4..11 (two per SIMD, a 32-sample block each) are VECTOR waves: they generate the encoding
+//     features and run EVERY epilogue (ReLU, sign bits, fused heads, the three-way bf16 split, the X
+//     stores, the slab / mask stores) -- a tile's accumulators reach them through a 32 KiB hand-over
+//     buffer in LDS;
 //   * a hidden step runs tile A then tile B: the epilogue of A (writing K blocks 0..7 of the next
 //     X image IN PLACE, once every matrix wave is past K block 7 of tile B) runs under the K loop of B,
 //     the epilogue of B (K blocks 8..15) under the first half of the NEXT step's K loop of A, which
 //     reads K blocks 0..7 only: 96 KiB of X, 32 KiB of hand-over -- the LDS the ws kernels allocate;
-//   * the barriers ("S1: K blocks 8..15 are in X", "S2: A handed over", "S3: K blocks 0..7 consumed",
-//     "S3b: K blocks 0..7 of the next image are in X", "S4: B handed over") sit INSIDE the matrix
-//     waves' stream, in front of the operand reads they guard: no K loop starts cold;
-//   * a features-only step multiplies both tiles per K block (the features of a segment of eight K
-//     blocks are gone after it) while the vector waves generate the next segment, one barrier per
-//     segment; its LAST segment runs tile by tile like a hidden step, so that the first epilogue
-//     hides too.
+//   * the barriers ("S4: B of the step before handed over", "S1: K blocks 8..15 are in X", "S2: A
+//     handed over", "S3: K blocks 0..7 consumed", "S3b: K blocks 0..7 of the next image are in X") sit
+//     INSIDE the matrix waves' stream, in front of the operand reads they guard: no K loop starts
+//     cold, a hand-over's LDS stores run under the next tile's first unit;
+//   * a features-only step multiplies a segment of eight K blocks tile by tile (A, then B over the
+//     same operands) while the vector waves generate the next segment into the other half of X, one
+//     barrier per segment; the first segment of the NEXT pass is generated under the last step's
+//     tile B (K blocks 0..7 are free from S3 on), so that a pass starts multiplying at once;
+//   * what nobody waits for -- the slab, mask and dZ stores to HBM -- goes behind the barrier that
+//     releases the matrix waves.
 //
 // Arithmetic per accumulator is mlp_bf16_ws.hip's (the six partial products of a K block in the same
-// order, K blocks ascending, one accumulator in the forward): hidden activations, slabs and sign
-// masks are bit-identical; the fused heads' partial sums meet in another order (1e-7).
+// order, K blocks ascending; one accumulator in the forward, the small products on their own in the
+// backward): hidden activations, slabs, sign masks and dZ are bit-identical; the fused heads'
+// partial sums meet in another order (1e-7).
 //
 // Covers chains whose first step is features-only (a multiple of sixteen K blocks) and whose other
-// steps are 256 -> 256 (sixteen activation K blocks, eight output tiles): the tiny NeRF / Fourier
-// MLP family.  Everything else runs the ws kernels (mv_covers).
+// steps are 256 -> 256 (sixteen activation K blocks, eight output tiles), and their backward-data
+// chains: the tiny NeRF / Fourier MLP family.  Everything else runs the ws kernels (mv_covers).
 #include <type_traits>
 
 #include "bf16_ring.h"
@@ -299,9 +304,10 @@ __device__ __forceinline__ void mv_take_over(const MvCtx& w, f32x16& acc) {
 // tile B reads K blocks 8..15)
 
 // ---------------------------------------------------------------------------------- the matrix waves
-// Barriers of a step, in order (the vector waves' code has the same list):
-//   features-only: F_0 .. F_{segments-2} (segment s + 1 is in X, segment s consumed), S2, S3, S3b, S4
-//   hidden:        S1, S2, S3, S3b, S4
+// Barriers of a pass, in order (the vector waves' code has the same list):
+//   features-only: F_0 .. F_{segments-2} (segment s + 1 is in X, segment s consumed), S2, S3, S3b
+//   hidden:        S4 (of the step before), S1, S2, S3, S3b
+//   end of a pass: S4 (of the last step)
 // (the accumulators of the two tiles live across steps: the barrier that publishes a hand-over sits in
 // front of the SECOND unit of whatever the matrix wave multiplies next -- the hand-over's LDS stores and
 // the barrier's wait for them run under the first unit's matrix instructions)
