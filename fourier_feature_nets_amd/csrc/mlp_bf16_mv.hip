@@ -287,7 +287,13 @@ __device__ __forceinline__ void mv_hand_over(const MvCtx& w, const f32x16 (&acc)
             dst[(b * 4 + q) * 64] = v;
         }
 }
+#ifdef MV_KO_VECTOR_IDLE             // (timing only: the vector waves keep the barriers and do nothing else)
+#define MV_VECTOR_WORK 0
+#else
+#define MV_VECTOR_WORK 1
+#endif
 __device__ __forceinline__ void mv_take_over(const MvCtx& w, f32x16& acc) {
+    if (!MV_VECTOR_WORK) return;
     const f32x4* src = w.hand + (w.m * 2 + w.sub) * 256 + w.lane;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -383,7 +389,7 @@ __device__ __forceinline__ void mv_generate(const ffn_mlp_chain& ch, const ffn_s
     if (w.saved != nullptr && L.save_enc_slot >= 0 && block0 + fb < w.num_blocks)
         fsave = reinterpret_cast<f32x4*>(w.saved + ch.slot_offset[L.save_enc_slot] * w.num_blocks * 32) +
                 (block0 + fb) * (int64_t)(ch.slot_channels[L.save_enc_slot] * 8);
-    for (int G = rank; G < count; G += stride) {
+    for (int G = rank; G < count && MV_VECTOR_WORK; G += stride) {
         const int k = k0 + G;
         float f[8];
         if (k < g_trig) features16_lockstep<true>(enc, k, w.h, p0, p1, p2, f);
@@ -420,6 +426,7 @@ struct MvDeferred {
 
 __device__ __forceinline__ void mv_epilogue(const ffn_step& L, bool last_step, const MvCtx& w, MvVec& v, int o,
                                             const f32x16& acc, bf16x8 (&res)[2][3], MvDeferred& d) {
+    if (!MV_VECTOR_WORK) return;
     const bool fused_head = L.head_off >= 0;
     const float* hw = w.bias_lds + (fused_head ? L.head_off : 0) + 4 + 16 * w.h;
     if (fused_head && o == 0 && w.h == 0) {
@@ -455,6 +462,7 @@ __device__ __forceinline__ void mv_epilogue(const ffn_step& L, bool last_step, c
 
 __device__ __forceinline__ void mv_epilogue_stores(const ffn_mlp_chain& ch, const ffn_step& L, const MvCtx& w, int o,
                                                    const MvDeferred& d) {
+    if (!MV_VECTOR_WORK) return;
     int save_s = w.s, save_h = w.h, e_lane = w.lane;
     asm volatile("" : "+v"(save_s), "+v"(save_h), "+v"(e_lane));     // (see mlp_bf16.hip: no hoisted address tables)
     const int64_t block = w.block0 + w.sub;
@@ -479,6 +487,7 @@ __device__ __forceinline__ void mv_epilogue_stores(const ffn_mlp_chain& ch, cons
 
 // (tile o, this wave's block) of the output = its share of K blocks 2 o, 2 o + 1 of the next X image
 __device__ __forceinline__ void mv_store_x(const MvCtx& w, int o, const bf16x8 (&res)[2][3]) {
+    if (!MV_VECTOR_WORK) return;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         f32x4* dst = w.xbuf + (2 * o + half) * kMvKbVecs + w.sub * kMvBlkVecs + w.lane;
@@ -856,6 +865,7 @@ __device__ __forceinline__ unsigned mv_load_mask(const ffn_step& L, const MvCtx&
 // the next barrier (mv_epilogue_bwd_stores: see MvDeferred)
 __device__ __forceinline__ void mv_epilogue_bwd(bool last_step, unsigned word, const f32x16& acc, bf16x8 (&res)[2][3],
                                                 MvDeferred& d) {
+    if (!MV_VECTOR_WORK) return;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         float y[8];
@@ -875,6 +885,7 @@ __device__ __forceinline__ void mv_epilogue_bwd(bool last_step, unsigned word, c
 
 __device__ __forceinline__ void mv_epilogue_bwd_stores(const ffn_mlp_chain& ch, const ffn_step& L, const MvCtx& w,
                                                        const MvVecB& v, int o, const MvDeferred& d) {
+    if (!MV_VECTOR_WORK) return;
     int save_s = w.s, save_h = w.h;
     asm volatile("" : "+v"(save_s), "+v"(save_h));
     const int64_t block = w.block0 + w.sub;
