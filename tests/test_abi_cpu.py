@@ -73,3 +73,54 @@ def test_ops_refuse_cpu_tensors():
     from fourier_feature_nets_amd import ops
     with pytest.raises(RuntimeError, match="GPU"):
         ops._dev(torch.zeros(3))
+
+
+def _chain(steps, bias_floats=2000, wide=0):
+    """A chain descriptor with only the fields `ffn_mlp_bf16x6_organisation` looks at: per step
+    (act_groups, aux_groups, out_tiles)."""
+    from fourier_feature_nets_amd import mlp_engine as me
+    chain = me.FfnMlpChain()
+    chain.num_steps = len(steps)
+    chain.bias_floats = bias_floats
+    chain.wide = wide
+    for i, (act, aux, tiles) in enumerate(steps):
+        chain.step[i].act_groups, chain.step[i].aux_groups, chain.step[i].out_tiles = act, aux, tiles
+    return chain
+
+
+def test_bf16x6_organisation_query_is_host_logic(monkeypatch):
+    """`ffn_mlp_bf16x6_organisation` (include/ffn_hip.h) decides on the host which workgroup organisation a
+    bf16x6 chain runs in: 1 = matrix / vector waves (csrc/mlp_bf16_mv.hip) for a features-only first step of
+    16 j K blocks followed by 256 -> 256 steps with eight output tiles (groups are half K blocks), and for the
+    backward chains of the same models (the d_logits term alone in step 0); 0 = two waves per SIMD for
+    everything else, and for everything under FFN_BF16X6_ORG=ws."""
+    import ctypes
+    lib = _lib.load()
+    fn = lib.ffn_mlp_bf16x6_organisation
+    fn.restype = ctypes.c_int
+    monkeypatch.delenv("FFN_BF16X6_ORG", raising=False)
+    monkeypatch.delenv("FFN_BF16X6_PRODUCTS", raising=False)
+    monkeypatch.delenv("FFN_BF16X6_FWD_ACCS", raising=False)
+
+    def org(chain, backward=0):
+        return fn(ctypes.byref(chain), ctypes.c_int(backward))
+
+    tiny = _chain([(0, 64, 8), (32, 0, 8), (32, 0, 8)])            # 510 features -> 32 K blocks, two hidden steps
+    assert org(tiny) == 1
+    assert org(_chain([(0, 64, 8)] + [(32, 0, 8)] * 7)) == 1      # eight layers
+    assert org(_chain([(0, 32, 8), (32, 0, 8)])) == 1             # 16 K blocks of features, one hidden step
+    for other in ([(0, 64, 8)],                                    # a single step
+                  [(0, 8, 8), (32, 0, 8)],                         # NeRF's 63-channel encoding: 4 K blocks
+                  [(0, 48, 8), (32, 0, 8)],                        # 24 K blocks: not 16 j
+                  [(0, 64, 8), (32, 8, 8), (32, 0, 8)],            # a skip connection (activations + features)
+                  [(0, 64, 8), (32, 0, 4), (16, 0, 8)],            # a 128-wide layer
+                  [(0, 4, 8), (32, 0, 8)]):                        # three raw inputs
+        assert org(_chain(other)) == 0, other
+    assert org(_chain([(0, 64, 8), (32, 0, 8)], bias_floats=5000)) == 0     # a bias buffer beyond its LDS copy
+    assert org(_chain([(0, 64, 8), (32, 0, 8)], wide=2)) == 0
+    # backward-data chains: step 0 is the d_logits term alone, then 256 -> 256
+    assert org(_chain([(0, 4, 8), (32, 0, 8), (32, 0, 8)]), 1) == 1
+    assert org(_chain([(32, 4, 8), (32, 0, 8)]), 1) == 0           # a head fused mid-chain
+    assert org(_chain([(0, 4, 8), (32, 0, 4)]), 1) == 0
+    monkeypatch.setenv("FFN_BF16X6_ORG", "ws")
+    assert org(tiny) == 0 and org(_chain([(0, 4, 8), (32, 0, 8)]), 1) == 0
