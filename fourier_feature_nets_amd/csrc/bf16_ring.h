@@ -27,7 +27,12 @@ __device__ __forceinline__ void split8(const float (&x)[8], bf16x8& hi, bf16x8& 
 
 // Three-way split: x = hi + mid + lo EXACTLY (8 + 8 + 8 significand bits cover f32's 24; both
 // remainders are exact f32 subtractions).  The operands of the f32-accurate "bf16x6" mode.
+// On PAIRS of values: one v_cvt_pk_bf16_f32 converts two, and its packed result IS the operand layout
+// (element 2 i in the low half of dword i) -- 5.5 vector instructions per value where a conversion per
+// value, a shift back and the packing at the end compile to 8.5.  -DFFN_SPLIT_ONE_AT_A_TIME keeps that
+// form (A/B; identical bits: the same round-to-nearest-even conversions, the same exact remainders).
 __device__ __forceinline__ void split8x3(const float (&x)[8], bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+#ifdef FFN_SPLIT_ONE_AT_A_TIME
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const __bf16 h = (__bf16)x[j];
@@ -37,6 +42,31 @@ __device__ __forceinline__ void split8x3(const float (&x)[8], bf16x8& hi, bf16x8
         mid[j] = m;
         lo[j] = (__bf16)(r - (float)m);
     }
+#else
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    u4 ph, pm, pl;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f2 v;
+        v[0] = x[2 * i]; v[1] = x[2 * i + 1];
+        const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(v, b2));
+        f2 r;
+        r[0] = v[0] - __builtin_bit_cast(float, h << 16);
+        r[1] = v[1] - __builtin_bit_cast(float, h & 0xffff0000u);
+        const unsigned m = __builtin_bit_cast(unsigned, __builtin_convertvector(r, b2));
+        f2 q;
+        q[0] = r[0] - __builtin_bit_cast(float, m << 16);
+        q[1] = r[1] - __builtin_bit_cast(float, m & 0xffff0000u);
+        ph[i] = h;
+        pm[i] = m;
+        pl[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(q, b2));
+    }
+    hi = __builtin_bit_cast(bf16x8, ph);
+    mid = __builtin_bit_cast(bf16x8, pm);
+    lo = __builtin_bit_cast(bf16x8, pl);
+#endif
 }
 
 struct Ring16 {
@@ -265,19 +295,6 @@ __device__ __forceinline__ void features16_lockstep(const Enc16& enc, int G, int
         }
     }
 #undef FFN_L4
-}
-
-// split8x3 level by level over the eight values (identical bits; see features16_lockstep)
-__device__ __forceinline__ void split8x3_lockstep(const float (&x)[8], bf16x8& hi, bf16x8& mid, bf16x8& lo) {
-    __bf16 h[8], m[8];
-    float r[8];
-#define FFN_L8 _Pragma("unroll") for (int j = 0; j < 8; ++j)
-    FFN_L8 h[j] = (__bf16)x[j];
-    FFN_L8 r[j] = x[j] - (float)h[j];
-    FFN_L8 m[j] = (__bf16)r[j];
-    FFN_L8 r[j] = r[j] - (float)m[j];
-    FFN_L8 { hi[j] = h[j]; mid[j] = m[j]; lo[j] = (__bf16)r[j]; }
-#undef FFN_L8
 }
 
 // Hardware sin / cos for the split-bf16 kernels: exact two-constant reduction by 2 pi (the angle is

@@ -403,7 +403,7 @@ __device__ __forceinline__ void mv_generate(const ffn_mlp_chain& ch, const ffn_s
             __builtin_nontemporal_store(f1, &fsave[saved_index16(cq + 1, w.s)]);
         }
         bf16x8 fp[3];
-        split8x3_lockstep(f, fp[0], fp[1], fp[2]);
+        split8x3(f, fp[0], fp[1], fp[2]);
         f32x4* dst = w.xbuf + (k & 15) * kMvKbVecs + fb * kMvBlkVecs + w.lane;
 #pragma unroll
         for (int part = 0; part < 3; ++part) dst[64 * part] = __builtin_bit_cast(f32x4, fp[part]);
@@ -455,7 +455,7 @@ __device__ __forceinline__ void mv_epilogue(const ffn_step& L, bool last_step, c
                 for (int c = 0; c < 4; ++c) v.logit[c] = __builtin_fmaf(y[j], w4[c], v.logit[c]);
             }
         }
-        if (!last_step) split8x3_lockstep(y, res[half][0], res[half][1], res[half][2]);
+        if (!last_step) split8x3(y, res[half][0], res[half][1], res[half][2]);
     }
     d.sign_bits = sign_bits;
 }
@@ -879,7 +879,7 @@ __device__ __forceinline__ void mv_epilogue_bwd(bool last_step, unsigned word, c
             y[j] = __builtin_bit_cast(float, __builtin_bit_cast(int, a) & keep);
             d.y[8 * half + j] = y[j];
         }
-        if (!last_step) split8x3_lockstep(y, res[half][0], res[half][1], res[half][2]);
+        if (!last_step) split8x3(y, res[half][0], res[half][1], res[half][2]);
     }
 }
 
