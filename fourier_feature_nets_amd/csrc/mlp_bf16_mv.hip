@@ -62,6 +62,8 @@ constexpr int kMvWaves = 4 + 4 * kMvVecPerSimd;
 constexpr int kMvThreads = 64 * kMvWaves;
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef const f32x4 __attribute__((address_space(1)))* mv_gptr;
+typedef const char __attribute__((address_space(1)))* mv_gbytes;
 
 // -DMV_STAMPS (scripts/probes/mv_stamps.py builds that variant library): cycle stamps of one pass of
 // workgroup 0 -- (id, s_memtime) pairs of its matrix wave 0 and its vector wave 4
@@ -84,6 +86,9 @@ struct MvCtx {
     const i32x4* tbl4;             // LDS: refill table, entry t = units 4t+3 .. 4t+6 (mod U)
     int trips_total;               // U / 4
     const f32x4* gw;               // the chain's operand packs
+    mv_gptr gwm;                   // ... from this wave's tile on (gw + m tiles): the SGPR base of every weight request
+    int lane16;                    // lane * 16: the VGPR part of a request's address, next to the table entry (a byte offset)
+    int b_step1, b_stride;         // bias offset of step li >= 1: b_step1 + (li - 1) * b_stride (mv_covers) -- no load in the stream
     int64_t block0, num_blocks;
     float* saved;
     char* masks;
@@ -129,8 +134,6 @@ struct MvProducts {
     static constexpr int X[6] = {2, 0, 1, 1, 0, 0};
 };
 
-typedef const f32x4 __attribute__((address_space(1)))* mv_gptr;
-
 // One unit: the 12 matrix instructions of (one tile, one K block) out of ring slot J and hi-operand
 // set HB.  READX: the operands of the next K block stream in behind the matrix instructions that free
 // their registers (lo behind the first product; hi and mid -- other set -- behind the second and third);
@@ -144,9 +147,14 @@ typedef const f32x4 __attribute__((address_space(1)))* mv_gptr;
 // TWO (backward data): the five small partial products accumulate on `lo`, h.h on `acc` (mlp_bf16_ws.hip:
 // the matrix unit's accumulation is not round-to-nearest); they meet at the end of the K loop.
 template <int J, int HB, int READX, int FIRST = 0, bool TWO = false>       // READX: bit 0 = the lo parts (in place), bit 1 = the hi and mid parts (other set)
-__device__ __forceinline__ void mv_unit(const MvCtx& w, f32x16 (&acc)[2], f32x16 (&lo)[2], MvMat& r, const f32x4* xnext, mv_gptr refill, bool bar) {
+__device__ __forceinline__ void mv_unit(const MvCtx& w, f32x16 (&acc)[2], f32x16 (&lo)[2], MvMat& r, const f32x4* xnext, bool bar) {
     typedef MvProducts P;
-    const int lane = w.lane;
+    // the weight requests' address: one SGPR base for the whole kernel (w.gwm) + a 32-bit VGPR offset = the
+    // table entry of this unit (a byte offset, the same in every lane) + lane * 16 -- ONE vector add, issued
+    // behind the fifth matrix instruction.  (Four 64-bit SGPR bases per trip -- readfirstlane, add, two
+    // multiplies, add, add-with-carry each -- were 31 instructions in a row at the head of every trip: ~3 cycles
+    // per matrix instruction of a stream whose pipe drains in 32.)
+    unsigned voff = 0;
     if (bar) {
         MV_STAMP(w, 30);
         mv_barrier();
@@ -181,6 +189,7 @@ __device__ __forceinline__ void mv_unit(const MvCtx& w, f32x16 (&acc)[2], f32x16
         if constexpr ((READX & 2) != 0 && q == 1) r.xh[HB ^ 1][b] = __builtin_bit_cast(bf16x8, xnext[b * kMvBlkVecs]);
         if constexpr ((READX & 2) != 0 && q == 2) r.xm[HB ^ 1][b] = __builtin_bit_cast(bf16x8, xnext[b * kMvBlkVecs + 64]);
         }
+        if constexpr (g == 5) asm volatile("v_add_u32 %0, %1, %2" : "=v"(voff) : "v"(r.cur[J]), "v"(w.lane16));
         // the weight requests: behind groups 6, 7, 8
         constexpr int slot = g >= 6 && g < 9 ? g - 6 : -1;
 #ifdef MV_KO_PAIR_W
@@ -188,7 +197,13 @@ __device__ __forceinline__ void mv_unit(const MvCtx& w, f32x16 (&acc)[2], f32x16
 #else
         if constexpr (slot >= 0)
 #endif
-            r.wr[(J + 3) & 3][slot] = __builtin_bit_cast(bf16x8, refill[slot * 64 + lane]);
+            r.wr[(J + 3) & 3][slot] = __builtin_bit_cast(bf16x8, *reinterpret_cast<mv_gptr>(reinterpret_cast<mv_gbytes>(w.gwm) + (uint64_t)voff + slot * 1024));
+        // the table entry of the NEXT trip: behind the last request of this one (five matrix instructions
+        // ahead of its first use)
+        if constexpr (J == 3 && g == 9) {
+            r.tq = r.tq + 1 < w.trips_total ? r.tq + 1 : 0;
+            r.cur = w.tbl4[r.tq];
+        }
         __builtin_amdgcn_sched_barrier(0);
     };
     typedef std::integral_constant<int, 0> i0;
@@ -202,18 +217,6 @@ __device__ __forceinline__ void mv_unit(const MvCtx& w, f32x16 (&acc)[2], f32x16
     group(std::integral_constant<int, 5>{}, i0{}); group(std::integral_constant<int, 5>{}, i1{});
 }
 
-// the refill bases of a trip (four SGPR pointers) and the table entry of the next one
-__device__ __forceinline__ void mv_trip_bases(const MvCtx& w, MvMat& r, mv_gptr (&base)[4]) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int e = __builtin_amdgcn_readfirstlane(r.cur[j]);
-        base[j] = (mv_gptr)(w.gw + (int64_t)(e + w.m) * kMvTileVecs);
-        asm volatile("" : "+s"(base[j]));
-    }
-    r.tq = r.tq + 1 < w.trips_total ? r.tq + 1 : 0;
-    r.cur = w.tbl4[r.tq];
-}
-
 // The K loop of ONE tile over `trips` x 4 K blocks of X from K block g0 (operands of g0 already in the
 // registers); the last unit streams K block g_after in -- the first one of whatever comes next.
 // bars: bit 4 t + j = barrier in front of unit j of trip t.  FIRST != 0: the tile starts here (1: acc[0]
@@ -223,12 +226,10 @@ __device__ __forceinline__ void mv_k_loop2(const MvCtx& w, MvMat& r, f32x16 (&ac
                                            int g_after, unsigned bars) {
     const f32x4* xb = w.xbuf + w.lane;
     if constexpr (FIRST != 0) {
-        mv_gptr base[4];
-        mv_trip_bases(w, r, base);
-        mv_unit<0, 0, 3, FIRST, TWO>(w, acc, lo, r, xb + (g0 + 1) * kMvKbVecs, base[0], (bars & 1u) != 0);
-        mv_unit<1, 1, 3, 0, TWO>(w, acc, lo, r, xb + (g0 + 2) * kMvKbVecs, base[1], (bars & 2u) != 0);
-        mv_unit<2, 0, 3, 0, TWO>(w, acc, lo, r, xb + (g0 + 3) * kMvKbVecs, base[2], (bars & 4u) != 0);
-        mv_unit<3, 1, 3, 0, TWO>(w, acc, lo, r, xb + (trips == 1 ? g_after : g0 + 4) * kMvKbVecs, base[3], (bars & 8u) != 0);
+        mv_unit<0, 0, 3, FIRST, TWO>(w, acc, lo, r, xb + (g0 + 1) * kMvKbVecs, (bars & 1u) != 0);
+        mv_unit<1, 1, 3, 0, TWO>(w, acc, lo, r, xb + (g0 + 2) * kMvKbVecs, (bars & 2u) != 0);
+        mv_unit<2, 0, 3, 0, TWO>(w, acc, lo, r, xb + (g0 + 3) * kMvKbVecs, (bars & 4u) != 0);
+        mv_unit<3, 1, 3, 0, TWO>(w, acc, lo, r, xb + (trips == 1 ? g_after : g0 + 4) * kMvKbVecs, (bars & 8u) != 0);
     }
     // (not unrolled: with constant trip counts hipcc unrolls, turns the operand addresses beyond the 64 KiB
     // immediate range into values it keeps -- and SPILLS them: scratch traffic inside the stream, in
@@ -237,13 +238,11 @@ __device__ __forceinline__ void mv_k_loop2(const MvCtx& w, MvMat& r, f32x16 (&ac
     for (int t = FIRST != 0 ? 1 : 0; t < trips; ++t) {
         const int g = g0 + 4 * t;
         const int g4 = t + 1 == trips ? g_after : g + 4;
-        mv_gptr base[4];
-        mv_trip_bases(w, r, base);
         const unsigned bt = bars >> (4 * t);
-        mv_unit<0, 0, 3, 0, TWO>(w, acc, lo, r, xb + (g + 1) * kMvKbVecs, base[0], (bt & 1u) != 0);
-        mv_unit<1, 1, 3, 0, TWO>(w, acc, lo, r, xb + (g + 2) * kMvKbVecs, base[1], (bt & 2u) != 0);
-        mv_unit<2, 0, 3, 0, TWO>(w, acc, lo, r, xb + (g + 3) * kMvKbVecs, base[2], (bt & 4u) != 0);
-        mv_unit<3, 1, 3, 0, TWO>(w, acc, lo, r, xb + g4 * kMvKbVecs, base[3], (bt & 8u) != 0);
+        mv_unit<0, 0, 3, 0, TWO>(w, acc, lo, r, xb + (g + 1) * kMvKbVecs, (bt & 1u) != 0);
+        mv_unit<1, 1, 3, 0, TWO>(w, acc, lo, r, xb + (g + 2) * kMvKbVecs, (bt & 2u) != 0);
+        mv_unit<2, 0, 3, 0, TWO>(w, acc, lo, r, xb + (g + 3) * kMvKbVecs, (bt & 4u) != 0);
+        mv_unit<3, 1, 3, 0, TWO>(w, acc, lo, r, xb + g4 * kMvKbVecs, (bt & 8u) != 0);
     }
 }
 template <bool FIRST = false>
@@ -264,8 +263,8 @@ __device__ __forceinline__ void mv_read_x0(const MvCtx& w, MvMat& r, int G) {
 }
 
 // the bias of output tile o in the accumulator layout of one block, straight into a tile's acc[0] (see FIRST)
-__device__ __forceinline__ void mv_load_bias(const MvCtx& w, const ffn_step& L, int o, f32x16& acc0) {
-    const float* bv = w.bias_lds + L.b_off + 32 * o + 4 * w.h;       // (mv_covers: the whole bias buffer is staged)
+__device__ __forceinline__ void mv_load_bias(const MvCtx& w, int b_off, int o, f32x16& acc0) {
+    const float* bv = w.bias_lds + b_off + 32 * o + 4 * w.h;         // (mv_covers: the whole bias buffer is staged)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const f32x4 b4 = *reinterpret_cast<const f32x4*>(bv + 8 * q);
@@ -321,10 +320,9 @@ struct MvAcc {
     f32x16 a[2], b[2];
 };
 
-__device__ __forceinline__ void mv_matrix_features(const ffn_step& L, const ffn_step& L1, const MvCtx& w, MvMat& r, MvAcc& c) {
-    const int segments = L.aux_groups >> 4;        // (K blocks: a multiple of sixteen, mv_covers)
-    mv_load_bias(w, L, w.m, c.a[0]);
-    mv_load_bias(w, L, w.m + 4, c.b[0]);
+__device__ __forceinline__ void mv_matrix_features(int segments, int b_off, const MvCtx& w, MvMat& r, MvAcc& c) {
+    mv_load_bias(w, b_off, w.m, c.a[0]);
+    mv_load_bias(w, b_off, w.m + 4, c.b[0]);
     mv_read_x0(w, r, 0);                           // (segment 0 is in X: the first pass's prologue, or S4 of the pass before)
     MV_STAMP(w, 9);
     // every segment tile by tile (eight K blocks of tile A, then the same eight of tile B): the barrier F
@@ -344,21 +342,23 @@ __device__ __forceinline__ void mv_matrix_features(const ffn_step& L, const ffn_
     mv_k_loop(w, r, c.a, 8, 2, 8, 0u);
     MV_STAMP(w, 11);
     mv_hand_over(w, c.a);
-    mv_load_bias(w, L1, w.m, c.a[0]);              // (tile A of the next step starts from it)
+    mv_load_bias(w, w.b_step1, w.m, c.a[0]);       // (tile A of the next step starts from it)
     mv_k_loop(w, r, c.b, 8, 2, 0, 0xA2u);                                                    // S2, S3, S3b: units 1, 5, 7
     MV_STAMP(w, 13);
     // (tile B is handed over in front of the next step's tile A)
 }
 
-__device__ __forceinline__ void mv_matrix_hidden(const ffn_step& L, const ffn_step& next, bool last_step, const MvCtx& w,
-                                                 MvMat& r, MvAcc& c) {
+// (b_off: this step's biases; the next step's are b_stride further -- scalar arithmetic: a load of a step's
+// descriptor here, from the kernel's arguments, is an s_load and an lgkmcnt(0) in front of the tile's first
+// matrix instruction -- with the hand-over's eight LDS stores in the queue)
+__device__ __forceinline__ void mv_matrix_hidden(int b_off, bool last_step, const MvCtx& w, MvMat& r, MvAcc& c) {
     MV_STAMP(w, 20);
     mv_hand_over(w, c.b);                          // tile B of the step before
-    mv_load_bias(w, L, w.m + 4, c.b[0]);
+    mv_load_bias(w, b_off, w.m + 4, c.b[0]);
     mv_k_loop<true>(w, r, c.a, 0, 4, 0, 0x82u);                                              // S4, S1: units 1, 7
     MV_STAMP(w, 21);
     mv_hand_over(w, c.a);
-    if (!last_step) mv_load_bias(w, next, w.m, c.a[0]);
+    if (!last_step) mv_load_bias(w, b_off + w.b_stride, w.m, c.a[0]);
     // (the last step stores nothing into X: S3b right behind S3, and the vector waves have the rest of
     // this K loop for the next pass's first segment of features)
     mv_k_loop<true>(w, r, c.b, 0, 4, 0, last_step ? 0x182u : 0x882u);                        // S2, S3, S3b: units 1, 7, 11 (1, 7, 8)
@@ -424,8 +424,9 @@ struct MvDeferred {
     unsigned sign_bits;
 };
 
-__device__ __forceinline__ void mv_epilogue(const ffn_step& L, bool last_step, const MvCtx& w, MvVec& v, int o,
-                                            const f32x16& acc, bf16x8 (&res)[2][3], MvDeferred& d) {
+template <bool TRAIN>                                // (inference: no sign bits, nothing kept for the HBM stores)
+__device__ __forceinline__ void mv_epilogue_t(const ffn_step& L, bool last_step, const MvCtx& w, MvVec& v, int o,
+                                              const f32x16& acc, bf16x8 (&res)[2][3], MvDeferred& d) {
     if (!MV_VECTOR_WORK) return;
     const bool fused_head = L.head_off >= 0;
     const float* hw = w.bias_lds + (fused_head ? L.head_off : 0) + 4 + 16 * w.h;
@@ -442,9 +443,9 @@ __device__ __forceinline__ void mv_epilogue(const ffn_step& L, bool last_step, c
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float a = acc[8 * half + j];
-            sign_bits = __builtin_amdgcn_alignbit(sign_bits, __builtin_bit_cast(unsigned, 0.0f - a), 31);
+            if (TRAIN) sign_bits = __builtin_amdgcn_alignbit(sign_bits, __builtin_bit_cast(unsigned, 0.0f - a), 31);
             y[j] = __builtin_bit_cast(float, __builtin_elementwise_max(__builtin_bit_cast(int, a), relu_floor));
-            d.y[8 * half + j] = y[j];
+            if (TRAIN) d.y[8 * half + j] = y[j];
         }
         if (fused_head) {
 #pragma unroll
@@ -458,6 +459,11 @@ __device__ __forceinline__ void mv_epilogue(const ffn_step& L, bool last_step, c
         if (!last_step) split8x3(y, res[half][0], res[half][1], res[half][2]);
     }
     d.sign_bits = sign_bits;
+}
+__device__ __forceinline__ void mv_epilogue(const ffn_step& L, bool last_step, const MvCtx& w, MvVec& v, int o,
+                                            const f32x16& acc, bf16x8 (&res)[2][3], MvDeferred& d) {
+    if (w.saved != nullptr || w.masks != nullptr) mv_epilogue_t<true>(L, last_step, w, v, o, acc, res, d);
+    else mv_epilogue_t<false>(L, last_step, w, v, o, acc, res, d);
 }
 
 __device__ __forceinline__ void mv_epilogue_stores(const ffn_mlp_chain& ch, const ffn_step& L, const MvCtx& w, int o,
@@ -591,7 +597,7 @@ mlp_forward_bf16_mv_kernel(const ffn_mlp_chain ch, const uint16_t* __restrict__ 
         // the refill table: tbl[i] = unit (i + 3) mod U, so that int4 entry t holds what trip t refills
         int* units = reinterpret_cast<int*>(smem);             // (X is not in use yet)
         const int u_total = mv_build_units(ch, units);
-        for (int i = 0; i < u_total; ++i) tbl[i] = units[(i + 3) % u_total];
+        for (int i = 0; i < u_total; ++i) tbl[i] = units[(i + 3) % u_total] * (kMvTileVecs * 16);       // (byte offsets)
     }
     MvCtx w;
     w.lane = threadIdx.x & 63;
@@ -609,6 +615,10 @@ mlp_forward_bf16_mv_kernel(const ffn_mlp_chain ch, const uint16_t* __restrict__ 
     w.tbl4 = reinterpret_cast<const i32x4*>(tbl);
     w.trips_total = num_units >> 2;
     w.gw = reinterpret_cast<const f32x4*>(packed + ch.step[0].w_off);
+    w.gwm = (mv_gptr)(w.gw + w.m * kMvTileVecs);
+    w.lane16 = w.lane * 16;
+    w.b_step1 = (int)ch.step[1].b_off;
+    w.b_stride = ch.num_steps > 2 ? (int)(ch.step[2].b_off - ch.step[1].b_off) : 0;
     w.saved = saved;
     w.masks = reinterpret_cast<char*>(masks);
     w.num_blocks = (n + 31) / 32;
@@ -617,7 +627,8 @@ mlp_forward_bf16_mv_kernel(const ffn_mlp_chain ch, const uint16_t* __restrict__ 
     __syncthreads();                               // tables, biases and the unit table are staged
 
     const ffn_step& L0 = ch.step[0];
-    const int segments = L0.aux_groups >> 4;
+    const int segments = L0.aux_groups >> 4;       // (K blocks: a multiple of sixteen, mv_covers)
+    const int num_steps = ch.num_steps, b_step0 = (int)L0.b_off;
     const int fb = w.wave & 1;
     auto inputs_of = [&](int64_t pass, MvVec& dst) {
         int64_t block = pass * 2 + fb;
@@ -645,10 +656,9 @@ mlp_forward_bf16_mv_kernel(const ffn_mlp_chain ch, const uint16_t* __restrict__ 
         const i32x4 first = w.tbl4[w.trips_total - 1];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const int e = __builtin_amdgcn_readfirstlane(first[j + 1]);
-            mv_gptr base = (mv_gptr)(w.gw + (int64_t)(e + w.m) * kMvTileVecs);
+            mv_gptr base = reinterpret_cast<mv_gptr>(reinterpret_cast<mv_gbytes>(w.gwm) + (uint64_t)(unsigned)(first[j + 1] + w.lane16));
 #pragma unroll
-            for (int part = 0; part < 3; ++part) r.wr[j][part] = __builtin_bit_cast(bf16x8, base[part * 64 + w.lane]);
+            for (int part = 0; part < 3; ++part) r.wr[j][part] = __builtin_bit_cast(bf16x8, base[part * 64]);
         }
         r.tq = 0;
         r.cur = w.tbl4[0];
@@ -658,11 +668,9 @@ mlp_forward_bf16_mv_kernel(const ffn_mlp_chain ch, const uint16_t* __restrict__ 
             w.stamp_n = 0;
 #endif
             MV_STAMP(w, 1);
-            mv_matrix_features(L0, ch.step[1], w, r, c);
-            for (int li = 1; li < ch.num_steps; ++li) {
-                const bool last = li + 1 == ch.num_steps;
-                mv_matrix_hidden(ch.step[li], ch.step[last ? li : li + 1], last, w, r, c);
-            }
+            mv_matrix_features(segments, b_step0, w, r, c);
+            for (int li = 1; li < num_steps; ++li)
+                mv_matrix_hidden(w.b_step1 + (li - 1) * w.b_stride, li + 1 == num_steps, w, r, c);
             mv_hand_over(w, c.b);                  // (the last tile of the pass: nothing follows to carry its barrier)
             mv_barrier();                                                                    // S4
             MV_STAMP(w, 24);
@@ -728,6 +736,8 @@ bool mv_covers(const ffn_mlp_chain* chain, int* num_units) {
         const ffn_step& L = chain->step[i];
         const int kb_act = L.act_groups >> 1, kb_feat = L.aux_groups >> 1;
         if (L.out_tiles != 8) return false;
+        // (the matrix waves compute a step's bias offset: equally spaced from step 1 on)
+        if (i >= 2 && L.b_off - chain->step[1].b_off != (i - 1) * (chain->step[2].b_off - chain->step[1].b_off)) return false;
         if (i == 0) {
             if (kb_act != 0 || kb_feat < 16 || (kb_feat & 15) != 0) return false;
             units += 2 * kb_feat;
@@ -788,16 +798,14 @@ __device__ __forceinline__ void mv_matrix_bwd_first(const MvCtx& w, MvMat& r, Mv
     const f32x4* xb = w.xbuf + w.lane;
     MV_STAMP(w, 80);
     mv_read_x0(w, r, 0);                           // (published by the prologue, or by S4 of the pass before)
-    mv_gptr base[4];
-    mv_trip_bases(w, r, base);
-    mv_unit<0, 0, 3, 2, kMvBwdTwo>(w, c.main, c.lo, r, xb + kMvKbVecs, base[0], false);
-    mv_unit<1, 1, 3, 0, kMvBwdTwo>(w, c.main, c.lo, r, xb, base[1], false);
+    mv_unit<0, 0, 3, 2, kMvBwdTwo>(w, c.main, c.lo, r, xb + kMvKbVecs, false);
+    mv_unit<1, 1, 3, 0, kMvBwdTwo>(w, c.main, c.lo, r, xb, false);
     MV_STAMP(w, 81);
     mv_meet_and_hand_over(w, c);                   // tile A
     mv_barrier();                                                                            // S2
     MV_STAMP(w, 82);
-    mv_unit<2, 0, 3, 2, kMvBwdTwo>(w, c.main, c.lo, r, xb + kMvKbVecs, base[2], false);
-    mv_unit<3, 1, 0, 0, kMvBwdTwo>(w, c.main, c.lo, r, nullptr, base[3], false);
+    mv_unit<2, 0, 3, 2, kMvBwdTwo>(w, c.main, c.lo, r, xb + kMvKbVecs, false);
+    mv_unit<3, 1, 0, 0, kMvBwdTwo>(w, c.main, c.lo, r, nullptr, false);
     MV_STAMP(w, 83);
     mv_barrier();                                                                            // S3: K blocks 0, 1 consumed
     MV_STAMP(w, 84);
@@ -946,7 +954,7 @@ mlp_backward_bf16_mv_kernel(const ffn_mlp_chain ch, const uint16_t* __restrict__
     if (threadIdx.x == 0) {
         int* units = reinterpret_cast<int*>(smem);             // (X is not in use yet)
         const int u_total = mv_build_units_bwd(ch, units);
-        for (int i = 0; i < u_total; ++i) tbl[i] = units[(i + 3) % u_total];
+        for (int i = 0; i < u_total; ++i) tbl[i] = units[(i + 3) % u_total] * (kMvTileVecs * 16);       // (byte offsets)
     }
     MvCtx w;
     w.lane = threadIdx.x & 63;
@@ -964,6 +972,9 @@ mlp_backward_bf16_mv_kernel(const ffn_mlp_chain ch, const uint16_t* __restrict__
     w.tbl4 = reinterpret_cast<const i32x4*>(tbl);
     w.trips_total = num_units >> 2;
     w.gw = reinterpret_cast<const f32x4*>(packed + ch.step[0].w_off);
+    w.gwm = (mv_gptr)(w.gw + w.m * kMvTileVecs);
+    w.lane16 = w.lane * 16;
+    w.b_step1 = w.b_stride = 0;
     w.saved = nullptr;
     w.masks = nullptr;
 #ifdef MV_STAMPS
@@ -982,10 +993,9 @@ mlp_backward_bf16_mv_kernel(const ffn_mlp_chain ch, const uint16_t* __restrict__
         const i32x4 first = w.tbl4[w.trips_total - 1];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const int e = __builtin_amdgcn_readfirstlane(first[j + 1]);
-            mv_gptr base = (mv_gptr)(w.gw + (int64_t)(e + w.m) * kMvTileVecs);
+            mv_gptr base = reinterpret_cast<mv_gptr>(reinterpret_cast<mv_gbytes>(w.gwm) + (uint64_t)(unsigned)(first[j + 1] + w.lane16));
 #pragma unroll
-            for (int part = 0; part < 3; ++part) r.wr[j][part] = __builtin_bit_cast(bf16x8, base[part * 64 + w.lane]);
+            for (int part = 0; part < 3; ++part) r.wr[j][part] = __builtin_bit_cast(bf16x8, base[part * 64]);
         }
         r.tq = 0;
         r.cur = w.tbl4[0];
