@@ -36,6 +36,7 @@ sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 TRAFFIC_PROFILE = "profiles/r06_hbm_traffic.json"
+SUSTAINED_PROFILE = "profiles/r06_sustained_bf16_matrix_rate.json"
 
 KERNEL_OF = {"ffn_mlp_forward": "mlp_forward_kernel<train>",
              "ffn_mlp_backward_data": "mlp_backward_data_kernel",
@@ -368,6 +369,22 @@ def git_head():
         with open(os.path.join(ROOT, ".git_head")) as f:
             return f.read().strip() or None
     except OSError:
+        return None
+
+
+def sustained_matrix_rates():
+    """The committed record of scripts/probes/mfma_sustained_probe + chain_stream_probe `sustained`
+    (power-limited bf16 matrix rates of the whole chip on random three-part operands); None if absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), SUSTAINED_PROFILE)
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+        return {"file": SUSTAINED_PROFILE,
+                "matrix_rate_tflops": rec["reading"]["sustained_matrix_rate_tflops"],
+                "operand_stream_tflops": rec["reading"]["sustained_operand_stream_tflops"],
+                "note": "back-to-back matrix instructions from registers / the matrix waves' bare stream (LDS operand "
+                        "reads + weights out of the L2s), ~30 ms launches: 2500 TFLOP/s needs 2.4 GHz, random operands clock 1.86 / 1.65 GHz"}
+    except (OSError, KeyError, ValueError):
         return None
 
 
@@ -987,6 +1004,14 @@ def bf16_train_leg(device, dataset, rays_per_step, samples, steps=6, mode="bf16x
                     "emulation_ceiling": "2500 TFLOP/s dense bf16 / %d matrix instructions per f32 product" % info["products"],
                     "algorithmic_flop_per_launch": flop["forward"] * n_samples,
                     "avg_launch_ms": fwd["avg_ms"]}
+        sustained = sustained_matrix_rates()
+        if mode == "bf16x6" and sustained is not None:
+            # a third denominator, MEASURED (committed probe record, another box): what the bf16 matrix pipe
+            # sustains under the chip's power budget on operands with these kernels' statistics
+            issued = fwd["algorithmic_tflops"] * info["products"]
+            roofline["sustained"] = dict(sustained, issued_tflops=round(issued, 1),
+                                         frac_of_sustained_matrix_rate=round(issued / sustained["matrix_rate_tflops"], 4),
+                                         frac_of_sustained_operand_stream=round(issued / sustained["operand_stream_tflops"], 4))
     organisation = None
     if mode == "bf16x6":
         torch.manual_seed(20080524)
