@@ -69,7 +69,11 @@ typedef const char __attribute__((address_space(1)))* mv_gbytes;
 // workgroup 0 -- (id, s_memtime) pairs of its matrix wave 0 and its vector wave 4
 #ifdef MV_STAMPS
 __device__ long long mv_stamp_buf[2][1024];
+#ifdef MV_STAMPS_ENDS               // (only the two ends of a pass: a stamp is an s_memtime behind an lgkmcnt(0) -- ~50 of them move a pass)
+#define MV_STAMP(w, id) do { if ((id) == 1 || (id) == 24 || (id) == 80) mv_stamp((w), (id)); } while (0)
+#else
 #define MV_STAMP(w, id) mv_stamp((w), (id))
+#endif
 #else
 #define MV_STAMP(w, id) ((void)0)
 #endif
