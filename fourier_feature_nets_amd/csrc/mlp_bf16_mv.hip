@@ -774,16 +774,27 @@ int launch_forward_bf16x6_mv(const ffn_mlp_chain* chain, const uint16_t* packed_
 
 // ================================================================================== backward data
 // The same organisation for the backward-data chain of the same models: step 0 takes d(loss)/d(logits)
-// through the fused head (one K block of operands and a zero one, written by the vector waves), every
-// other step is 256 -> 256.  Two accumulators per (tile, block) -- one tile at a time in the matrix
-// wave's registers: it adds them up and hands the tile over before the next one starts.  The vector
-// waves' epilogue: the ReLU mask of the layer being differentiated, the dZ slab, the three-way split.
+// through the fused head, every other step is 256 -> 256.  Two accumulators per (tile, block) -- one tile
+// at a time in the matrix wave's registers: it adds them up and hands the tile over before the next one
+// starts.  The vector waves' epilogue: the ReLU mask of the layer being differentiated, the dZ slab, the
+// three-way split.
+//
+// STEP 0 IS THE VECTOR WAVES' (round 6): four real K rows per output -- 64 fused multiply-adds per lane
+// and tile on head weights kept in LDS as f32 (hi + mid + lo of the pack, exactly).  As matrix work it was
+// 48 matrix instructions (half of them on a zero K block) inside a chain of three barriers in which
+// nothing overlapped: 6-9 k cycles of a 40 k pass.  Its output is the X image of step 1, written where a
+// hidden step's epilogues write theirs: tiles 0..3 (K blocks 0..7) of the NEXT pass between S3 and S3b of
+// the last step, tiles 4..7 (K blocks 8..15) behind the barrier that ends the pass, under the first half of
+// the next pass's first K loop.  The matrix waves' stream is hidden steps only, pass after pass.
+// (The head term in f32 arithmetic instead of six bf16 products: this chain's dZ differs from the
+// two-waves-per-SIMD kernels' in the last bits -- 1e-7 relative -- where the forward's slabs are identical.)
 #ifdef MV_KO_BWD_ONE_ACC            // (timing only: all six products on one accumulator)
 constexpr bool kMvBwdTwo = false;
 #else
 constexpr bool kMvBwdTwo = true;
 #endif
-constexpr size_t kMvBwdLdsBytes = (size_t)kMvXBytes + kMvHandBytes + kMvMaxUnits * 4;
+constexpr int kMvHeadBytes = 256 * 16;             // head weights W[channel][4] as f32
+constexpr size_t kMvBwdLdsBytes = (size_t)kMvXBytes + kMvHandBytes + kMvMaxUnits * 4 + kMvHeadBytes;
 
 struct MvAcc2 {
     f32x16 main[2], lo[2];
@@ -797,65 +808,28 @@ __device__ __forceinline__ void mv_meet_and_hand_over(const MvCtx& w, MvAcc2& c)
     mv_hand_over(w, c.main);
 }
 
-// step 0 (the d_logits term only: X K blocks 0 and 1, both tiles in ONE trip of four units)
-__device__ __forceinline__ void mv_matrix_bwd_first(const MvCtx& w, MvMat& r, MvAcc2& c) {
-    const f32x4* xb = w.xbuf + w.lane;
-    MV_STAMP(w, 80);
-    mv_read_x0(w, r, 0);                           // (published by the prologue, or by S4 of the pass before)
-    mv_unit<0, 0, 3, 2, kMvBwdTwo>(w, c.main, c.lo, r, xb + kMvKbVecs, false);
-    mv_unit<1, 1, 3, 0, kMvBwdTwo>(w, c.main, c.lo, r, xb, false);
-    MV_STAMP(w, 81);
-    mv_meet_and_hand_over(w, c);                   // tile A
-    mv_barrier();                                                                            // S2
-    MV_STAMP(w, 82);
-    mv_unit<2, 0, 3, 2, kMvBwdTwo>(w, c.main, c.lo, r, xb + kMvKbVecs, false);
-    mv_unit<3, 1, 0, 0, kMvBwdTwo>(w, c.main, c.lo, r, nullptr, false);
-    MV_STAMP(w, 83);
-    mv_barrier();                                                                            // S3: K blocks 0, 1 consumed
-    MV_STAMP(w, 84);
-    mv_meet_and_hand_over(w, c);                   // tile B (its barrier S4: in front of the next step's second unit)
-    mv_barrier();                                                                            // S3b: K blocks 0..7 of the next image are in X
-    MV_STAMP(w, 85);
-    mv_read_x0(w, r, 0);
-}
-
-__device__ __forceinline__ void mv_matrix_bwd_hidden(bool last_step, const MvCtx& w, MvMat& r, MvAcc2& c) {
+// a hidden step.  Barriers in the stream: S4 (tile B of the step before handed over; not in a pass's first
+// step: nothing was), S1 (K blocks 8..15 are in X) in K(A); S2, S3, S3b in K(B) -- the LAST step's S3b in
+// front of its last unit, whose operand reads are K block 0 of the next pass's image (the vector waves
+// compute it from S3 on)
+__device__ __forceinline__ void mv_matrix_bwd_hidden(bool first_step, bool last_step, const MvCtx& w, MvMat& r, MvAcc2& c) {
     MV_STAMP(w, 20);
-    mv_k_loop2<2, kMvBwdTwo>(w, r, c.main, c.lo, 0, 4, 0, 0x82u);                                 // S4, S1: units 1, 7
+    mv_k_loop2<2, kMvBwdTwo>(w, r, c.main, c.lo, 0, 4, 0, first_step ? 0x80u : 0x82u);           // (S4,) S1: units (1,) 7
     MV_STAMP(w, 21);
     mv_meet_and_hand_over(w, c);                   // tile A
-    mv_k_loop2<2, kMvBwdTwo>(w, r, c.main, c.lo, 0, 4, 0, last_step ? 0x182u : 0x882u);           // S2, S3, S3b: units 1, 7, 11 (1, 7, 8)
+    mv_k_loop2<2, kMvBwdTwo>(w, r, c.main, c.lo, 0, 4, 0, last_step ? 0x8082u : 0x882u);          // S2, S3, S3b: units 1, 7, 11 (15)
     MV_STAMP(w, 23);
     mv_meet_and_hand_over(w, c);                   // tile B
 }
 
 struct MvVecB {
-    f32x4 dl;                      // d(loss)/d(logits) of the block this wave writes operands for (sub), lane's sample
+    f32x4 dl;                      // d(loss)/d(logits) of this wave's block (sub), lane's sample: the pass being prepared
     const float* d_logits;
     float* dz;
     const char* masks;
+    const f32x4* head_lds;         // LDS: W[channel][4]
     int64_t n;
 };
-
-// the operand K blocks of step 0 for the pass at block0: K block 0 = the logits columns lg_col.. in K rows
-// 0..lg_n-1 (lane half 0), K block 1 = zero; waves m = 0, 1 of either block write one each
-__device__ __forceinline__ void mv_write_dlogits(const ffn_step& L, const MvCtx& w, const f32x4& dl) {
-    if (w.m >= 2) return;
-    const int G = w.m;
-    float v[8];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int c = L.lg_col + j;
-        const float d = c == 0 ? dl[0] : (c == 1 ? dl[1] : (c == 2 ? dl[2] : dl[3]));
-        v[j] = (G == 0 && w.h == 0 && j < L.lg_n && c < 4) ? d : 0.0f;
-        v[4 + j] = 0.0f;
-    }
-    bf16x8 dp[3];
-    split8x3(v, dp[0], dp[1], dp[2]);
-    f32x4* dst = w.xbuf + G * kMvKbVecs + w.sub * kMvBlkVecs + w.lane;
-#pragma unroll
-    for (int part = 0; part < 3; ++part) dst[64 * part] = __builtin_bit_cast(f32x4, dp[part]);
-}
 
 __device__ __forceinline__ f32x4 mv_load_dlogits(const MvCtx& w, const MvVecB& v, int64_t block0) {
     int64_t block = block0 + w.sub;
@@ -866,9 +840,9 @@ __device__ __forceinline__ f32x4 mv_load_dlogits(const MvCtx& w, const MvVecB& v
     return (real && sample < v.n) ? reinterpret_cast<const f32x4*>(v.d_logits)[sample] : (f32x4)(0.0f);
 }
 
-__device__ __forceinline__ unsigned mv_load_mask(const ffn_step& L, const MvCtx& w, const MvVecB& v, int o) {
+__device__ __forceinline__ unsigned mv_load_mask(const ffn_step& L, const MvCtx& w, const MvVecB& v, int64_t block0, int o) {
     if (L.mask_slot < 0) return 0xffffu;
-    int64_t block = w.block0 + w.sub;
+    int64_t block = block0 + w.sub;
     block = block < w.num_blocks ? block : w.num_blocks - 1;
     return *reinterpret_cast<const uint16_t*>(v.masks + mv_mask_at(L.mask_slot, w.num_blocks, block, w.lane, o));
 }
@@ -896,11 +870,11 @@ __device__ __forceinline__ void mv_epilogue_bwd(bool last_step, unsigned word, c
 }
 
 __device__ __forceinline__ void mv_epilogue_bwd_stores(const ffn_mlp_chain& ch, const ffn_step& L, const MvCtx& w,
-                                                       const MvVecB& v, int o, const MvDeferred& d) {
+                                                       const MvVecB& v, int64_t block0, int o, const MvDeferred& d) {
     if (!MV_VECTOR_WORK) return;
     int save_s = w.s, save_h = w.h;
     asm volatile("" : "+v"(save_s), "+v"(save_h));
-    const int64_t block = w.block0 + w.sub;
+    const int64_t block = block0 + w.sub;
     if (L.out_slot < 0 || block >= w.num_blocks) return;
     f32x4* save_out = reinterpret_cast<f32x4*>(v.dz + ch.slot_offset[L.out_slot] * w.num_blocks * 32) +
                       block * (int64_t)(ch.slot_channels[L.out_slot] * 8);
@@ -915,35 +889,72 @@ __device__ __forceinline__ void mv_epilogue_bwd_stores(const ffn_mlp_chain& ch, 
     }
 }
 
-// a step seen from a vector wave, from its barrier S2 on.  next: the LAST step of a pass that has a
-// successor writes the next pass's step-0 operands (K blocks 0, 1: free from S3 on) between S3b and S4.
-// The dZ stores of tile B are left to the caller (`late`): behind the next barrier.
+// Step 0 of (tile o, this wave's block) for the pass at block0: the head term in the accumulator layout
+// (value 4 q + p of lane (h, s) = channel 32 o + 8 q + 4 h + p of sample s), masked, split, stored into X;
+// its dZ slab is left to the caller (`d`: behind the next barrier).
+__device__ __forceinline__ void mv_step0(const ffn_step& L0, const MvCtx& w, const MvVecB& v, const f32x4& dl, unsigned mask_word,
+                                         int o, MvDeferred& d) {
+    if (!MV_VECTOR_WORK) return;
+    float dj[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = L0.lg_col + j;
+        const float x = c == 0 ? dl[0] : (c == 1 ? dl[1] : (c == 2 ? dl[2] : dl[3]));
+        dj[j] = (j < L0.lg_n && c < 4) ? x : 0.0f;
+    }
+    const f32x4* hw = v.head_lds + 32 * o + 4 * w.h;
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const f32x4 w4 = hw[8 * q + p];
+            acc[4 * q + p] = __builtin_fmaf(w4[3], dj[3], __builtin_fmaf(w4[2], dj[2], __builtin_fmaf(w4[1], dj[1], w4[0] * dj[0])));
+        }
+    bf16x8 res[2][3];
+    mv_epilogue_bwd(false, mask_word, acc, res, d);
+    mv_store_x(w, o, res);
+}
+
+// a hidden step seen from a vector wave, from its barrier S2 on.  next: the LAST step of a pass that has a
+// successor computes tiles 0..3 of the next pass's step 0 (K blocks 0..7 of X: free from S3 on) between S3
+// and S3b; their dZ slabs (`next_a`) and tile B's of this step (`late`) are left to the caller: behind the
+// next barrier.  The last step's tile B is only TAKEN over here (`acc_b`, its mask word in `word_b_out`): what
+// the matrix waves wait for next is the other half of the next pass's step 0, the caller computes that first.
 __device__ __forceinline__ void mv_vector_tail_bwd(const ffn_mlp_chain& ch, const ffn_step& L, bool last_step, const MvCtx& w,
-                                                   const MvVecB& v, bool next, const f32x4& dl_next, MvDeferred& late) {
+                                                   const MvVecB& v, bool next, const f32x4& dl_next, unsigned next_word_a,
+                                                   MvDeferred& next_a, MvDeferred& late, f32x16& acc_b, unsigned& word_b_out) {
     f32x16 acc;
     bf16x8 res[2][3];
     MvDeferred early;
-    const unsigned word_a = mv_load_mask(L, w, v, w.m), word_b = mv_load_mask(L, w, v, w.m + 4);
+    const unsigned word_a = mv_load_mask(L, w, v, w.block0, w.m), word_b = mv_load_mask(L, w, v, w.block0, w.m + 4);
     mv_barrier();                                  // S2: tile A handed over
     mv_take_over(w, acc);
     mv_epilogue_bwd(last_step, word_a, acc, res, early);
     mv_barrier();                                  // S3: K blocks 0..7 of X are consumed
     if (!last_step) mv_store_x(w, w.m, res);
+    else if (next) mv_step0(ch.step[0], w, v, dl_next, next_word_a, w.m, next_a);
     mv_barrier();                                  // S3b: K blocks 0..7 of the next image are in X
-    mv_epilogue_bwd_stores(ch, L, w, v, w.m, early);
-    if (next) mv_write_dlogits(ch.step[0], w, dl_next);
+    mv_epilogue_bwd_stores(ch, L, w, v, w.block0, w.m, early);
     mv_barrier();                                  // S4: tile B handed over, X consumed
+    if (last_step) {
+        mv_take_over(w, acc_b);
+        word_b_out = word_b;
+        return;
+    }
     mv_take_over(w, acc);
-    mv_epilogue_bwd(last_step, word_b, acc, res, late);
-    if (!last_step) mv_store_x(w, w.m + 4, res);
+    mv_epilogue_bwd(false, word_b, acc, res, late);
+    mv_store_x(w, w.m + 4, res);
 }
 
+// (step 0 has no units: its K blocks of the pack are skipped)
 __device__ __forceinline__ int mv_build_units_bwd(const ffn_mlp_chain& ch, int* units) {
     int u = 0, flat = 0;
     for (int li = 0; li < ch.num_steps; ++li) {
         const int kb = (ch.step[li].act_groups >> 1) + (ch.step[li].aux_groups > 0 ? 2 : 0);
-        for (int t = 0; t < 2; ++t)
-            for (int k = 0; k < kb; ++k) units[u++] = (flat + k) * 8 + 4 * t;
+        if (li > 0)
+            for (int t = 0; t < 2; ++t)
+                for (int k = 0; k < kb; ++k) units[u++] = (flat + k) * 8 + 4 * t;
         flat += kb;
     }
     return u;
@@ -955,6 +966,7 @@ mlp_backward_bf16_mv_kernel(const ffn_mlp_chain ch, const uint16_t* __restrict__
                             const uint32_t* __restrict__ masks, float* __restrict__ dz, int num_units) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* tbl = reinterpret_cast<int*>(smem + kMvXBytes + kMvHandBytes);
+    f32x4* head_lds = reinterpret_cast<f32x4*>(smem + kMvXBytes + kMvHandBytes + kMvMaxUnits * 4);
     if (threadIdx.x == 0) {
         int* units = reinterpret_cast<int*>(smem);             // (X is not in use yet)
         const int u_total = mv_build_units_bwd(ch, units);
@@ -988,7 +1000,28 @@ mlp_backward_bf16_mv_kernel(const ffn_mlp_chain ch, const uint16_t* __restrict__
     w.num_blocks = (n + 31) / 32;
     const int64_t passes = (w.num_blocks + 1) / 2;
     const bool matrix = w.wave < 4;
-    __syncthreads();                               // the unit table is staged
+    if (w.wave < 8 && w.h == 0) {
+        // the head weights as f32: K rows 0..3 of step 0's K block 0, tile `wave` -- the A-operand layout keeps row
+        // (= channel) r's K values 0..7 in lane r of the lower half; hi + mid + lo is the f32 value exactly
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 part[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) part[p] = __builtin_bit_cast(u32x4, w.gw[(w.wave * 3 + p) * 64 + w.lane]);
+        f32x4 wt;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float sum = 0.0f;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const unsigned word = part[p][j >> 1];
+                sum += __builtin_bit_cast(float, (j & 1) ? (word & 0xffff0000u) : (word << 16));
+            }
+            wt[j] = sum;
+        }
+        head_lds[32 * w.wave + w.lane] = wt;
+    }
+    __syncthreads();                               // the unit table and the head weights are staged
+    const int num_steps = ch.num_steps;
 
     if (matrix) {
         __builtin_amdgcn_s_setprio(3);
@@ -1003,15 +1036,16 @@ mlp_backward_bf16_mv_kernel(const ffn_mlp_chain ch, const uint16_t* __restrict__
         }
         r.tq = 0;
         r.cur = w.tbl4[0];
-        mv_barrier();                                                                        // P1: the first pass's operands
+        mv_barrier();                                                                        // P1: the first pass's step-0 image
         asm volatile("" ::"v"(r.wr[2][2]));        // (see mv_matrix_features)
+        mv_read_x0(w, r, 0);
         for (int64_t pass = blockIdx.x; pass < passes; pass += gridDim.x) {
 #ifdef MV_STAMPS
             w.stamp_on = blockIdx.x == 0 && pass == blockIdx.x + 2 * (int64_t)gridDim.x && w.wave == 0;
             w.stamp_n = 0;
 #endif
-            mv_matrix_bwd_first(w, r, c);
-            for (int li = 1; li < ch.num_steps; ++li) mv_matrix_bwd_hidden(li + 1 == ch.num_steps, w, r, c);
+            MV_STAMP(w, 80);
+            for (int li = 1; li < num_steps; ++li) mv_matrix_bwd_hidden(li == 1, li + 1 == num_steps, w, r, c);
             mv_barrier();                                                                    // S4 of the last step
             MV_STAMP(w, 24);
         }
@@ -1023,29 +1057,76 @@ mlp_backward_bf16_mv_kernel(const ffn_mlp_chain ch, const uint16_t* __restrict__
     v.d_logits = d_logits;
     v.dz = dz;
     v.masks = reinterpret_cast<const char*>(masks);
+    v.head_lds = head_lds;
     v.n = n;
+    const ffn_step& L0 = ch.step[0];
     w.block0 = (int64_t)blockIdx.x * 2;
     v.dl = mv_load_dlogits(w, v, w.block0);
-    mv_write_dlogits(ch.step[0], w, v.dl);
+    {   // the first pass's step 0, both halves (nothing streams yet: the slabs go out at once)
+        MvDeferred da, db;
+        mv_step0(L0, w, v, v.dl, mv_load_mask(L0, w, v, w.block0, w.m), w.m, da);
+        mv_step0(L0, w, v, v.dl, mv_load_mask(L0, w, v, w.block0, w.m + 4), w.m + 4, db);
+        mv_epilogue_bwd_stores(ch, L0, w, v, w.block0, w.m, da);
+        mv_epilogue_bwd_stores(ch, L0, w, v, w.block0, w.m + 4, db);
+    }
     mv_barrier();                                                                            // P1
+    bool have_a = false;                           // tiles 0..3 of this pass's step 0 came out of the pass before: slabs pending
+    bool have_last = false;                        // tile B of the pass before's last step: taken over, its epilogue pending
+    int64_t last_block0 = 0;
+    f32x16 last_acc;
+    unsigned last_word = 0xffffu;
+    MvDeferred step0_a, step0_b;
+    unsigned word_b = 0xffffu;                     // step 0's mask word of tile m + 4, this pass (requested a pass ahead)
+    const ffn_step& Llast = ch.step[num_steps - 1];
     for (int64_t pass = blockIdx.x; pass < passes; pass += gridDim.x) {
+        const bool first_pass = pass == (int64_t)blockIdx.x;
         w.block0 = pass * 2;
         const bool has_next = pass + gridDim.x < passes;
         f32x4 dl_next = (f32x4)(0.0f);
-        if (has_next) dl_next = mv_load_dlogits(w, v, w.block0 + 2 * (int64_t)gridDim.x);
-        MvDeferred late;
-        mv_vector_tail_bwd(ch, ch.step[0], false, w, v, false, dl_next, late);
-        for (int li = 1; li < ch.num_steps; ++li) {
-            const bool last = li + 1 == ch.num_steps;
-            mv_barrier();                                                                    // S1
-            mv_epilogue_bwd_stores(ch, ch.step[li - 1], w, v, w.m + 4, late);  // (tile B of the step before)
-            mv_vector_tail_bwd(ch, ch.step[li], last, w, v, last && has_next, dl_next, late);
+        unsigned next_word_a = 0xffffu, next_word_b = 0xffffu;
+        if (has_next) {
+            const int64_t next_block0 = w.block0 + 2 * (int64_t)gridDim.x;
+            dl_next = mv_load_dlogits(w, v, next_block0);
+            next_word_a = mv_load_mask(L0, w, v, next_block0, w.m);
+            next_word_b = mv_load_mask(L0, w, v, next_block0, w.m + 4);
         }
-        mv_epilogue_bwd_stores(ch, ch.step[ch.num_steps - 1], w, v, w.m + 4, late);
+        // tiles 4..7 of this pass's step 0 (K blocks 8..15 of X: free since the barrier that ended the pass before),
+        // under the first half of the matrix waves' first K loop -- the first thing behind that barrier
+        if (!first_pass) mv_step0(L0, w, v, v.dl, word_b, w.m + 4, step0_b);
+        MvDeferred late;
+        for (int li = 1; li < num_steps; ++li) {
+            const bool last = li + 1 == num_steps;
+            mv_barrier();                                                                    // S1
+            if (li == 1) {
+                if (have_last) {                   // (tile B of the pass before's last step: no X image follows it)
+                    bf16x8 none[2][3];
+                    mv_epilogue_bwd(true, last_word, last_acc, none, late);
+                    mv_epilogue_bwd_stores(ch, Llast, w, v, last_block0, w.m + 4, late);
+                }
+                if (!first_pass) {
+                    if (have_a) mv_epilogue_bwd_stores(ch, L0, w, v, w.block0, w.m, step0_a);
+                    mv_epilogue_bwd_stores(ch, L0, w, v, w.block0, w.m + 4, step0_b);
+                }
+            } else {
+                mv_epilogue_bwd_stores(ch, ch.step[li - 1], w, v, w.block0, w.m + 4, late);      // (tile B of the step before)
+            }
+            mv_vector_tail_bwd(ch, ch.step[li], last, w, v, last && has_next, dl_next, next_word_a, step0_a, late, last_acc, last_word);
+        }
+        have_last = true;
+        last_block0 = w.block0;
+        have_a = has_next;
+        v.dl = dl_next;
+        word_b = next_word_b;
+    }
+    if (have_last) {
+        MvDeferred late;
+        bf16x8 none[2][3];
+        mv_epilogue_bwd(true, last_word, last_acc, none, late);
+        mv_epilogue_bwd_stores(ch, Llast, w, v, last_block0, w.m + 4, late);
     }
 }
 
-// backward chains this organisation covers: the d_logits term alone in step 0, then 256 -> 256 steps
+// backward chains this organisation covers: the d_logits term alone in step 0 (the vector waves'), then 256 -> 256 steps
 bool mv_covers_bwd(const ffn_mlp_chain* chain, int* num_units) {
     if (chain->num_steps < 2 || chain->wide != 0) return false;
     int units = 0;
@@ -1054,7 +1135,7 @@ bool mv_covers_bwd(const ffn_mlp_chain* chain, int* num_units) {
         if (L.out_tiles != 8) return false;
         if (i == 0) {
             if (L.act_groups != 0 || L.aux_groups <= 0) return false;
-            units += 4;
+            if (L.lg_col < 0 || L.lg_n < 1 || L.lg_col + L.lg_n > 4) return false;
         } else {
             if ((L.act_groups >> 1) != 16 || L.aux_groups != 0) return false;
             units += 32;

@@ -1,7 +1,9 @@
 """bf16x6 chain kernels: the matrix-waves / vector-waves organisation (csrc/mlp_bf16_mv.hip) against the
-two-waves-per-SIMD one (csrc/mlp_bf16_ws.hip) on the chains both cover -- buffers compared bit for bit
-(slabs, masks, dZ), logits to 1e-6, then timings interleaved in one process (FFN_BF16X6_ORG is read per
-launch).  Run on a GPU box:  python scripts/probes/mv_check.py [--time-only] [--n 4194304]"""
+two-waves-per-SIMD one (csrc/mlp_bf16_ws.hip) on the chains both cover -- the forward's buffers compared bit
+for bit (slabs, masks), logits to 1e-6; the backward's dZ and gradients to 1e-6 of their largest element with
+the zeros of the ReLU masks in the same places (its step 0, the head term, is f32 arithmetic of the vector
+waves where the ws kernels issue six bf16 products), and bit for bit against ITSELF across repetitions; then
+timings interleaved in one process (FFN_BF16X6_ORG is read per launch).  Run on a GPU box:  python scripts/probes/mv_check.py [--time-only] [--n 4194304]"""
 import argparse
 import json
 import os
@@ -35,9 +37,17 @@ def run(prog, x, n, org, train):
     return logits, buf
 
 
+def close(ref, new, what, tol=1e-6):
+    """largest difference over the largest element (the backward's head term is computed in another arithmetic)"""
+    scale = max(float(ref.abs().max()), 1e-30)
+    err = float((new - ref).abs().max()) / scale
+    assert err <= tol, what + (err,)
+    return err
+
+
 def check(name, model):
     prog = model.program()
-    worst = 0.0
+    worst = worst_b = 0.0
     for n in (1, 31, 64, 65, 1000, 4097, 70000):
         torch.manual_seed(n)
         x = torch.rand(n, 3, device=dev()) * 2 - 1
@@ -62,9 +72,10 @@ def check(name, model):
                 prog.backward(d_logits, x, None, ref_s, flat, precision="bf16x6")
                 torch.cuda.synchronize()
                 got[org] = (ws.dz.clone(), flat)
-            assert torch.equal(got["ws"][0].view(torch.int32), got["mv"][0].view(torch.int32)), (name, n, "dZ differs")
-            assert torch.equal(got["ws"][1], got["mv"][1]), (name, n, "gradients differ")
-    print("%-14s parity ok (logits within %.1e of the ws kernels'; slabs, masks, dZ, gradients bit-identical)" % (name, worst), flush=True)
+            worst_b = max(worst_b, close(got["ws"][0], got["mv"][0], (name, n, "dZ")), close(got["ws"][1], got["mv"][1], (name, n, "gradients")))
+            assert torch.equal(got["ws"][0] == 0, got["mv"][0] == 0), (name, n, "dZ: the masks' zeros moved")
+    print("%-14s parity ok (logits within %.1e of the ws kernels', slabs and masks bit-identical; dZ and gradients within %.1e of "
+          "their largest element)" % (name, worst, worst_b), flush=True)
 
 
 def timeit(fn, reps):
@@ -102,6 +113,7 @@ def stress(name, model, n, reps):
     backward_data(prog, d_logits, ref_s, n)
     torch.cuda.synchronize()
     ref_dz = ws.dz.clone()
+    first_dz = None
     for rep in range(reps):
         new_l, new_s = run(prog, x, n, "mv", True)
         assert torch.equal(ref_s.view(torch.int32), new_s.view(torch.int32)), (name, rep, "slabs / masks differ")
@@ -109,8 +121,12 @@ def stress(name, model, n, reps):
         ws.dz.zero_()
         backward_data(prog, d_logits, new_s, n)
         torch.cuda.synchronize()
-        assert torch.equal(ref_dz.view(torch.int32), ws.dz.view(torch.int32)), (name, rep, "dZ differs")
-    print("%-14s %d repetitions at %d samples: bit-identical every time" % (name, reps, n), flush=True)
+        if first_dz is None:
+            first_dz = ws.dz.clone()
+            close(ref_dz, first_dz, (name, rep, "dZ against the ws kernels'"))
+        assert torch.equal(first_dz.view(torch.int32), ws.dz.view(torch.int32)), (name, rep, "dZ differs from the first repetition's")
+    print("%-14s %d repetitions at %d samples: slabs / masks bit-identical to the ws kernels' every time, dZ bit-identical to the "
+          "first repetition's" % (name, reps, n), flush=True)
 
 
 def timing(name, model, n, reps):

@@ -136,10 +136,14 @@ def test_bf16x6_matrix_vector_waves_write_the_bits_of_the_two_waves_per_simd_ker
     """The bf16x6 chain kernels of the tiny NeRF / Fourier MLP family run in the matrix-waves / vector-waves
     organisation (csrc/mlp_bf16_mv.hip); `FFN_BF16X6_ORG=ws` keeps the two-waves-per-SIMD kernels
     (csrc/mlp_bf16_ws.hip) that every other chain runs and that `test_round5_gpu.py` holds against the
-    exact-f32 kernels and float64.  Same six partial products per K block in the same order per
-    accumulator: activation slabs, feature slabs, sign masks, dZ and with them every gradient are
-    BIT-identical; the logits (the fused head's partial sums meet in another order) within 2e-7 of their
-    scale; inference == training forward.  Sizes: a lone sample, the 32-sample block and the 64-sample
+    exact-f32 kernels and float64.  Forward: the same six partial products per K block in the same order
+    per accumulator -- activation slabs, feature slabs and sign masks are BIT-identical; the logits (the
+    fused head's partial sums meet in another order) within 2e-7 of their scale; inference == training
+    forward.  Backward data: the hidden steps are the same arithmetic, but step 0 -- d(loss)/d(logits)
+    through the fused head, four real K rows -- is f32 arithmetic of the vector waves where the
+    two-waves-per-SIMD kernels issue six bf16 products: dZ and every gradient within 1e-6 of their largest
+    element, the zeros of the ReLU masks in the same places, and a second launch BIT-identical to the
+    first.  Sizes: a lone sample, the 32-sample block and the 64-sample
     pass either side, a ragged tail, and more passes than a workgroup gets at once (the next pass's first
     feature segment is generated under the last step of the pass before)."""
     import fourier_feature_nets_amd as ffn
@@ -164,8 +168,11 @@ def test_bf16x6_matrix_vector_waves_write_the_bits_of_the_two_waves_per_simd_ker
         assert float((new[0] - ref[0]).abs().max()) <= 2e-7 * scale, (n, "logits")
         assert torch.equal(new[0], new[1]), (n, "inference != training forward")
         assert torch.equal(ref[2].view(torch.int32), new[2].view(torch.int32)), (n, "slabs / masks")
-        assert torch.equal(ref[3].view(torch.int32), new[3].view(torch.int32)), (n, "dZ")
-        assert torch.equal(ref[4], new[4]), (n, "gradients")
+        for what, a, b in (("dZ", ref[3], new[3]), ("gradients", ref[4], new[4])):
+            assert float((a - b).abs().max()) <= 1e-6 * max(float(a.abs().max()), 1e-30), (n, what)
+        assert torch.equal(ref[3] == 0, new[3] == 0), (n, "dZ: the masks' zeros moved")
+        again = _x6_buffers(prog, x, n, "mv", monkeypatch)
+        assert torch.equal(again[3].view(torch.int32), new[3].view(torch.int32)) and torch.equal(again[4], new[4]), (n, "repeat")
 
 
 def test_bf16x6_chains_outside_the_family_keep_the_two_waves_per_simd_kernels(golden):
