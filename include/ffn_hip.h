@@ -499,8 +499,10 @@ int ffn_mlp_backward_data_bf16x3(const ffn_mlp_chain* chain, const uint16_t* pac
  * windows -- both read the slabs these kernels write (host: MlpProgram._plan_wgrad;
  * FFN_BF16X6_WGRAD=f32 keeps every unit on the exact-f32 kernel).
  * FFN_BF16X6_PRODUCTS=9 (environment, measurement only) multiplies out all nine partial products.
- * Two workgroup organisations sit behind these entry points (same packs, same slab / mask / dZ formats,
- * bit-identical slabs, masks and dZ): chains whose first step is features-only (16 j K blocks) and whose
+ * Two workgroup organisations sit behind these entry points (same packs, same slab / mask / dZ formats;
+ * the forward's slabs and masks bit-identical, the backward's dZ within 2e-7 of its largest element: the
+ * head term of its step 0 is f32 vector arithmetic in one, six bf16 products in the other): chains whose
+ * first step is features-only (16 j K blocks) and whose
  * other steps are 256 -> 256 -- the tiny NeRF / Fourier MLP family -- run the MATRIX WAVES / VECTOR WAVES
  * kernels (csrc/mlp_bf16_mv.hip: four waves that only multiply, eight that only generate features and
  * run epilogues), everything else the two-waves-per-SIMD kernels (csrc/mlp_bf16_ws.hip);
