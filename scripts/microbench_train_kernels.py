@@ -65,6 +65,10 @@ def main():
         torch.cuda.synchronize()
         row = {k.replace("ffn_mlp_", ""): round(sum(a.elapsed_time(b) for a, b in v) / len(v), 3) for k, v in spans.items()}
         row["sum_ms"] = round(sum(row.values()), 3)
+        # (a digest of the last step's gradients: two builds that claim identical arithmetic can be
+        # compared bit for bit across processes)
+        import hashlib
+        row["grads_sha16"] = hashlib.sha256(grads.cpu().numpy().tobytes()).hexdigest()[:16]
         out[mode] = row
     _lib.call = orig
     print(json.dumps(out))
