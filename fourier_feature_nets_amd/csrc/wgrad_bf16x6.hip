@@ -139,11 +139,11 @@ __device__ __forceinline__ void unit_segment24(const ffn_mlp_chain& ch, const ff
             for (int r = 0; r < 16; ++r) acc[p][q][r] = 0.0f;
     f32x2v bsum[2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
 
-    // ---- LDS-DMA (wgrad_bf16.hip): a stage = up to 32 pieces of 1 KiB; wave w issues pieces w,
-    // w + 4, ... of both halves
+    // ---- LDS-DMA (wgrad_bf16.hip): a stage = up to 32 pieces of 1 KiB; wave w issues pieces
+    // 4w .. 4w + 3 of both halves
     const int a_pieces = unit.m_quads >> 2, b_pieces = unit.n_quads >> 2;    // <= 16 each
-    const int per_stage = (a_pieces > wave ? (a_pieces - wave + 3) >> 2 : 0) +
-                          (b_pieces > wave ? (b_pieces - wave + 3) >> 2 : 0);
+    auto clamp4 = [](int x) { return x < 0 ? 0 : (x > 4 ? 4 : x); };
+    const int per_stage = clamp4(a_pieces - 4 * wave) + clamp4(b_pieces - 4 * wave);
     const int dma_lane = ((lane >> 4) * 512) + ((lane & 15) * 16);
     auto issue_stage = [&](int64_t st, auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;        // both windows 256 channels: no tests
@@ -152,20 +152,19 @@ __device__ __forceinline__ void unit_segment24(const ffn_mlp_chain& ch, const ff
         const char* ga = a_base + blk * a_stride + half + dma_lane;
         const char* gb = b_base + blk * b_stride + half + dma_lane;
         char* l = smem + (int)(st & (kStages - 1)) * kStageBytes;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int p = wave + 4 * k;
-            if (FULL || p < a_pieces)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga + p * 2048),
-                                                 (__attribute__((address_space(3))) void*)(l + p * 1024), 16, 0, 2);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int p = wave + 4 * k;
-            if (FULL || p < b_pieces)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + p * 2048),
-                                                 (__attribute__((address_space(3))) void*)(l + kHalfBytes + p * 1024), 16, 0, 2);
-        }
+        // (wave w requests the four CONSECUTIVE pieces 4w .. 4w + 3 of each half: their LDS
+        // addresses differ by the instruction's immediate offset -- which the hardware adds to the
+        // global address as well, hence the k * 1024 taken off it -- so that M0 is written once per
+        // half, not once per request)
+#define FFN_DMA(G, PIECES, LDS, K)                                                                 \
+    if (FULL || 4 * wave + K < PIECES)                                                             \
+        __builtin_amdgcn_global_load_lds(                                                          \
+            (const __attribute__((address_space(1))) void*)(G + (4 * wave + K) * 2048 - K * 1024), \
+            (__attribute__((address_space(3))) void*)(LDS + 4 * wave * 1024), 16, K * 1024, 2);
+        FFN_DMA(ga, a_pieces, l, 0) FFN_DMA(ga, a_pieces, l, 1) FFN_DMA(ga, a_pieces, l, 2) FFN_DMA(ga, a_pieces, l, 3)
+        FFN_DMA(gb, b_pieces, l + kHalfBytes, 0) FFN_DMA(gb, b_pieces, l + kHalfBytes, 1)
+        FFN_DMA(gb, b_pieces, l + kHalfBytes, 2) FFN_DMA(gb, b_pieces, l + kHalfBytes, 3)
+#undef FFN_DMA
     };
 
     // This lane's float4 of sample 8 hh + t of a stage sits at byte ((8 hh + t) ^ (li & 15)) * 16 of
