@@ -251,6 +251,28 @@ __device__ __forceinline__ void unit_segment24(const ffn_mlp_chain& ch, const ff
 #define FFN_ROWSET(AP, BP, P)                                                                      \
     _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                  \
         acc[P][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.AP[P], b.BP[q], acc[P][q], 0, 0, 0);
+ // one LDS read behind each of eight matrix instructions (a burst of eight 1-KiB reads per wave,
+        // four waves at once, holds the LDS for 256+ cycles)
+#define FFN_PIN_READS()                                                                            \
+    _Pragma("unroll") for (int k = 0; k < 8; ++k) {                                                \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                         \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                         \
+    }
+#define FFN_PIN_READS2()      /* two behind each of four: the values are needed eight instructions on */  \
+    _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                         \
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                         \
+    }
+#define FFN_PIN_DMA()         /* one request behind each of the step's first eight */              \
+    _Pragma("unroll") for (int k = 0; k < 8; ++k) {                                                \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                         \
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                         \
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                         \
+    }                                                                                              \
+    _Pragma("unroll") for (int k = 0; k < 8; ++k) {                                                \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                         \
+        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);                                         \
+    }
 #define FFN_PIN16(NV)                                                                              \
     _Pragma("unroll") for (int k = 0; k < 16; ++k) {                                               \
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                         \
@@ -280,7 +302,7 @@ __device__ __forceinline__ void unit_segment24(const ffn_mlp_chain& ch, const ff
         FFN_ROWSET(l, h, 1) split_stage<false>(v.x[0], b.m[0], b.m[1]);
         FFN_ROWSET(l, h, 2)
         FFN_ROWSET(l, h, 3) split_stage<false>(v.x[1], b.m[2], b.m[3]);
-        FFN_PIN16(6)
+        FFN_PIN_DMA()
         FFN_FENCE();
         // a_m b_h, with the lo parts of B behind it
         FFN_ROWSET(m, h, 0) split_stage<true>(v.x[0], b.l[0], b.l[1]);
@@ -292,6 +314,7 @@ __device__ __forceinline__ void unit_segment24(const ffn_mlp_chain& ch, const ff
         // a_h b_h, over the LDS round trip of the next step's raw A (v is free)
         if (!last) read_half(i + 1, a_row, 0, v);
         FFN_ROWSET(h, h, 0) FFN_ROWSET(h, h, 1) FFN_ROWSET(h, h, 2) FFN_ROWSET(h, h, 3)
+        FFN_PIN_READS()
         FFN_FENCE();
         // a_m b_m and a_h b_m, with the conversion of the next step's A behind them
         FFN_ROWSET(m, m, 0)
@@ -314,6 +337,7 @@ __device__ __forceinline__ void unit_segment24(const ffn_mlp_chain& ch, const ff
         // next step starts with matrix instructions
         if (!last) read_half(i + 1, b_row, kHalfBytes, v);
         FFN_ROWSET(h, l, 0) FFN_ROWSET(h, l, 1)
+        FFN_PIN_READS2()
         FFN_FENCE();
         FFN_ROWSET(h, l, 2)
         if (!last) split_stage<false>(v.x[0], b.h[0], b.h[1]);
@@ -322,6 +346,9 @@ __device__ __forceinline__ void unit_segment24(const ffn_mlp_chain& ch, const ff
         FFN_PIN8(8)
         FFN_FENCE();
 #undef FFN_FENCE
+#undef FFN_PIN_READS
+#undef FFN_PIN_READS2
+#undef FFN_PIN_DMA
 #undef FFN_PIN12
 #undef FFN_PIN8
 #undef FFN_ROWSET
