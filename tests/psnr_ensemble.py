@@ -240,7 +240,14 @@ def compare(doc, reference_path, out_path):
     `python -m tests.psnr_ensemble compare --hip <file> --reference <file> --out <file>`)."""
     with open(reference_path) as f:
         ref = json.load(f)
-    a, b = doc["final_val_psnr"], ref["final_val_psnr"]
+    a_all, b = doc["final_val_psnr"], ref["final_val_psnr"]
+    # the two halves share their seeds: the means are compared over the seeds BOTH hold (a HIP half that
+    # ran more seeds than an incomplete reference fixture would otherwise be compared with seeds of
+    # another difficulty -- round 6's config-3 slow protocol: the reference's two seeds are the 1st and
+    # 3rd best of the HIP half's 24); the HIP half's statistics over all of its seeds stay in `hip_final_all_seeds`
+    ref_seeds = {r["seed"] for r in ref["runs"]}
+    common_runs = [r for r in doc["runs"] if r["seed"] in ref_seeds]
+    a = stats_of(common_runs)["final_val_psnr"] if 0 < len(common_runs) < len(doc["runs"]) else a_all
     delta = a["mean"] - b["mean"]
     se = float(np.sqrt((a["stderr"] or 0.0) ** 2 + (b["stderr"] or 0.0) ** 2))
     curve = []
@@ -276,7 +283,19 @@ def compare(doc, reference_path, out_path):
     # UNPAIRED means (2 standard errors of their difference) next to the 0.05 dB bar, and how long
     # the seed-PAIRED trajectories stay inside it
     # (a side with a single seed has no standard error: nothing is resolved by the means then)
-    mdd = 2.0 * se if (a["stderr"] is not None and b["stderr"] is not None) else float("inf")
+    # ... with few seeds on a side the two halves' OWN standard errors are no bound (two reference seeds that
+    # happen to agree estimate a spread of nothing; round 6's config-3 slow protocol compared 24 HIP seeds
+    # with 2 reference seeds and read `fail`): the test is the two-sample t test under the hypothesis being
+    # tested -- both halves draw from ONE distribution, hence one POOLED variance -- with Student's t at
+    # n_a + n_b - 2 degrees of freedom as the critical value, never below 2
+    critical, dof, se_unpooled = 2.0, None, se
+    if a["stderr"] is not None and b["stderr"] is not None:
+        dof = a["n"] + b["n"] - 2
+        pooled = ((a["n"] - 1) * a["std"] ** 2 + (b["n"] - 1) * b["std"] ** 2) / dof
+        se = float(np.sqrt(pooled * (1.0 / a["n"] + 1.0 / b["n"])))
+        from scipy import stats as _stats
+        critical = max(2.0, float(_stats.t.ppf(0.975, dof)))
+    mdd = critical * se if (a["stderr"] is not None and b["stderr"] is not None) else float("inf")
     held = [r["step"] for r in paired_reports if r["max_abs_delta_db"] < 0.05]
     first_out = next((r["step"] for r in paired_reports if r["max_abs_delta_db"] >= 0.05), None)
     if abs(delta) >= 0.05 and abs(delta) >= mdd:
@@ -288,6 +307,8 @@ def compare(doc, reference_path, out_path):
     doc["against_reference"] = {
         "resolution": {
             "bar_db": 0.05, "minimum_detectable_difference_db (2 s.e. of the difference of the means)": mdd if np.isfinite(mdd) else None,
+            "critical_value (Student's t, 97.5 %, n_a + n_b - 2 degrees of freedom; never below 2)": critical,
+            "degrees_of_freedom": dof,
             "seeds_per_side_for_mdd_0p05": int(np.ceil((2.0 * np.sqrt(2.0) * max(a["std"] or 0.0, b["std"] or 0.0) / 0.05) ** 2)),
             "verdict": verdict3,
             "verdicts": "fail: |delta| >= 0.05 dB and >= 2 s.e.; pass-resolved: not failed and the ensemble COULD "
@@ -297,11 +318,15 @@ def compare(doc, reference_path, out_path):
             "first_report_step_with_a_seed_outside_0p05_db": first_out},
         "paired_val_psnr_by_report": paired_reports,
         "file": os.path.relpath(reference_path, ROOT), "reference_final": b, "hip_final": a,
+        "hip_final_is": "over the %d seeds the reference fixture holds" % a["n"], "hip_final_all_seeds": a_all,
         "per_seed_delta_db": paired,
         "per_seed_delta_mean_db": float(np.mean(paired)) if paired else None,
         "per_seed_delta_stderr_db": float(np.std(paired, ddof=1) / np.sqrt(len(paired))) if len(paired) > 1 else None,
         "delta_mean_db": delta, "stderr_of_delta_db": se,
         "within_0p05_db": abs(delta) < 0.05, "within_2_stderr": abs(delta) < 2 * se,
+        "within_critical_stderr": abs(delta) < critical * se,
+        "stderr_of_delta_db_is": "pooled variance of the two halves x sqrt(1/n_a + 1/n_b)",
+        "stderr_of_delta_unpooled_db": se_unpooled,
         # (the HIP half may run MORE seeds than the reference half: the reference's are a prefix)
         # (and a reference fixture may hold fewer runs than its protocol planned: the seeds that
         # count are the ones its runs carry)

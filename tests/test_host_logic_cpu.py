@@ -517,6 +517,15 @@ def test_psnr_ensemble_verdicts_and_stale_scene_files(tmp_path):
     # a fixture with fewer runs than its protocol planned still matches on the seeds it carries
     d = verdict(tight, tight[:3], planned=6)
     assert d["protocol_matches"] and len(d["per_seed_delta_db"]) == 3
+    # TWO seeds on a side resolve next to nothing: two values that happen to agree estimate a spread
+    # of nothing -- the test pools the variance of the two halves; a 0.7 dB gap must not read `fail`
+    # (the round-6 config-3 slow protocol: 2 reference seeds against 24 HIP seeds of other difficulty)
+    many = [17.0 + 0.5 * ((i * 7) % 5 - 2) for i in range(24)]
+    e = verdict(many, [17.7, 17.8], planned=24)
+    assert e["resolution"]["verdict"] == "pass-unresolved" and e["verdict"] == "pass"
+    assert e["resolution"]["critical_value (Student's t, 97.5 %, n_a + n_b - 2 degrees of freedom; never below 2)"] > 2.0
+    # (the means are taken over the two seeds both halves hold)
+    assert e["hip_final"]["n"] == 2 and e["hip_final_all_seeds"]["n"] == 24 and e["stderr_of_delta_db"] > 0.3
 
     args = argparse.Namespace(workdir=str(tmp_path), size=8, cameras=3, val_cameras=2)
     first = pe.scene_path(args)
