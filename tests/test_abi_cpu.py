@@ -75,9 +75,10 @@ def test_ops_refuse_cpu_tensors():
         ops._dev(torch.zeros(3))
 
 
-def _chain(steps, bias_floats=2000, wide=0):
+def _chain(steps, bias_floats=2000, wide=0, head=None):
     """A chain descriptor with only the fields `ffn_mlp_bf16x6_organisation` looks at: per step
-    (act_groups, aux_groups, out_tiles)."""
+    (act_groups, aux_groups, out_tiles); `head` = (lg_col, lg_n) of step 0 -- which logits columns a
+    backward chain's first step reads."""
     from fourier_feature_nets_amd import mlp_engine as me
     chain = me.FfnMlpChain()
     chain.num_steps = len(steps)
@@ -85,6 +86,8 @@ def _chain(steps, bias_floats=2000, wide=0):
     chain.wide = wide
     for i, (act, aux, tiles) in enumerate(steps):
         chain.step[i].act_groups, chain.step[i].aux_groups, chain.step[i].out_tiles = act, aux, tiles
+    if head is not None:
+        chain.step[0].lg_col, chain.step[0].lg_n = head
     return chain
 
 
@@ -119,8 +122,12 @@ def test_bf16x6_organisation_query_is_host_logic(monkeypatch):
     assert org(_chain([(0, 64, 8), (32, 0, 8)], bias_floats=5000)) == 0     # a bias buffer beyond its LDS copy
     assert org(_chain([(0, 64, 8), (32, 0, 8)], wide=2)) == 0
     # backward-data chains: step 0 is the d_logits term alone, then 256 -> 256
-    assert org(_chain([(0, 4, 8), (32, 0, 8), (32, 0, 8)]), 1) == 1
-    assert org(_chain([(32, 4, 8), (32, 0, 8)]), 1) == 0           # a head fused mid-chain
-    assert org(_chain([(0, 4, 8), (32, 0, 4)]), 1) == 0
+    # (the vector waves compute that term from the head's 1 .. 4 logits columns: lg_col, lg_n)
+    assert org(_chain([(0, 4, 8), (32, 0, 8), (32, 0, 8)], head=(0, 4)), 1) == 1
+    assert org(_chain([(0, 4, 8), (32, 0, 8), (32, 0, 8)], head=(3, 1)), 1) == 1
+    assert org(_chain([(0, 4, 8), (32, 0, 8), (32, 0, 8)]), 1) == 0              # no logits columns named
+    assert org(_chain([(0, 4, 8), (32, 0, 8), (32, 0, 8)], head=(2, 3)), 1) == 0   # columns 2 .. 4 of four
+    assert org(_chain([(32, 4, 8), (32, 0, 8)], head=(0, 4)), 1) == 0           # a head fused mid-chain
+    assert org(_chain([(0, 4, 8), (32, 0, 4)], head=(0, 4)), 1) == 0
     monkeypatch.setenv("FFN_BF16X6_ORG", "ws")
-    assert org(tiny) == 0 and org(_chain([(0, 4, 8), (32, 0, 8)]), 1) == 0
+    assert org(tiny) == 0 and org(_chain([(0, 4, 8), (32, 0, 8)], head=(0, 4)), 1) == 0
