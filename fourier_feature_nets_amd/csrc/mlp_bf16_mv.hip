@@ -128,7 +128,13 @@ struct MvMat {
     // wave has 168.  (The mid part in place too -- behind the fourth product, eight matrix instructions
     // before its next use -- is 8 registers less and measurably slower: the LDS round trip shows.)
     bf16x8 xh[2][2], xm[2][2], xl[2];
-    i32x4 cur;                     // refill entries of the coming trip
+    // refill entries of the coming trip: four byte offsets, the same in every lane -- kept in SCALAR registers
+    // (v_readfirstlane of the LDS read, once per trip): as four vector registers they were what tipped the
+    // backward kernel's matrix wave over its 168 -- hipcc spilled a weight-ring slot at the head of every
+    // hidden step, `s_waitcnt vmcnt(0)` + scratch store behind the request, the same again at the reload:
+    // the whole ring's latency exposed twice per step
+    int cur[4];
+    i32x4 cur_read;                // ... between the LDS read and the readfirstlanes (two matrix instructions)
     int tq;                        // index of `cur` in the table
 };
 
@@ -193,7 +199,7 @@ __device__ __forceinline__ void mv_unit(const MvCtx& w, f32x16 (&acc)[2], f32x16
         if constexpr ((READX & 2) != 0 && q == 1) r.xh[HB ^ 1][b] = __builtin_bit_cast(bf16x8, xnext[b * kMvBlkVecs]);
         if constexpr ((READX & 2) != 0 && q == 2) r.xm[HB ^ 1][b] = __builtin_bit_cast(bf16x8, xnext[b * kMvBlkVecs + 64]);
         }
-        if constexpr (g == 5) asm volatile("v_add_u32 %0, %1, %2" : "=v"(voff) : "v"(r.cur[J]), "v"(w.lane16));
+        if constexpr (g == 5) asm volatile("v_add_u32 %0, %1, %2" : "=v"(voff) : "s"(r.cur[J]), "v"(w.lane16));
         // the weight requests: behind groups 6, 7, 8
         constexpr int slot = g >= 6 && g < 9 ? g - 6 : -1;
 #ifdef MV_KO_PAIR_W
@@ -206,7 +212,11 @@ __device__ __forceinline__ void mv_unit(const MvCtx& w, f32x16 (&acc)[2], f32x16
         // ahead of its first use)
         if constexpr (J == 3 && g == 9) {
             r.tq = r.tq + 1 < w.trips_total ? r.tq + 1 : 0;
-            r.cur = w.tbl4[r.tq];
+            r.cur_read = w.tbl4[r.tq];
+        }
+        if constexpr (J == 3 && g == 11) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r.cur[j] = __builtin_amdgcn_readfirstlane(r.cur_read[j]);
         }
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -665,7 +675,11 @@ mlp_forward_bf16_mv_kernel(const ffn_mlp_chain ch, const uint16_t* __restrict__ 
             for (int part = 0; part < 3; ++part) r.wr[j][part] = __builtin_bit_cast(bf16x8, base[part * 64]);
         }
         r.tq = 0;
-        r.cur = w.tbl4[0];
+        {
+            const i32x4 entry = w.tbl4[0];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r.cur[j] = __builtin_amdgcn_readfirstlane(entry[j]);
+        }
         for (int64_t pass = blockIdx.x; pass < passes; pass += gridDim.x) {
 #ifdef MV_STAMPS
             w.stamp_on = blockIdx.x == 0 && pass == blockIdx.x + 2 * (int64_t)gridDim.x && w.wave == 0;
@@ -1035,7 +1049,11 @@ mlp_backward_bf16_mv_kernel(const ffn_mlp_chain ch, const uint16_t* __restrict__
             for (int part = 0; part < 3; ++part) r.wr[j][part] = __builtin_bit_cast(bf16x8, base[part * 64]);
         }
         r.tq = 0;
-        r.cur = w.tbl4[0];
+        {
+            const i32x4 entry = w.tbl4[0];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r.cur[j] = __builtin_amdgcn_readfirstlane(entry[j]);
+        }
         mv_barrier();                                                                        // P1: the first pass's step-0 image
         asm volatile("" ::"v"(r.wr[2][2]));        // (see mv_matrix_features)
         mv_read_x0(w, r, 0);
