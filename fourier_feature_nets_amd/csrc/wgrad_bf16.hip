@@ -120,33 +120,35 @@ __device__ __forceinline__ void unit_segment16(const ffn_mlp_chain& ch, const ff
 
     // ---- LDS-DMA: a stage = up to 32 pieces of 1 KiB (16 for the A half, 16 for the B half),
     // piece p of a half = rows 4p..4p+3 (quads) x 256 B; lane l of the issuing wave fetches the
-    // 16 B at row 4p + (l >> 4), column l & 15.  Wave w issues pieces w, w + 4, ... of both halves;
-    // pieces past the end of a window are not issued (`per_stage` = what this wave issues).
+    // 16 B at row 4p + (l >> 4), column l & 15.  Wave w issues the four CONSECUTIVE pieces 4w .. 4w + 3
+    // of both halves -- their LDS addresses differ by the request's immediate offset, which the
+    // hardware adds to the global address as well (hence the K * 1024 taken off it): M0 is written
+    // once per half, not once per request; pieces past the end of a window are not issued
+    // (`per_stage` = what this wave issues).
     const int a_pieces = unit.m_quads >> 2, b_pieces = unit.n_quads >> 2;    // <= 16 each
-    const int per_stage = (a_pieces > wave ? (a_pieces - wave + 3) >> 2 : 0) +
-                          (b_pieces > wave ? (b_pieces - wave + 3) >> 2 : 0);
+    auto clamp4 = [](int x) { return x < 0 ? 0 : (x > 4 ? 4 : x); };
+    const int per_stage = clamp4(a_pieces - 4 * wave) + clamp4(b_pieces - 4 * wave);
     const int dma_lane = ((lane >> 4) * 512) + ((lane & 15) * 16);
-    auto issue_stage = [&](int64_t st, auto full_tag) {
+    auto issue_stage = [&](int64_t st, auto full_tag, int which = 2) {      // which: 0 = the A half, 1 = the B half, 2 = both
         constexpr bool FULL = decltype(full_tag)::value;        // both windows 256 channels: no tests
         const int64_t blk = seg.blk_begin + (st >> 1);
         const int half = (int)(st & 1) * 256;
         const char* ga = a_base + blk * a_stride + half + dma_lane;
         const char* gb = b_base + blk * b_stride + half + dma_lane;
         char* l = smem + (int)(st & (kStages - 1)) * kStageBytes;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int p = wave + 4 * k;
-            if (FULL || p < a_pieces)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga + p * 2048),
-                                                 (__attribute__((address_space(3))) void*)(l + p * 1024), 16, 0, 2);
+#define FFN_DMA(G, PIECES, LDS, K)                                                                 \
+    if (FULL || 4 * wave + K < PIECES)                                                             \
+        __builtin_amdgcn_global_load_lds(                                                          \
+            (const __attribute__((address_space(1))) void*)(G + (4 * wave + K) * 2048 - K * 1024), \
+            (__attribute__((address_space(3))) void*)(LDS + 4 * wave * 1024), 16, K * 1024, 2);
+        if (which != 1) {
+            FFN_DMA(ga, a_pieces, l, 0) FFN_DMA(ga, a_pieces, l, 1) FFN_DMA(ga, a_pieces, l, 2) FFN_DMA(ga, a_pieces, l, 3)
         }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int p = wave + 4 * k;
-            if (FULL || p < b_pieces)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + p * 2048),
-                                                 (__attribute__((address_space(3))) void*)(l + kHalfBytes + p * 1024), 16, 0, 2);
+        if (which != 0) {
+            FFN_DMA(gb, b_pieces, l + kHalfBytes, 0) FFN_DMA(gb, b_pieces, l + kHalfBytes, 1)
+            FFN_DMA(gb, b_pieces, l + kHalfBytes, 2) FFN_DMA(gb, b_pieces, l + kHalfBytes, 3)
         }
+#undef FFN_DMA
     };
 
     // This lane's float4 of sample 8 hh + t of a stage sits at byte ((8 hh + t) ^ (li & 15)) * 16 of
@@ -154,12 +156,12 @@ __device__ __forceinline__ void unit_segment16(const ffn_mlp_chain& ch, const ff
     const unsigned lane_x = (unsigned)(((8 * hh) ^ (li & 15)) << 4);
     const int a_row = a_ok ? (32 * mp + li) * 256 : -1;
     const int b_row = b_ok ? (32 * np + li) * 256 : -1;
-    auto read_half = [&](int64_t st, int row, int half_off, f32x4 (&v)[8]) {
+    auto read_half = [&](int64_t st, int row, int half_off, f32x4 (&v)[8], int t0 = 0, int t1 = 8) {
         const char* base = row >= 0 ? smem + (int)(st & (kStages - 1)) * kStageBytes + half_off + row
                                     : smem + kZeroRowAt;
 #pragma unroll
         for (int t = 0; t < 8; ++t)
-            v[t] = *reinterpret_cast<const f32x4*>(base + (lane_x ^ (unsigned)(t << 4)));
+            if (t >= t0 && t < t1) v[t] = *reinterpret_cast<const f32x4*>(base + (lane_x ^ (unsigned)(t << 4)));
     };
     auto mine = [&](int64_t st) -> bool {       // (wave-uniform) does this wave contract step st?
         return NQ == 4 || (NQ == 2 ? (int)(st & 1) == part : (part < 2 && (int)(st & 1) == part));
@@ -229,51 +231,72 @@ __device__ __forceinline__ void unit_segment16(const ffn_mlp_chain& ch, const ff
         if (BULK) {
             asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            issue_stage(i + kStages, std::true_type{});
         } else {
             stage_ready(i + 1);
-            if (i + kStages < steps) issue_stage(i + kStages, std::false_type{});
         }
-        f32x4 v[8];
-        read_half(i + 1, a_row, 0, v);
-        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-#define FFN_PASS(X, Y, TAIL)                                                                   \
+        // (a step STARTS with matrix instructions behind its barrier -- both operand sets of this
+        // step are ready --: the requests for stage i + 4 and the LDS reads of the next step's raw A
+        // go out under the first four (four reads behind each of the first two, four requests behind each of
+        // the others); they used to sit in
+        // front of the step: ~35 + 8 instructions with the matrix pipe idle)
+#define FFN_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define FFN_ROWSET(X, Y, P)                                                                    \
     _Pragma("unroll") for (int q = 0; q < 4; ++q)                                              \
-        acc[0][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.X[0], cur.Y[q], acc[0][q], 0, 0, 0);  \
-    TAIL(0);                                                                                   \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q)                                              \
-        acc[1][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.X[1], cur.Y[q], acc[1][q], 0, 0, 0);  \
-    TAIL(1);                                                                                   \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q)                                              \
-        acc[2][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.X[2], cur.Y[q], acc[2][q], 0, 0, 0);  \
-    TAIL(2);                                                                                   \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q)                                              \
-        acc[3][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.X[3], cur.Y[q], acc[3][q], 0, 0, 0);  \
-    TAIL(3);
+        acc[P][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.X[P], cur.Y[q], acc[P][q], 0, 0, 0);
 #define FFN_SPLIT_A(P) split_component<P>(v, nxt.ah[P], nxt.al[P])
 #define FFN_SPLIT_B(P) split_component<P>(v, nxt.bh[P], nxt.bl[P])
-#define FFN_NOTHING(P)
-#define FFN_PIN()                                                                              \
-    _Pragma("unroll") for (int k = 0; k < 16; ++k) {                                           \
+#define FFN_PIN(N, NV)                                                                         \
+    _Pragma("unroll") for (int k = 0; k < N; ++k) {                                            \
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                     \
-        __builtin_amdgcn_sched_group_barrier(0x002, BIAS ? 7 : 6, 0);                          \
+        __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);                                    \
     }
+        f32x4 v[8];
+        auto request = [&](int which) {
+            if (BULK) {
+                issue_stage(i + kStages, std::true_type{}, which);
+            } else {
+                if (i + kStages < steps) issue_stage(i + kStages, std::false_type{}, which);
+            }
+        };
+#define FFN_ONE(X, Y, P, Q) acc[P][Q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.X[P], cur.Y[Q], acc[P][Q], 0, 0, 0);
+        // (every group of this row-set fenced: left to the pins hipcc bursts the eight reads)
+        FFN_FENCE();
+        FFN_ONE(ah, bl, 0, 0) read_half(i + 1, a_row, 0, v, 0, 4);
+        FFN_FENCE();
+        FFN_ONE(ah, bl, 0, 1) read_half(i + 1, a_row, 0, v, 4, 8);
+        FFN_FENCE();
+        FFN_ONE(ah, bl, 0, 2) request(0);
+        FFN_FENCE();
+        FFN_ONE(ah, bl, 0, 3) request(1);
+        FFN_FENCE();
         if (BIAS) {
 #pragma unroll
             for (int t = 0; t < 8; ++t) bsum += v[t];
         }
-        FFN_PASS(ah, bl, FFN_SPLIT_A)
-        FFN_PIN()
-        read_half(i + 1, b_row, kHalfBytes, v);
-        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-        FFN_PASS(al, bh, FFN_SPLIT_B)
-        FFN_PIN()
-        FFN_PASS(ah, bh, FFN_NOTHING)
-#undef FFN_PASS
+        FFN_ROWSET(ah, bl, 1) FFN_SPLIT_A(0); FFN_SPLIT_A(1);
+        FFN_ROWSET(ah, bl, 2) FFN_SPLIT_A(2);
+        FFN_ROWSET(ah, bl, 3) FFN_SPLIT_A(3);
+        FFN_PIN(12, BIAS ? 9 : 8)
+        FFN_FENCE();
+        FFN_ONE(al, bh, 0, 0) read_half(i + 1, b_row, kHalfBytes, v, 0, 4);
+        FFN_FENCE();
+        FFN_ONE(al, bh, 0, 1) read_half(i + 1, b_row, kHalfBytes, v, 4, 8);
+        FFN_FENCE();
+        FFN_ONE(al, bh, 0, 2) FFN_ONE(al, bh, 0, 3)
+        FFN_FENCE();
+        FFN_ROWSET(al, bh, 1) FFN_SPLIT_B(0); FFN_SPLIT_B(1);
+        FFN_ROWSET(al, bh, 2) FFN_SPLIT_B(2);
+        FFN_ROWSET(al, bh, 3) FFN_SPLIT_B(3);
+        FFN_PIN(12, 8)
+        FFN_FENCE();
+        FFN_ROWSET(ah, bh, 0) FFN_ROWSET(ah, bh, 1) FFN_ROWSET(ah, bh, 2) FFN_ROWSET(ah, bh, 3)
+        FFN_FENCE();
+#undef FFN_FENCE
+#undef FFN_ROWSET
 #undef FFN_SPLIT_A
 #undef FFN_SPLIT_B
-#undef FFN_NOTHING
 #undef FFN_PIN
+#undef FFN_ONE
     };
     auto step = [&](int64_t i, Operands& cur, Operands& nxt) {
         if (i + 1 < steps) {
