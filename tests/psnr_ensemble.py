@@ -23,15 +23,17 @@ Fixtures of rounds 5 and 6 (reference halves, build container; HIP halves: scrip
         --report-interval 125 --anneal-steps 250 --threads 3 --seeds 24 \
         --out tests/golden/psnr_ensemble_reference_slow.json
     # config 3: full NeRF + a frozen voxel opacity model, 300 steps inside the crop phase (round 5: 6
-    # seeds; round 6 continued the same file with --resume --seeds 24 for as many seeds as the round's
-    # CPU-hours gave, `complete: false` says how many of the planned 24 it holds)
+    # seeds; round 6 continued the same file with --resume --seeds 24 to all 24 -- ~30 min per seed on 4
+    # threads, the last nine by two processes over disjoint seed ranges joined by
+    # tests/golden/merge_ensemble_parts.py: `computed_in_parallel_parts` in the fixture)
     python -m tests.psnr_ensemble reference --model nerf --opacity voxels --size 128 --cameras 20 \
         --val-cameras 4 --samples 128 --rays 1024 --steps 300 --crop-steps 1000 --report-interval 100 \
         --anneal-steps 150 --threads 4 --seeds 6 --out tests/golden/psnr_ensemble_reference_nerf.json
     # ... its first seed with --threads 2 --seeds 1 -> psnr_ensemble_reference_nerf_2threads.json
     # ... with --steps 100 --report-interval 10 --seeds 2 -> psnr_ensemble_reference_nerf_fine.json
     # config 3, slow-diverging (round 6): 4096 rays, lr 1e-4, 300 steps, a report every 25 (~2 h per
-    # seed on 3 threads of a busy 8-core container)
+    # seed on 3 threads of a busy 8-core container: the fixture holds the seeds the round's CPU-hours
+    # gave, `complete: false`; `compare` takes the means over the seeds both halves hold)
     python -m tests.psnr_ensemble reference --model nerf --opacity voxels --size 128 --cameras 20 \
         --val-cameras 4 --samples 128 --rays 4096 --lr 1e-4 --steps 300 --crop-steps 1000 \
         --report-interval 25 --anneal-steps 150 --threads 3 --seeds 8 --resume \
